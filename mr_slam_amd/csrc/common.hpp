@@ -1,0 +1,72 @@
+// common.hpp -- shared host-side plumbing of libmrslam_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "../../include/mrslam_hip.h"
+
+namespace mrs {
+
+void set_error(const char* fmt, ...);
+
+#define MRS_HIP_TRY(expr)                                                                   \
+    do {                                                                                    \
+        hipError_t e__ = (expr);                                                            \
+        if (e__ != hipSuccess) {                                                            \
+            ::mrs::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, \
+                             __LINE__);                                                     \
+            return MRS_ERR_HIP;                                                             \
+        }                                                                                   \
+    } while (0)
+
+#define MRS_REQUIRE(cond, msg)                                     \
+    do {                                                           \
+        if (!(cond)) {                                             \
+            ::mrs::set_error("bad argument: %s (%s)", msg, #cond); \
+            return MRS_ERR_ARG;                                    \
+        }                                                          \
+    } while (0)
+
+// Stream-ordered scratch buffer (hipMallocAsync): re-entrant, no hidden global state.
+struct Scratch {
+    void* p = nullptr;
+    hipStream_t s = nullptr;
+    ~Scratch() {
+        if (p) (void)hipFreeAsync(p, s);
+    }
+    int alloc(size_t bytes, hipStream_t stream) {
+        s = stream;
+        MRS_HIP_TRY(hipMallocAsync(&p, bytes ? bytes : 16, stream));
+        return MRS_OK;
+    }
+    template <class T>
+    T* as() const { return static_cast<T*>(p); }
+};
+
+// Device lookup table that reproduces the reference's sector() step function exactly
+// (built on the host with the host libm, see bev.hip).
+struct SectorLut {
+    float* d_thr = nullptr;  // [4][stride] ascending change points of q=|y|/|x| per quadrant
+    int* d_val = nullptr;    // [4][stride] sector value from thr[j] on
+    int stride = 0;
+    int cnt[4] = {0, 0, 0, 0};
+};
+
+}  // namespace mrs
+
+struct mrs_ctx {
+    int device = 0;
+    int num_cu = 0;
+    size_t lds_bytes = 0;
+    std::mutex mu;
+    std::map<int, mrs::SectorLut> sector_luts;  // keyed by num_sector
+    // device-resident constant tables for the correlation / Radon kernels (lazily built)
+    std::map<int, float*> twiddles;             // keyed by FFT length
+};

@@ -1,0 +1,130 @@
+"""oracle/pyoracle.py -- TEST INFRASTRUCTURE ONLY.
+
+ctypes front-end to oracle/liboracle.so (the CPU restatements) and, when present,
+oracle/_ref/libref_polar.so (the reference's own CPU polar rasteriser compiled in place).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_REF = None
+DROP = np.int32(-2**31)
+
+
+def build(quiet=True):
+    """(Re)build liboracle.so and, if /root/reference exists, _ref/."""
+    subprocess.run(["make", "-C", _HERE] + (["-s"] if quiet else []), check=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.orc_occupied_fingerprint.restype = C.c_uint64
+    return _LIB
+
+
+def ref_polar():
+    """The reference library, or None if it was never built (no /root/reference)."""
+    global _REF
+    if _REF is None:
+        path = os.path.join(_HERE, "_ref", "libref_polar.so")
+        if not os.path.exists(path):
+            return None
+        _REF = C.CDLL(path)
+    return _REF
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ----------------------------------------------------------------------------- polar BEV
+def bev_polar_indices(xyz_soa, max_length, max_height, R, S, H):
+    xyz = _f32(xyz_soa)
+    n = xyz.size // 3
+    ring = np.empty(n, np.int32); sector = np.empty(n, np.int32); height = np.empty(n, np.int32)
+    valid = np.empty(n, np.uint8)
+    lib().orc_bev_polar_indices(_p(xyz), n, max_length, max_height, R, S, H,
+                                _p(ring), _p(sector), _p(height), _p(valid))
+    return ring, sector, height, valid.astype(bool)
+
+
+def bev_polar(xyz_soa, max_length, max_height, R, S, H, enough_large=1):
+    xyz = _f32(xyz_soa)
+    n = xyz.size // 3
+    ring, sector, height, _ = bev_polar_indices(xyz, max_length, max_height, R, S, H)
+    out = np.zeros(3 * R * S * H * enough_large, np.float32)
+    lib().orc_bev_polar_scatter(_p(xyz), n, _p(ring), _p(sector), _p(height), R, S, H,
+                                enough_large, _p(out))
+    return out
+
+
+def ref_bev_polar(xyz_soa, max_length, max_height, R, S, H, enough_large=1):
+    r = ref_polar()
+    if r is None:
+        raise RuntimeError("oracle/_ref/libref_polar.so not built")
+    xyz = _f32(xyz_soa).copy()
+    n = xyz.size // 3
+    out = np.zeros(3 * R * S * H * enough_large, np.float32)
+    r.ref_polar_bev(_p(xyz), n, max_length, max_height, R, S, H, enough_large, _p(out))
+    return out
+
+
+def ref_bev_polar_indices(xyz_soa, max_length, max_height, R, S, H):
+    r = ref_polar()
+    if r is None:
+        raise RuntimeError("oracle/_ref/libref_polar.so not built")
+    xyz = _f32(xyz_soa).copy()
+    n = xyz.size // 3
+    ring = np.empty(n, np.int32); sector = np.empty(n, np.int32); height = np.empty(n, np.int32)
+    r.ref_polar_indices(_p(xyz), n, max_length, max_height, R, S, H,
+                        _p(ring), _p(sector), _p(height))
+    return ring, sector, height
+
+
+# ------------------------------------------------------------------------- Cartesian BEV
+def bev_cart_indices(xyz_soa, max_length, max_height, NX, NY, H):
+    xyz = _f32(xyz_soa)
+    n = xyz.size // 3
+    ix = np.empty(n, np.int32); iy = np.empty(n, np.int32); ih = np.empty(n, np.int32)
+    valid = np.empty(n, np.uint8)
+    lib().orc_bev_cart_indices(_p(xyz), n, max_length, max_height, NX, NY, H,
+                               _p(ix), _p(iy), _p(ih), _p(valid))
+    return ix, iy, ih, valid.astype(bool)
+
+
+def bev_cart(xyz_soa, max_length, max_height, NX, NY, H):
+    xyz = _f32(xyz_soa)
+    n = xyz.size // 3
+    ix, iy, ih, _ = bev_cart_indices(xyz, max_length, max_height, NX, NY, H)
+    out = np.zeros(3 * NX * NY * H, np.float32)
+    lib().orc_bev_cart_scatter(_p(xyz), n, _p(ix), _p(iy), _p(ih), NX, NY, H, _p(out))
+    return out
+
+
+def bev_feat(pts_cm, F, max_length, max_height, NX, NY, H):
+    pts = _f32(pts_cm)
+    n = pts.size // F
+    out = np.zeros(NX * NY * H * F, np.float32)
+    lib().orc_bev_feat(_p(pts), n, F, max_length, max_height, NX, NY, H, _p(out))
+    return out
+
+
+def occupied_fingerprint(out3):
+    out3 = _f32(out3)
+    cnt = C.c_int64(0)
+    h = lib().orc_occupied_fingerprint(_p(out3), C.c_int64(out3.size // 3), C.byref(cnt))
+    return int(h), int(cnt.value)
