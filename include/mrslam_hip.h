@@ -126,6 +126,85 @@ int mrs_bev_polar_host(mrs_ctx* ctx, const float* h_xyz_soa, int32_t n, const mr
 int mrs_bev_cart_host(mrs_ctx* ctx, const float* h_xyz_soa, int32_t n, const mrs_bev_cfg* cfg, float* h_out);
 int mrs_bev_feat_host(mrs_ctx* ctx, const float* h_pts_cm, int32_t n, const mrs_bev_cfg* cfg, float* h_out);
 
+/* ------------------------------------------------------------------------------------
+ * Radon sinogram (rows R1, R2)
+ * ---------------------------------------------------------------------------------- */
+typedef struct mrs_radon_plan mrs_radon_plan;
+
+/* Replaces the constructor torch_radon.ParallelBeam(det_count, angles, det_spacing, volume=None)
+ * (torch_radon/radon.py:139-167) for a fixed image size; volume centre 0, voxel size 1
+ * (torch_radon/volumes.py:13-21), which is how every MR_SLAM call site uses it
+ * (RING_ros/util.py:192-195,241-245).  h_angles: n_angles floats on the HOST (radians);
+ * their cos/sin are evaluated once, in double, when the plan is built. */
+int mrs_radon_plan_create(mrs_ctx* ctx, const float* h_angles, int32_t n_angles, int32_t det_count,
+                          float det_spacing, int32_t height, int32_t width, mrs_radon_plan** out_plan);
+int mrs_radon_plan_destroy(mrs_radon_plan* plan);
+
+/* R1 (+R2a): d_img float[batch][H][W] -> d_sino float[batch][n_angles][det_count].
+ * Replaces torch_radon_cuda.forward / radon_forward_cuda<float>, parallel beam
+ * (torch-radon/src/pytorch.cpp:42-81, src/forward.cu:12-178).
+ * d_sino_norm (optional, may be NULL; d_sino may be NULL when it is given) receives
+ * (S - mean(S)) / std(S) per image with the unbiased std: the fn.normalize(...) step of
+ * generate_RING (RING_ros/util.py:197), fused so the sinogram never makes a second trip. */
+int mrs_radon_forward(mrs_radon_plan* plan, const float* d_img, int32_t batch, float* d_sino,
+                      float* d_sino_norm, mrs_stream stream);
+
+/* (x - mean) / std over n_groups consecutive groups of group_len floats (unbiased std):
+ * torchvision fn.normalize(t, mean=t.mean(), std=t.std()) as RING_ros/util.py:197,339-340,429-430
+ * use it (RING++ normalises a whole [C,H,W] descriptor with ONE mean/std -> group_len=C*H*W).
+ * In-place allowed (d_out == d_in). */
+int mrs_normalize_groups(mrs_ctx* ctx, const float* d_in, float* d_out, int32_t n_groups,
+                         int32_t group_len, mrs_stream stream);
+
+/* ------------------------------------------------------------------------------------
+ * RING / RING++ descriptors and rotation correlation (rows R2, C1, C2, C3)
+ * ---------------------------------------------------------------------------------- */
+
+/* R2: TIRING = ortho FFT over the ANGLE axis of (already normalised) sinograms.
+ * Replaces torch.fft.fft2(x, dim=-2, norm="ortho") at RING_ros/util.py:198.
+ * d_x float[n_img][n_angles][det] -> d_out interleaved complex64 [n_img][n_angles][det]. */
+int mrs_fft_angle_r2c(mrs_ctx* ctx, const float* d_x, int32_t n_img, int32_t n_angles, int32_t det,
+                      float* d_out, mrs_stream stream);
+
+/* R2 (RING++): |ortho FFT over the DETECTOR axis|.  Replaces forward_row_fft,
+ * RING_ros/util.py:295-300 (first return value).  float[n_img][n_angles][det] both ways. */
+int mrs_fft_row_magnitude(mrs_ctx* ctx, const float* d_x, int32_t n_img, int32_t n_angles, int32_t det,
+                          float* d_out, mrs_stream stream);
+
+/* C1/C2 database sweep: every query against every database entry.
+ * Replaces the Python loop `for idx in range(len(pc_candidates)): fast_corr(...)`
+ * (RING_ros/main_RING.py:133-140 -> util.py:362-374; RING++: util.py:337-358 after its two
+ * fn.normalize calls, i.e. feed mrs_normalize_groups output).
+ * d_query float[n_query][channels][n_angles][det], d_db float[n_db][...]: NORMALISED REAL
+ * sinograms (RING) / normalised row-FFT magnitudes (RING++), the inverse transform of the
+ * spectra the reference stores.  d_dist float[n_query][n_db] = 1 - max / (0.15*C*A*D),
+ * d_angle int32[n_query][n_db] = A/2 - argmax(fftshift(corr)); d_corr (optional, may be NULL)
+ * float[n_query][n_db][n_angles] = the shifted correlation vector. */
+int mrs_ring_corr_sweep(mrs_ctx* ctx, const float* d_query, int32_t n_query, const float* d_db, int32_t n_db,
+                        int32_t channels, int32_t n_angles, int32_t det, float* d_dist, int32_t* d_angle,
+                        float* d_corr, mrs_stream stream);
+
+/* Pairwise form of the sweep: pair i = (d_a[i], d_b[i]); outputs have n_pairs entries
+ * (d_corr: float[n_pairs][n_angles]). */
+int mrs_ring_corr_pairs(mrs_ctx* ctx, const float* d_a, const float* d_b, int32_t n_pairs, int32_t channels,
+                        int32_t n_angles, int32_t det, float* d_dist, int32_t* d_angle, float* d_corr,
+                        mrs_stream stream);
+
+/* C1 literal: fast_corr(a, b) on complex spectra, pair by pair (RING_ros/util.py:362-374).
+ * d_a, d_b interleaved complex64 [n_pairs][channels][n_angles][det]; outputs per pair. */
+int mrs_ring_corr_spectra(mrs_ctx* ctx, const float* d_a, const float* d_b, int32_t n_pairs, int32_t channels,
+                          int32_t n_angles, int32_t det, float* d_dist, int32_t* d_angle, float* d_corr,
+                          mrs_stream stream);
+
+/* C3: solve_translation(query, positive, rot_angle) (RING_ros/util.py:388-423,488-506).
+ * d_query/d_positive float[n_pairs][channels][height][width] (RING sinograms, `positive`
+ * already row-rolled by the caller as main_RING.py:172-178 does); d_angles float[height]
+ * (linspace(0, 2*pi, height)); d_rot float[n_pairs].  d_xy_err float[n_pairs][3] = x, y,
+ * residual norm; d_shifts (optional) float[n_pairs][height] = the per-row integer shifts. */
+int mrs_ring_solve_translation(mrs_ctx* ctx, const float* d_query, const float* d_positive, int32_t n_pairs,
+                               int32_t channels, int32_t height, int32_t width, const float* d_angles,
+                               const float* d_rot, float* d_xy_err, float* d_shifts, mrs_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

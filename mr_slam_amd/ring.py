@@ -1,0 +1,197 @@
+"""RING / RING++ host logic over the C ABI: Radon plans, descriptor generation, rotation
+correlation and translation solving.  Function names and argument meaning mirror
+LoopDetection/src/RING_ros/util.py so the parity tests read like the reference's call sites.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, bev
+from ._lib import OUT_COMPACT
+
+# RING_ros/config.py:7-11
+NUM_RING = 120
+NUM_SECTOR = 120
+NUM_HEIGHT = 1
+MAX_LENGTH = 1
+MAX_HEIGHT = 1
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise _lib.MrsError("expected a device tensor (no CPU fallback)")
+    return t.device.index or 0
+
+
+class RadonPlan:
+    """Parallel-beam geometry bound to one device (C ABI mrs_radon_plan_*)."""
+
+    def __init__(self, det_count, angles, det_spacing, height, width, device=0):
+        ang = np.ascontiguousarray(np.asarray(angles, dtype=np.float32))
+        self.n_angles, self.det, self.h, self.w = int(ang.size), int(det_count), int(height), int(width)
+        self.device = device
+        self._h = C.c_void_p()
+        _lib.check(_lib.load().mrs_radon_plan_create(_lib.ctx(device), _lib.ptr(ang), self.n_angles, self.det,
+                                                     C.c_float(det_spacing), self.h, self.w, C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.load().mrs_radon_plan_destroy(self._h)
+        except Exception:
+            pass
+
+    def forward(self, img, raw=True, normalized=False):
+        """img float32 [B,H,W] (device, contiguous) -> (sino [B,A,D] | None, sino_norm | None)."""
+        d = _dev(img)
+        assert img.dtype == torch.float32 and img.is_contiguous() and img.shape[-2:] == (self.h, self.w)
+        B = img.numel() // (self.h * self.w)
+        sino = torch.empty((B, self.n_angles, self.det), dtype=torch.float32, device=img.device) if raw else None
+        norm = torch.empty((B, self.n_angles, self.det), dtype=torch.float32, device=img.device) if normalized else None
+        _lib.check(_lib.load().mrs_radon_forward(self._h, _lib.ptr(img), B,
+                                                 _lib.ptr(sino) if raw else None,
+                                                 _lib.ptr(norm) if normalized else None, _lib.current_stream(d)))
+        return sino, norm
+
+
+_plans = {}
+
+
+def ring_plan(device=0, num_ring=NUM_RING, num_sector=NUM_SECTOR):
+    """The geometry generate_RING builds (util.py:191-192): det_count = num_sector,
+    angles = linspace(0, 2*pi, num_ring) (endpoint included), image num_ring x num_sector."""
+    key = (device, num_ring, num_sector)
+    if key not in _plans:
+        angles = np.linspace(0, 2 * np.pi, num_ring).astype(np.float32)
+        _plans[key] = RadonPlan(num_sector, angles, 1.0, num_ring, num_sector, device)
+    return _plans[key]
+
+
+def normalize(x, group_len=None):
+    """fn.normalize(t, mean=t.mean(), std=t.std()) per group of `group_len` floats
+    (default: per leading-dim entry)."""
+    d = _dev(x)
+    x = x.contiguous()
+    gl = int(group_len or x[0].numel())
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().mrs_normalize_groups(_lib.ctx(d), _lib.ptr(x), _lib.ptr(out), x.numel() // gl, gl,
+                                                _lib.current_stream(d)))
+    return out
+
+
+def fft_angle(x):
+    """torch.fft.fft2(x, dim=-2, norm='ortho') of real [..., A, D] (util.py:198) -> complex64."""
+    d = _dev(x)
+    x = x.contiguous()
+    A, D = x.shape[-2:]
+    out = torch.empty(x.shape + (2,), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().mrs_fft_angle_r2c(_lib.ctx(d), _lib.ptr(x), x.numel() // (A * D), A, D, _lib.ptr(out),
+                                             _lib.current_stream(d)))
+    return torch.view_as_complex(out)
+
+
+def forward_row_fft(x):
+    """util.py:295-300 (magnitude only): |fft along the detector axis|, ortho."""
+    d = _dev(x)
+    x = x.contiguous()
+    A, D = x.shape[-2:]
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().mrs_fft_row_magnitude(_lib.ctx(d), _lib.ptr(x), x.numel() // (A * D), A, D,
+                                                 _lib.ptr(out), _lib.current_stream(d)))
+    return out
+
+
+def ring_descriptors(xyz, offsets, num_ring=NUM_RING, num_sector=NUM_SECTOR, want_bev=False):
+    """Batched generate_RING front half (util.py:174-197): Cartesian BEV -> Radon -> normalise.
+    Returns (bev | None, sinogram [B,A,D], normalised sinogram [B,A,D])."""
+    d = _dev(xyz)
+    img = bev.cart_bev(xyz, offsets, MAX_LENGTH, MAX_HEIGHT, num_ring, num_sector, 1, layout=OUT_COMPACT)
+    img = img.view(-1, num_ring, num_sector)
+    sino, norm = ring_plan(d, num_ring, num_sector).forward(img, raw=True, normalized=True)
+    return (img if want_bev else None), sino, norm
+
+
+def generate_RING(pc, device="cuda:0"):
+    """util.py:174-200 for one pre-processed cloud [n,3]: returns (pc_bev [1,R,S] numpy,
+    pc_RING [1,A,D] cpu tensor, pc_TIRING complex64 [1,A,D] cpu tensor)."""
+    xyz, offs = bev.pack_scans([np.asarray(pc)[:, 0:3]], device)
+    img, sino, norm = ring_descriptors(xyz, offs, want_bev=True)
+    tiring = fft_angle(norm)
+    return img.cpu().numpy(), sino.cpu(), tiring.cpu()
+
+
+def corr_sweep(query, db, want_corr=False):
+    """C1/C2 sweep: query [Q,C,A,D], db [N,C,A,D] normalised real descriptors (device).
+    Returns (dist [Q,N] float32, angle [Q,N] int32[, corr [Q,N,A]])."""
+    d = _dev(query)
+    query, db = query.contiguous(), db.contiguous()
+    Q, Cc, A, D = query.shape
+    N = db.shape[0]
+    assert db.shape[1:] == query.shape[1:]
+    dist = torch.empty((Q, N), dtype=torch.float32, device=query.device)
+    ang = torch.empty((Q, N), dtype=torch.int32, device=query.device)
+    corr = torch.empty((Q, N, A), dtype=torch.float32, device=query.device) if want_corr else None
+    _lib.check(_lib.load().mrs_ring_corr_sweep(_lib.ctx(d), _lib.ptr(query), Q, _lib.ptr(db), N, Cc, A, D,
+                                               _lib.ptr(dist), _lib.ptr(ang),
+                                               _lib.ptr(corr) if want_corr else None, _lib.current_stream(d)))
+    return (dist, ang, corr) if want_corr else (dist, ang)
+
+
+def corr_pairs(a, b, out=None):
+    """Pairwise C1/C2: a, b [P,C,A,D] normalised real descriptors -> (dist [P], angle [P])."""
+    d = _dev(a)
+    a, b = a.contiguous(), b.contiguous()
+    P, Cc, A, D = a.shape
+    assert b.shape == a.shape
+    dist, ang = out if out is not None else (torch.empty(P, dtype=torch.float32, device=a.device),
+                                             torch.empty(P, dtype=torch.int32, device=a.device))
+    _lib.check(_lib.load().mrs_ring_corr_pairs(_lib.ctx(d), _lib.ptr(a), _lib.ptr(b), P, Cc, A, D, _lib.ptr(dist),
+                                               _lib.ptr(ang), None, _lib.current_stream(d)))
+    return dist, ang
+
+
+def fast_corr(a, b, device="cuda:0", want_corr=False):
+    """util.py:362-374 on TIRING spectra a, b (complex64 [C,A,D], host or device).
+    Returns (dist, angle) as numpy scalars like the reference."""
+    a = torch.as_tensor(a).to(device).to(torch.complex64).contiguous()
+    b = torch.as_tensor(b).to(device).to(torch.complex64).contiguous()
+    Cc, A, D = a.shape
+    d = _dev(a)
+    dist = torch.empty(1, dtype=torch.float32, device=a.device)
+    ang = torch.empty(1, dtype=torch.int32, device=a.device)
+    corr = torch.empty(A, dtype=torch.float32, device=a.device) if want_corr else None
+    _lib.check(_lib.load().mrs_ring_corr_spectra(_lib.ctx(d), _lib.ptr(torch.view_as_real(a)),
+                                                 _lib.ptr(torch.view_as_real(b)), 1, Cc, A, D, _lib.ptr(dist),
+                                                 _lib.ptr(ang), _lib.ptr(corr) if want_corr else None,
+                                                 _lib.current_stream(d)))
+    out = (dist.cpu().numpy()[0], ang.cpu().numpy()[0])
+    return out + (corr.cpu().numpy(),) if want_corr else out
+
+
+def fast_corr_RINGplusplus(a, b, device="cuda:0"):
+    """util.py:337-358 on RING++ TIRING magnitudes a, b (float32 [C,A,D])."""
+    a = torch.as_tensor(a, dtype=torch.float32).to(device).contiguous()
+    b = torch.as_tensor(b, dtype=torch.float32).to(device).contiguous()
+    an = normalize(a[None])
+    bn = normalize(b[None])
+    dist, ang = corr_sweep(an, bn)
+    return dist.cpu().numpy()[0, 0], ang.cpu().numpy()[0, 0]
+
+
+def solve_translation(query, positive, rot_angle, device="cuda:0", want_shifts=False):
+    """util.py:388-423: query, positive float32 [C,H,W]; returns (x, y, error)."""
+    q = torch.as_tensor(query, dtype=torch.float32).to(device).contiguous()
+    p = torch.as_tensor(positive, dtype=torch.float32).to(device).contiguous()
+    Cc, H, W = q.shape
+    d = _dev(q)
+    angles = torch.from_numpy(np.linspace(0, 2 * np.pi, H).astype(np.float32)).to(q.device)
+    rot = torch.tensor([float(rot_angle)], dtype=torch.float32, device=q.device)
+    res = torch.empty(3, dtype=torch.float32, device=q.device)
+    sh = torch.empty(H, dtype=torch.float32, device=q.device) if want_shifts else None
+    _lib.check(_lib.load().mrs_ring_solve_translation(_lib.ctx(d), _lib.ptr(q), _lib.ptr(p), 1, Cc, H, W,
+                                                      _lib.ptr(angles), _lib.ptr(rot), _lib.ptr(res),
+                                                      _lib.ptr(sh) if want_shifts else None, _lib.current_stream(d)))
+    r = res.cpu().numpy()
+    out = (r[0:1].copy(), r[1:2].copy(), r[2])
+    return out + (sh.cpu().numpy(),) if want_shifts else out

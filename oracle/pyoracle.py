@@ -128,3 +128,64 @@ def occupied_fingerprint(out3):
     cnt = C.c_int64(0)
     h = lib().orc_occupied_fingerprint(_p(out3), C.c_int64(out3.size // 3), C.byref(cnt))
     return int(h), int(cnt.value)
+
+
+# ---------------------------------------------------------------------------------- Radon
+def radon_parallel(img, angles, det, spacing=1.0):
+    """img [B,H,W] or [H,W] float32 -> sinogram [B,n_angles,det] (orc_radon_parallel)."""
+    img = _f32(img)
+    squeeze = img.ndim == 2
+    if squeeze:
+        img = img[None]
+    B, H, W = img.shape
+    ang = _f32(angles)
+    out = np.empty((B, ang.size, det), np.float32)
+    lib().orc_radon_parallel_batch(_p(img), B, H, W, _p(ang), ang.size, det, C.c_float(spacing), _p(out))
+    return out[0] if squeeze else out
+
+
+_SYM = None
+
+
+def ref_symbolic():
+    """The reference's analytic Radon checker (torch-radon/src/symbolic.cpp), or None."""
+    global _SYM
+    if _SYM is None:
+        path = os.path.join(_HERE, "_ref", "libref_symbolic.so")
+        if not os.path.exists(path):
+            return None
+        _SYM = C.CDLL(path)
+        _SYM.ref_sym_create.restype = C.c_void_p
+    return _SYM
+
+
+class RefSymbolicFunction:
+    """Mirror of torch_radon_cuda.SymbolicFunction as the reference tests use it
+    (torch-radon/tests/utils.py:17-32)."""
+
+    def __init__(self, h, w):
+        self._l = ref_symbolic()
+        if self._l is None:
+            raise RuntimeError("oracle/_ref/libref_symbolic.so not built")
+        self._f = C.c_void_p(self._l.ref_sym_create(C.c_float(h), C.c_float(w)))
+
+    def __del__(self):
+        if getattr(self, "_f", None):
+            self._l.ref_sym_destroy(self._f)
+
+    def add_gaussian(self, k, cx, cy, a, b):
+        self._l.ref_sym_add_gaussian(self._f, *(C.c_float(v) for v in (k, cx, cy, a, b)))
+
+    def add_ellipse(self, k, cx, cy, r, a):
+        self._l.ref_sym_add_ellipse(self._f, *(C.c_float(v) for v in (k, cx, cy, r, a)))
+
+    def discretize(self, h, w):
+        out = np.zeros((h, w), np.float32)
+        self._l.ref_sym_discretize(self._f, _p(out), h, w)
+        return out
+
+    def forward(self, angles, det, spacing=1.0):
+        ang = _f32(angles)
+        out = np.zeros((ang.size, det), np.float32)
+        self._l.ref_sym_forward(self._f, det, C.c_float(spacing), _p(ang), ang.size, _p(out))
+        return out

@@ -1,0 +1,205 @@
+"""GPU parity suite: Radon, RING/RING++ descriptors, rotation correlation, translation."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available()
+    from mr_slam_amd import _lib
+    _lib.load()
+    return "cuda:0"
+
+
+ANG = np.linspace(0, 2 * np.pi, 120).astype(np.float32)
+
+
+def _bev_images(n, seed=0):
+    """Sparse positive max-z style images like the Cartesian BEV produces."""
+    rng = np.random.default_rng(seed)
+    img = rng.uniform(0, 0.2, size=(n, 120, 120)).astype(np.float32)
+    img[rng.uniform(size=img.shape) > 0.15] = 0
+    return img
+
+
+def test_radon_matches_oracle_bit_exact(dev, oracle):
+    import torch
+    from mr_slam_amd import ring
+    img = _bev_images(5)
+    img[3] = 0                                    # empty image
+    img[4] = np.random.default_rng(9).normal(size=(120, 120)).astype(np.float32)  # dense, signed
+    plan = ring.RadonPlan(120, ANG, 1.0, 120, 120)
+    sino, _ = plan.forward(torch.from_numpy(img).to(dev))
+    want = oracle.radon_parallel(img, ANG, 120, 1.0)
+    got = sino.cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)
+    assert np.array_equal(got, want), "expected bit-identical results (shared op order)"
+
+
+@pytest.mark.parametrize("cfg", [(128, 128, 79, 2.0), (128, 128, 243, 0.5), (64, 100, 90, 1.3), (120, 120, 120, 1.0)])
+def test_radon_other_geometries(dev, oracle, cfg):
+    import torch
+    from mr_slam_amd.compat import torch_radon
+    H, W, det, spacing = cfg
+    rng = np.random.default_rng(3)
+    x = rng.uniform(0, 1, size=(2, 3, H, W)).astype(np.float32)
+    ang = np.linspace(0, np.pi, 64, endpoint=False).astype(np.float32)
+    radon = torch_radon.ParallelBeam(det, ang, spacing)
+    y = radon.forward(torch.from_numpy(x).to(dev))
+    assert tuple(y.shape) == (2, 3, 64, det)        # tests/test_torch.py:22-42 shape contract
+    want = oracle.radon_parallel(x.reshape(-1, H, W), ang, det, spacing).reshape(2, 3, 64, det)
+    np.testing.assert_allclose(y.cpu().numpy(), want, rtol=1e-6, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        radon.forward(torch.from_numpy(x))          # CPU tensor rejected like pytorch.cpp:16-20
+
+
+def test_radon_golden_and_analytic_bound(dev, golden_dir):
+    """HIP sinogram vs the reference's analytic sinogram (fixture), bound of
+    torch-radon/tests/test_parallel_beam.py:70."""
+    import os
+    import torch
+    from mr_slam_amd import ring
+    g = np.load(os.path.join(golden_dir, "radon_ring120.npz"))
+    plan = ring.RadonPlan(120, g["angles"], 1.0, 120, 120)
+    s, _ = plan.forward(torch.from_numpy(g["image"][None]).to(dev))
+    s = s.cpu().numpy()[0]
+    np.testing.assert_allclose(s, g["sino_oracle"], rtol=1e-6, atol=1e-6)
+    err = np.linalg.norm(g["sino_analytic"] - s) / (np.linalg.norm(g["sino_analytic"]) + 1e-6)
+    assert err < 2e-3 * (512 / 120) * (512 / 120)
+
+
+def test_generate_ring_matches_restatement(dev, oracle):
+    """generate_RING (util.py:174-200): BEV -> Radon -> normalise -> FFT over the angle axis."""
+    from mr_slam_amd import ring, synth
+    from oracle import corr_oracle as K
+    pc = synth.lidar_scan(21, 30000)
+    bev_img, sino, tiring = ring.generate_RING(pc)
+    want_bev = oracle.bev_cart(synth.to_soa(pc), 1, 1, 120, 120, 1).reshape(-1, 3)[:, 2].reshape(1, 120, 120)
+    np.testing.assert_array_equal(bev_img, want_bev)
+    want_sino = oracle.radon_parallel(want_bev, ANG, 120, 1.0)
+    np.testing.assert_allclose(sino.numpy(), want_sino, rtol=1e-6, atol=1e-6)
+    want_t = K.tiring_from_sinogram(want_sino).numpy()
+    scale = np.abs(want_t).max()
+    assert np.abs(tiring.numpy() - want_t).max() < 2e-5 * scale
+
+
+def test_normalize_and_row_fft(dev):
+    import torch
+    from mr_slam_amd import ring
+    from oracle import corr_oracle as K
+    rng = np.random.default_rng(5)
+    x = np.abs(rng.normal(size=(2, 6, 120, 120))).astype(np.float32)
+    t = torch.from_numpy(x).to(dev)
+    n = ring.normalize(t).cpu().numpy()
+    for b in range(2):
+        np.testing.assert_allclose(n[b], K.ring_normalize(x[b]).numpy(), rtol=2e-5, atol=2e-6)
+    m = ring.forward_row_fft(t).cpu().numpy()
+    want, _ = K.forward_row_fft(x)
+    np.testing.assert_allclose(m, want.numpy(), rtol=1e-4, atol=2e-5)
+
+
+def _ring_db(n, seed):
+    """n normalised sinograms (device-independent numpy) built from random sparse images."""
+    from oracle import pyoracle as O
+    from oracle import corr_oracle as K
+    sino = O.radon_parallel(_bev_images(n, seed), ANG, 120, 1.0)
+    return np.stack([K.ring_normalize(s[None]).numpy() for s in sino])   # [n,1,120,120]
+
+
+def test_corr_sweep_matches_fast_corr_restatement(dev):
+    import torch
+    from mr_slam_amd import ring
+    from oracle import corr_oracle as K
+    db = _ring_db(6, 1)
+    rng = np.random.default_rng(2)
+    q = np.stack([np.roll(db[1], 17, axis=1) + 0.01 * rng.normal(size=db[1].shape).astype(np.float32),
+                  db[4], np.roll(db[5], -33, axis=1)]).astype(np.float32)
+    q = np.stack([K.ring_normalize(v).numpy() for v in q])
+    dist, ang, corr = ring.corr_sweep(torch.from_numpy(q).to(dev), torch.from_numpy(db).to(dev), want_corr=True)
+    dist, ang, corr = dist.cpu().numpy(), ang.cpu().numpy(), corr.cpu().numpy()
+    for i in range(q.shape[0]):
+        a = torch.fft.fft2(torch.from_numpy(q[i]), dim=-2, norm="ortho")
+        for j in range(db.shape[0]):
+            b = torch.fft.fft2(torch.from_numpy(db[j]), dim=-2, norm="ortho")
+            d, g, c = K.fast_corr(a, b)
+            np.testing.assert_allclose(corr[i, j], c, rtol=1e-4, atol=1e-3)
+            assert abs(dist[i, j] - float(d)) < 1e-5
+            top2 = np.sort(c)[-2:]
+            if top2[1] - top2[0] > 1e-3 * top2[1]:      # unambiguous maximum
+                assert ang[i, j] == g
+    assert ang[0, 1] == -17 and ang[1, 4] == 0 and ang[2, 5] == 33   # query rolled by +k <=> angle -k
+    assert dist[1, 4] == dist.min()
+
+
+def test_fast_corr_literal_spectra(dev):
+    """The drop-in fast_corr(a, b) on complex TIRING tensors, incl. non-Hermitian input."""
+    import torch
+    from mr_slam_amd import ring
+    from oracle import corr_oracle as K
+    db = _ring_db(2, 4)
+    a = torch.fft.fft2(torch.from_numpy(db[0]), dim=-2, norm="ortho")
+    b = torch.fft.fft2(torch.from_numpy(np.roll(db[0], 9, axis=1)), dim=-2, norm="ortho")
+    for (u, v) in ((a, b), (b, a), (a, a)):
+        d, g, c = ring.fast_corr(u, v, want_corr=True)
+        wd, wg, wc = K.fast_corr(u, v)
+        np.testing.assert_allclose(c, wc, rtol=1e-4, atol=1e-3)
+        assert g == wg and abs(d - float(wd)) < 1e-5
+    rng = np.random.default_rng(6)
+    z1 = torch.from_numpy((rng.normal(size=(2, 120, 120)) + 1j * rng.normal(size=(2, 120, 120))).astype(np.complex64))
+    z2 = torch.from_numpy((rng.normal(size=(2, 120, 120)) + 1j * rng.normal(size=(2, 120, 120))).astype(np.complex64))
+    d, g, c = ring.fast_corr(z1, z2, want_corr=True)
+    wd, wg, wc = K.fast_corr(z1, z2)
+    np.testing.assert_allclose(c, wc, rtol=2e-4, atol=2e-3)
+
+
+def test_fast_corr_ringplusplus(dev):
+    from mr_slam_amd import ring
+    from oracle import corr_oracle as K
+    rng = np.random.default_rng(7)
+    a = np.abs(rng.normal(size=(6, 120, 120))).astype(np.float32)
+    b = (np.roll(a, 23, axis=1) + 0.02 * np.abs(rng.normal(size=a.shape))).astype(np.float32)
+    d, g = ring.fast_corr_RINGplusplus(a, b)
+    wd, wg, _ = K.fast_corr_ringplusplus(a, b)
+    assert g == wg and abs(d - float(wd)) < 2e-5
+
+
+def test_solve_translation(dev):
+    from mr_slam_amd import ring
+    from oracle import corr_oracle as K
+    from oracle import pyoracle as O
+    img = _bev_images(1, 8)[0]
+    shifted = np.roll(np.roll(img, 5, axis=0), -3, axis=1)
+    q = O.radon_parallel(img, ANG, 120, 1.0)[None]
+    p = O.radon_parallel(shifted, ANG, 120, 1.0)[None]
+    x, y, err, sh = ring.solve_translation(q, p, 0.3, want_shifts=True)
+    wx, wy, werr, wsh = K.solve_translation(q, p, 0.3)
+    assert (sh == wsh).mean() > 0.97            # integer row shifts (ties aside)
+    if (sh == wsh).all():
+        assert abs(x[0] - wx.item()) < 1e-3 and abs(y[0] - wy.item()) < 1e-3 and abs(err - werr.item()) < 1e-2
+
+
+def test_full_size_pipeline_properties(dev):
+    """BASELINE size: 120k-point scans -> descriptors; rotating a scan by k*3 degrees about z
+    rolls its sinogram, so the sweep must report that rotation and dist(self) ~ minimal."""
+    import torch
+    from mr_slam_amd import bev, ring, synth
+    base = synth.lidar_scan(31, metric=True)
+    scans = []
+    for k in (0, 10, 33):
+        th = np.deg2rad(3.0 * k)
+        R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]], np.float32)
+        scans.append(synth.preprocess(base @ R.T))
+    scans.append(synth.lidar_scan(77))
+    xyz, offs = bev.pack_scans(scans, dev)
+    _, sino, norm = ring.ring_descriptors(xyz, offs)
+    assert torch.isfinite(norm).all()
+    d, a = ring.corr_sweep(norm[:1, None], norm[:, None])
+    d, a = d.cpu().numpy()[0], a.cpu().numpy()[0]
+    assert d[0] < d[1] < d[3] and d[2] < d[3]
+    assert a[0] == 0 and abs(abs(a[1]) - 10) <= 1 and abs(abs(a[2]) - 33) <= 1
+    # determinism
+    d2, a2 = ring.corr_sweep(norm[:1, None], norm[:, None])
+    assert np.array_equal(d2.cpu().numpy()[0], d) and np.array_equal(a2.cpu().numpy()[0], a)
