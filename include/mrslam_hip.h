@@ -205,6 +205,72 @@ int mrs_ring_solve_translation(mrs_ctx* ctx, const float* d_query, const float* 
                                int32_t channels, int32_t height, int32_t width, const float* d_angles,
                                const float* d_rot, float* d_xy_err, float* d_shifts, mrs_stream stream);
 
+/* ------------------------------------------------------------------------------------
+ * GICP refinement (rows G2-G6), batched over independent submap pairs
+ * ---------------------------------------------------------------------------------- */
+typedef struct mrs_gicp_batch mrs_gicp_batch;
+
+/* Parameters with fast_gicp's names and defaults (upstream include/fast_gicp/gicp/
+ * {fast_gicp.hpp,lsq_registration.hpp}).  Setters they replace:
+ * setCorrespondenceRandomness, setMaxCorrespondenceDistance, setMaximumIterations,
+ * setRotationEpsilon, setTransformationEpsilon (global_manager.cpp:2437-2442,
+ * main_RING.py:93-94).  setNumThreads has no meaning on the GPU and is accepted and ignored
+ * by the host-side mirrors. */
+typedef struct mrs_gicp_params {
+    int32_t k_correspondences;          /* neighbours for the covariances (20; Mapping: 15)   */
+    int32_t max_iterations;             /* outer LM iterations (64; Mapping: icp_iters = 50)  */
+    int32_t lm_max_iterations;          /* inner LM trials per iteration (10)                  */
+    int32_t force_iterations;           /* > 0: run exactly this many outer iterations with the
+                                           convergence test disabled (benchmark timing only)   */
+    double max_correspondence_distance; /* DBL_MAX = unbounded (RING: 5.0, Mapping: 100)       */
+    double rotation_epsilon;            /* 2e-3                                                */
+    double transformation_epsilon;      /* 5e-4 (Mapping: 1e-3)                                */
+    double lm_init_lambda_factor;       /* 1e-9                                                */
+} mrs_gicp_params;
+
+void mrs_gicp_default_params(mrs_gicp_params* p);
+
+/* One handle aligns n_pairs independent (source, target) pairs together.
+ * Replaces n_pairs instances of fast_gicp::FastGICP<PointXYZI,PointXYZI> / pygicp.FastGICP
+ * (factory at global_manager.cpp:2416-2461; pygicp use at main_RING.py:81-104). */
+int mrs_gicp_batch_create(mrs_ctx* ctx, int32_t n_pairs, mrs_gicp_batch** out);
+int mrs_gicp_batch_destroy(mrs_gicp_batch* h);
+int mrs_gicp_batch_set_params(mrs_gicp_batch* h, const mrs_gicp_params* p);
+
+/* setInputSource (which = 0) / setInputTarget (which = 1) for every pair at once.
+ * d_points: packed DEVICE array of points, x y z in the first three of every `stride_floats`
+ * floats (3 = pygicp's Nx3, 4 = pcl::PointXYZ, 8 = pcl::PointXYZI); h_offsets: HOST
+ * int64[n_pairs+1] point offsets of the pairs.  Copies into the library's float4 layout. */
+int mrs_gicp_batch_set_clouds(mrs_gicp_batch* h, int32_t which, const float* d_points, int32_t stride_floats,
+                              const int64_t* h_offsets, mrs_stream stream);
+
+/* G2: FastGICP::calculate_covariances (brute-force kNN, PLANE regularisation).  Called lazily
+ * by align; exposed so that it can be timed / cached per submap.  d_knn_out (optional, may be
+ * NULL): int32[total_points][k] neighbour indices (cloud-local, ascending distance). */
+int mrs_gicp_batch_compute_covariances(mrs_gicp_batch* h, int32_t which, int32_t* d_knn_out, mrs_stream stream);
+/* h_cov6: double[total_points][6] = xx xy xz yy yz zz of the regularised 3x3 block */
+int mrs_gicp_batch_get_covariances(mrs_gicp_batch* h, int32_t which, double* h_cov6);
+
+/* align(output, guess): h_guess double[n_pairs][16] row-major 4x4 (NULL = identity; narrowed to
+ * float like the reference's Eigen::Matrix4f guess), h_final double[n_pairs][16] =
+ * getFinalTransformation() (float precision), h_converged = hasConverged(), h_iterations =
+ * outer iterations used, h_hessian double[n_pairs][36] (each optional).  Synchronises `stream`. */
+int mrs_gicp_batch_align(mrs_gicp_batch* h, const double* h_guess, double* h_final, int32_t* h_converged,
+                         int32_t* h_iterations, double* h_hessian, mrs_stream stream);
+
+/* G3+G4 once at given poses (kernel-level parity hook): H double[n_pairs][36], b [n_pairs][6],
+ * err [n_pairs]; d_corr (optional) int32[total source points] correspondences or -1. */
+int mrs_gicp_batch_linearize(mrs_gicp_batch* h, const double* h_poses, double* h_H, double* h_b, double* h_err,
+                             int32_t* d_corr, mrs_stream stream);
+
+/* G6: pcl::Registration::getFitnessScore(max_range) at the given poses
+ * (global_manager.cpp:2058-2071, main_RING.py:100). */
+int mrs_gicp_batch_fitness(mrs_gicp_batch* h, const double* h_poses, double max_range, double* h_scores,
+                           mrs_stream stream);
+
+/* number of brute-force NN passes the last align() issued (for iterations/s accounting) */
+double mrs_gicp_batch_last_nn_passes(const mrs_gicp_batch* h);
+
 #ifdef __cplusplus
 }
 #endif

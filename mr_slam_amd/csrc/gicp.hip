@@ -1,0 +1,896 @@
+// gicp.hip -- batched GICP refinement for gfx950.
+//
+// Behaviour reproduced: fast_gicp's FastGICP (un-vendored submodule of the reference; algorithm
+// per SURVEY.md App. A.2) as configured at Mapping/src/global_manager/src/global_manager.cpp:
+// 2435-2443 and LoopDetection/src/RING_ros/main_RING.py:81-104:
+//   G2 calculate_covariances : kNN (k) in the own cloud, covariance of the neighbours (double),
+//                              PLANE regularisation U diag(1,1,1e-3) V^T == I - 0.999 n n^T
+//   G3 update_correspondences: 1-NN of the float-transformed source point, reject d^2 >= max^2,
+//                              M_i = (C_B + R C_A R^T)^-1
+//   G4 linearize             : e = b - T a, J = [skew(T a) | -I], H += J^T M J, b += J^T M e
+//   G5 LM optimiser          : LsqRegistration::step_lm / is_converged / se3_exp
+//   G6 getFitnessScore       : mean squared NN distance with d^2 <= max_range
+//
+// Design: kd-tree-free.  Every nearest-neighbour query is an exact brute-force scan: target
+// points are staged through LDS in tiles of 1024 float4 and read back as wave-wide broadcasts
+// (one ds_read_b128 per candidate per wave), two source points per lane, ~7 VALU ops per
+// (source, target) pair.  That scan is VALU-bound (N*M*7 lane-ops per pass, 1.0e11 at 120k x 120k);
+// the per-point 3x3 algebra and the 28-term fp64 reductions (wave __shfl butterflies -> one
+// partial per workgroup -> fixed-order final sum) are noise next to it.  All pairs of a batch
+// advance together; the Levenberg-Marquardt bookkeeping runs on the device (one lane per
+// pair), so the host only polls a "pairs still active" counter.  The evaluation at an accepted
+// candidate is reused as the next iteration's linearisation, which halves the number of NN
+// passes per iteration relative to the reference without changing results.
+#include <cfloat>
+#include <cmath>
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int kTile = 1024;      // target points per LDS tile
+constexpr int kNNThreads = 256;  // lanes per workgroup
+constexpr int kPts = 2;          // source points per lane
+constexpr int kTerms = 28;       // 21 (H upper) + 6 (b) + 1 (error)
+
+struct LmState {
+    double x[16];      // accepted pose (row-major 4x4)
+    double xi[16];     // candidate pose being evaluated
+    double delta[16];  // last increment
+    double H[36];      // linearisation at x
+    double b[6];
+    double d[6];       // last LM step
+    double y0;
+    double lambda;
+    double nu;
+    double final_H[36];
+    int phase;         // 0: first evaluation at the guess, 1: LM trial, 2: done
+    int inner;
+    int outer;
+    int trials;
+    int converged;
+    int failed;
+    int active;
+    int pad;
+};
+
+struct GicpParams {
+    double max_corr2;     // squared correspondence distance threshold (inf if unbounded)
+    double rot_eps, trans_eps;
+    double lm_init_factor;
+    int max_iter;
+    int lm_max_iter;
+    int force_iters;      // >0: run exactly this many outer iterations, no convergence test
+    int k;
+};
+
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float dist2(float qx, float qy, float qz, const float4& b)
+{
+    const float dx = qx - b.x, dy = qy - b.y, dz = qz - b.z;
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
+
+// Exact 1-NN of P query points per lane over tgt[0..m): returns squared distance + index
+// (ties -> the smaller index).  Whole workgroup must call it together.
+template <int P>
+__device__ __forceinline__ void nn_scan(const float4* __restrict__ tgt, int m, const float (&qx)[P],
+                                        const float (&qy)[P], const float (&qz)[P], float4* tile,
+                                        float (&best)[P], int (&bidx)[P])
+{
+    int grp[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) { best[p] = INFINITY; grp[p] = -1; }
+    for (int t0 = 0; t0 < m; t0 += kTile) {
+        const int cnt = min(kTile, m - t0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < kTile; i += kNNThreads)
+            tile[i] = i < cnt ? tgt[t0 + i] : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
+        __syncthreads();
+        const int groups = (cnt + 7) >> 3;
+        for (int g = 0; g < groups; ++g) {
+            float4 c[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) c[u] = tile[8 * g + u];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                float d[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) d[u] = dist2(qx[p], qy[p], qz[p], c[u]);
+                const float mn = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])), fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
+                if (mn < best[p]) { best[p] = mn; grp[p] = t0 + 8 * g; }
+            }
+        }
+    }
+    // resolve the index inside the winning group of 8
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        bidx[p] = -1;
+        if (grp[p] >= 0) {
+            for (int u = 7; u >= 0; --u) {
+                const int j = grp[p] + u;
+                if (j < m && dist2(qx[p], qy[p], qz[p], tgt[j]) == best[p]) bidx[p] = j;
+            }
+        }
+    }
+}
+
+__global__ void k_pack_points(const float* __restrict__ src, int stride, size_t n, float4* __restrict__ dst)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = make_float4(src[i * stride], src[i * stride + 1], src[i * stride + 2], 0.f);
+}
+
+// eigenvector of the smallest eigenvalue of a symmetric 3x3 (cyclic Jacobi, double)
+__device__ void smallest_eigvec(const double* c, double* n_out)
+{
+    double a[9], v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int i = 0; i < 9; ++i) a[i] = c[i];
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        const double off = a[1] * a[1] + a[2] * a[2] + a[5] * a[5];
+        if (off < 1e-300) break;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) {
+                const double apq = a[3 * p + q];
+                if (apq == 0.0) continue;
+                const double theta = (a[3 * q + q] - a[3 * p + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double akp = a[3 * k + p], akq = a[3 * k + q];
+                    a[3 * k + p] = cs * akp - sn * akq;
+                    a[3 * k + q] = sn * akp + cs * akq;
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double apk = a[3 * p + k], aqk = a[3 * q + k];
+                    a[3 * p + k] = cs * apk - sn * aqk;
+                    a[3 * q + k] = sn * apk + cs * aqk;
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double vkp = v[3 * k + p], vkq = v[3 * k + q];
+                    v[3 * k + p] = cs * vkp - sn * vkq;
+                    v[3 * k + q] = sn * vkp + cs * vkq;
+                }
+            }
+    }
+    int s = 0;
+    if (a[4] < a[0]) s = 1;
+    if (a[8] < a[4 * s]) s = 2;
+    n_out[0] = v[s]; n_out[1] = v[3 + s]; n_out[2] = v[6 + s];
+}
+
+// G2: brute-force kNN (KMAX slots, the first k are used) + covariance + PLANE regularisation.
+// grid = (blocks, clouds); cloud c spans pts[offs[c] .. offs[c+1]).
+// cov out: 6 doubles per point (xx, xy, xz, yy, yz, zz).  knn_out optional [n][k].
+template <int KMAX>
+__global__ __launch_bounds__(kNNThreads) void k_knn_cov(const float4* __restrict__ pts_all,
+                                                        const int64_t* __restrict__ offs, int k,
+                                                        double* __restrict__ cov_all, int* __restrict__ knn_out)
+{
+    __shared__ float4 tile[kTile];
+    const int c = blockIdx.y;
+    const int64_t o = offs[c];
+    const int n = (int)(offs[c + 1] - o);
+    const float4* pts = pts_all + o;
+    for (int base = blockIdx.x * kNNThreads; base < n; base += gridDim.x * kNNThreads) {
+        const int i = base + threadIdx.x;
+        const bool live = i < n;
+        const float4 q = pts[live ? i : 0];
+        float dk[KMAX];
+        int ik[KMAX];
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) { dk[s] = INFINITY; ik[s] = -1; }
+        for (int t0 = 0; t0 < n; t0 += kTile) {
+            const int cnt = min(kTile, n - t0);
+            __syncthreads();
+            for (int u = threadIdx.x; u < cnt; u += kNNThreads) tile[u] = pts[t0 + u];
+            __syncthreads();
+            for (int u = 0; u < cnt; ++u) {
+                const float d = dist2(q.x, q.y, q.z, tile[u]);
+                if (d < dk[KMAX - 1]) {  // sorted insertion, static register indices
+                    const int j = t0 + u;
+#pragma unroll
+                    for (int s = KMAX - 1; s > 0; --s) {
+                        const bool up = dk[s - 1] > d;
+                        const bool here = !up && dk[s] > d;
+                        dk[s] = up ? dk[s - 1] : (here ? d : dk[s]);
+                        ik[s] = up ? ik[s - 1] : (here ? j : ik[s]);
+                    }
+                    if (dk[0] > d) { dk[0] = d; ik[0] = j; }
+                }
+            }
+        }
+        if (!live) continue;
+        double mean[3] = {0, 0, 0};
+        int cnt = 0;
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s)
+            if (s < k && ik[s] >= 0) {
+                const float4 p = pts[ik[s]];
+                mean[0] += (double)p.x; mean[1] += (double)p.y; mean[2] += (double)p.z;
+                ++cnt;
+            }
+        mean[0] /= cnt; mean[1] /= cnt; mean[2] /= cnt;
+        double cv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s)
+            if (s < k && ik[s] >= 0) {
+                const float4 p = pts[ik[s]];
+                const double dx = (double)p.x - mean[0], dy = (double)p.y - mean[1], dz = (double)p.z - mean[2];
+                cv[0] += dx * dx; cv[1] += dx * dy; cv[2] += dx * dz;
+                cv[4] += dy * dy; cv[5] += dy * dz; cv[8] += dz * dz;
+            }
+        cv[3] = cv[1]; cv[6] = cv[2]; cv[7] = cv[5];
+        for (int a = 0; a < 9; ++a) cv[a] /= cnt;
+        double nrm[3];
+        smallest_eigvec(cv, nrm);
+        double* out = cov_all + 6 * (size_t)(o + i);
+        out[0] = 1.0 - 0.999 * nrm[0] * nrm[0];
+        out[1] = -0.999 * nrm[0] * nrm[1];
+        out[2] = -0.999 * nrm[0] * nrm[2];
+        out[3] = 1.0 - 0.999 * nrm[1] * nrm[1];
+        out[4] = -0.999 * nrm[1] * nrm[2];
+        out[5] = 1.0 - 0.999 * nrm[2] * nrm[2];
+        if (knn_out) {
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s)
+                if (s < k) knn_out[(size_t)(o + i) * k + s] = ik[s];
+        }
+    }
+}
+
+__device__ __forceinline__ bool inv3_sym(const double* a, double* r)
+{
+    // a: full 3x3 symmetric, r: full 3x3
+    const double c0 = a[4] * a[8] - a[5] * a[7], c1 = a[5] * a[6] - a[3] * a[8], c2 = a[3] * a[7] - a[4] * a[6];
+    const double det = a[0] * c0 + a[1] * c1 + a[2] * c2;
+    if (det == 0.0) return false;
+    const double id = 1.0 / det;
+    r[0] = c0 * id; r[1] = (a[2] * a[7] - a[1] * a[8]) * id; r[2] = (a[1] * a[5] - a[2] * a[4]) * id;
+    r[3] = c1 * id; r[4] = (a[0] * a[8] - a[2] * a[6]) * id; r[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+    r[6] = c2 * id; r[7] = (a[1] * a[6] - a[0] * a[7]) * id; r[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+    return true;
+}
+
+// G3 + G4 at the candidate pose of every active pair.  grid = (blocks, pairs).
+// partial[pair][block][28].  corr_out optional (per source point NN index or -1).
+__global__ __launch_bounds__(kNNThreads) void k_nn_linearize(
+    const float4* __restrict__ src_all, const int64_t* __restrict__ src_offs, const double* __restrict__ src_cov,
+    const float4* __restrict__ tgt_all, const int64_t* __restrict__ tgt_offs, const double* __restrict__ tgt_cov,
+    const LmState* __restrict__ st, GicpParams prm, double* __restrict__ partial, int max_blocks,
+    int* __restrict__ corr_out)
+{
+    __shared__ float4 tile[kTile];
+    __shared__ double red[kNNThreads / 64][kTerms];
+    const int pair = blockIdx.y;
+    const LmState& S = st[pair];
+    if (!S.active) return;
+    const int64_t so = src_offs[pair], to = tgt_offs[pair];
+    const int n = (int)(src_offs[pair + 1] - so), m = (int)(tgt_offs[pair + 1] - to);
+    const float4* src = src_all + so;
+    const float4* tgt = tgt_all + to;
+    const int per_block = kNNThreads * kPts;
+    double* pout = partial + ((size_t)pair * max_blocks + blockIdx.x) * kTerms;
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = S.xi[i];
+    float Tf[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Tf[i] = (float)T[i];
+
+    double acc[kTerms];
+#pragma unroll
+    for (int i = 0; i < kTerms; ++i) acc[i] = 0.0;
+
+    for (int base = blockIdx.x * per_block; base < n; base += gridDim.x * per_block) {
+        float qx[kPts], qy[kPts], qz[kPts];
+        int si[kPts];
+#pragma unroll
+        for (int p = 0; p < kPts; ++p) {
+            si[p] = base + p * kNNThreads + threadIdx.x;
+            const float4 a = src[si[p] < n ? si[p] : 0];
+            qx[p] = Tf[0] * a.x + Tf[1] * a.y + Tf[2] * a.z + Tf[3];
+            qy[p] = Tf[4] * a.x + Tf[5] * a.y + Tf[6] * a.z + Tf[7];
+            qz[p] = Tf[8] * a.x + Tf[9] * a.y + Tf[10] * a.z + Tf[11];
+        }
+        float best[kPts];
+        int bidx[kPts];
+        nn_scan<kPts>(tgt, m, qx, qy, qz, tile, best, bidx);
+#pragma unroll
+        for (int p = 0; p < kPts; ++p) {
+            if (si[p] >= n) continue;
+            const int j = (bidx[p] >= 0 && (double)best[p] < prm.max_corr2) ? bidx[p] : -1;
+            if (corr_out) corr_out[so + si[p]] = j;
+            if (j < 0) continue;
+            const float4 a = src[si[p]];
+            const float4 bb = tgt[j];
+            const double* ca = src_cov + 6 * (size_t)(so + si[p]);
+            const double* cb = tgt_cov + 6 * (size_t)(to + j);
+            const double CA[9] = {ca[0], ca[1], ca[2], ca[1], ca[3], ca[4], ca[2], ca[4], ca[5]};
+            // RCR = C_B + R C_A R^T
+            double RC[9], RCR[9], M[9];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    RC[3 * r + c] = T[4 * r] * CA[c] + T[4 * r + 1] * CA[3 + c] + T[4 * r + 2] * CA[6 + c];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    RCR[3 * r + c] = RC[3 * r] * T[4 * c] + RC[3 * r + 1] * T[4 * c + 1] + RC[3 * r + 2] * T[4 * c + 2];
+            RCR[0] += cb[0]; RCR[1] += cb[1]; RCR[2] += cb[2];
+            RCR[3] += cb[1]; RCR[4] += cb[3]; RCR[5] += cb[4];
+            RCR[6] += cb[2]; RCR[7] += cb[4]; RCR[8] += cb[5];
+            if (!inv3_sym(RCR, M)) continue;
+            double ta[3], e[3], Me[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                ta[r] = T[4 * r] * (double)a.x + T[4 * r + 1] * (double)a.y + T[4 * r + 2] * (double)a.z + T[4 * r + 3];
+            e[0] = (double)bb.x - ta[0]; e[1] = (double)bb.y - ta[1]; e[2] = (double)bb.z - ta[2];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) Me[r] = M[3 * r] * e[0] + M[3 * r + 1] * e[1] + M[3 * r + 2] * e[2];
+            acc[27] += e[0] * Me[0] + e[1] * Me[1] + e[2] * Me[2];
+            const double J[18] = {0, -ta[2], ta[1], -1, 0, 0,
+                                  ta[2], 0, -ta[0], 0, -1, 0,
+                                  -ta[1], ta[0], 0, 0, 0, -1};
+            double MJ[18];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+                    MJ[6 * r + c] = M[3 * r] * J[c] + M[3 * r + 1] * J[6 + c] + M[3 * r + 2] * J[12 + c];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                for (int c = r; c < 6; ++c)
+                    acc[r * 6 - (r * (r - 1)) / 2 + (c - r)] += J[r] * MJ[c] + J[6 + r] * MJ[6 + c] + J[12 + r] * MJ[12 + c];
+            }
+#pragma unroll
+            for (int r = 0; r < 6; ++r) acc[21 + r] += J[r] * Me[0] + J[6 + r] * Me[1] + J[12 + r] * Me[2];
+        }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < kTerms; ++i) {
+        const double v = wave_sum_d(acc[i]);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kTerms) {
+        double v = 0;
+        for (int w = 0; w < kNNThreads / 64; ++w) v += red[w][threadIdx.x];
+        pout[threadIdx.x] = v;
+    }
+}
+
+// ---- device-side LM bookkeeping (one lane per pair) ------------------------------------------
+__device__ void mul4d(const double* a, const double* b, double* c)
+{
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double s = 0;
+            for (int k = 0; k < 4; ++k) s += a[4 * i + k] * b[4 * k + j];
+            c[4 * i + j] = s;
+        }
+}
+
+__device__ void se3_exp_d(const double* a, double* T)
+{
+    const double wx = a[0], wy = a[1], wz = a[2];
+    const double theta_sq = wx * wx + wy * wy + wz * wz;
+    double imag, real, theta = 0;
+    if (theta_sq < 1e-10) {
+        const double t4 = theta_sq * theta_sq;
+        imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * t4;
+        real = 1.0 - (1.0 / 8.0) * theta_sq + (1.0 / 384.0) * t4;
+    } else {
+        theta = sqrt(theta_sq);
+        imag = sin(0.5 * theta) / theta;
+        real = cos(0.5 * theta);
+    }
+    double qw = real, qx = imag * wx, qy = imag * wy, qz = imag * wz;
+    const double nq = sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+    qw /= nq; qx /= nq; qy /= nq; qz /= nq;
+    const double R[9] = {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw),
+                         2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw),
+                         2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)};
+    double V[9];
+    if (theta < 1e-10) {
+        for (int i = 0; i < 9; ++i) V[i] = R[i];
+    } else {
+        const double O[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+        double O2[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) O2[3 * i + j] = O[3 * i] * O[j] + O[3 * i + 1] * O[3 + j] + O[3 * i + 2] * O[6 + j];
+        const double c1 = (1.0 - cos(theta)) / theta_sq, c2 = (theta - sin(theta)) / (theta_sq * theta);
+        for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0 ? 1.0 : 0.0) + c1 * O[i] + c2 * O2[i];
+    }
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) T[4 * i + j] = R[3 * i + j];
+        T[4 * i + 3] = V[3 * i] * a[3] + V[3 * i + 1] * a[4] + V[3 * i + 2] * a[5];
+    }
+    T[12] = T[13] = T[14] = 0; T[15] = 1;
+}
+
+__device__ bool solve6_d(const double* Hin, const double* rhs, double* x)
+{
+    double L[36], D[6];
+    for (int i = 0; i < 36; ++i) L[i] = 0;
+    for (int j = 0; j < 6; ++j) {
+        double d = Hin[6 * j + j];
+        for (int k = 0; k < j; ++k) d -= L[6 * j + k] * L[6 * j + k] * D[k];
+        D[j] = d;
+        if (d == 0.0 || !(d == d)) return false;
+        for (int i = j + 1; i < 6; ++i) {
+            double s = Hin[6 * i + j];
+            for (int k = 0; k < j; ++k) s -= L[6 * i + k] * L[6 * j + k] * D[k];
+            L[6 * i + j] = s / d;
+        }
+    }
+    double y[6];
+    for (int i = 0; i < 6; ++i) { double s = rhs[i]; for (int k = 0; k < i; ++k) s -= L[6 * i + k] * y[k]; y[i] = s; }
+    for (int i = 0; i < 6; ++i) y[i] /= D[i];
+    for (int i = 5; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * x[k]; x[i] = s; }
+    return true;
+}
+
+__device__ bool is_converged_d(const GicpParams& p, const double* delta)
+{
+    double mr = 0, mt = 0;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) mr = fmax(mr, fabs(delta[4 * i + j] - (i == j ? 1.0 : 0.0)) / p.rot_eps);
+        mt = fmax(mt, fabs(delta[4 * i + 3]) / p.trans_eps);
+    }
+    return fmax(mr, mt) < 1.0;
+}
+
+// propose the next candidate from (H, b, lambda); marks the pair failed if the solve breaks down
+__device__ void propose(LmState& S)
+{
+    double Hl[36], rhs[6];
+    for (int i = 0; i < 36; ++i) Hl[i] = S.H[i];
+    for (int i = 0; i < 6; ++i) { Hl[7 * i] += S.lambda; rhs[i] = -S.b[i]; }
+    if (!solve6_d(Hl, rhs, S.d)) { S.failed = 1; S.active = 0; S.phase = 2; return; }
+    se3_exp_d(S.d, S.delta);
+    mul4d(S.delta, S.x, S.xi);
+    ++S.trials;
+}
+
+// LsqRegistration::step_lm / computeTransformation bookkeeping; grid = pairs, 64 lanes each
+__global__ void k_lm_update(LmState* __restrict__ st, const double* __restrict__ partial, const int* __restrict__ nblocks,
+                            int max_blocks, GicpParams prm, int* __restrict__ n_active)
+{
+    const int pair = blockIdx.x;
+    LmState& S = st[pair];
+    if (!S.active) return;
+    __shared__ double sum[kTerms];
+    if (threadIdx.x < kTerms) {
+        double v = 0;
+        const double* p = partial + (size_t)pair * max_blocks * kTerms + threadIdx.x;
+        for (int b = 0; b < nblocks[pair]; ++b) v += p[(size_t)b * kTerms];  // fixed order
+        sum[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double H[36], b[6];
+    int t = 0;
+    for (int r = 0; r < 6; ++r)
+        for (int c = r; c < 6; ++c) { H[6 * r + c] = sum[t]; H[6 * c + r] = sum[t]; ++t; }
+    for (int r = 0; r < 6; ++r) b[r] = sum[21 + r];
+    const double y = sum[27];
+
+    bool take = false;  // adopt the evaluation at xi as the linearisation of the next iteration
+    if (S.phase == 0) {
+        double mx = 0;
+        for (int i = 0; i < 6; ++i) mx = fmax(mx, fabs(H[7 * i]));
+        S.lambda = prm.lm_init_factor * mx;
+        take = true;
+    } else {
+        double denom = 0;
+        for (int i = 0; i < 6; ++i) denom += S.d[i] * (S.lambda * S.d[i] - S.b[i]);
+        const double rho = (S.y0 - y) / denom;
+        if (!(rho == rho)) {
+            S.failed = 1; S.active = 0; S.phase = 2;
+        } else if (rho < 0) {
+            if (is_converged_d(prm, S.delta)) {
+                // step_lm returns true without moving; the outer loop then sees a converged delta
+                ++S.outer;
+                if (prm.force_iters <= 0) { S.converged = 1; S.active = 0; S.phase = 2; }
+                else if (S.outer >= prm.force_iters) { S.active = 0; S.phase = 2; }
+                else { S.nu = 2.0; S.inner = 0; propose(S); }
+            } else {
+                S.lambda = S.nu * S.lambda;
+                S.nu = 2 * S.nu;
+                ++S.inner;
+                if (S.inner >= prm.lm_max_iter) { S.failed = 1; S.active = 0; S.phase = 2; }  // "lm not converged"
+                else propose(S);
+            }
+        } else {
+            for (int i = 0; i < 16; ++i) S.x[i] = S.xi[i];
+            const double w = 2 * rho - 1;
+            S.lambda = S.lambda * fmax(1.0 / 3.0, 1.0 - w * w * w);
+            for (int i = 0; i < 36; ++i) S.final_H[i] = S.H[i];
+            ++S.outer;
+            const int limit = prm.force_iters > 0 ? prm.force_iters : prm.max_iter;
+            const bool conv = prm.force_iters > 0 ? false : is_converged_d(prm, S.delta);
+            if (conv) S.converged = 1;
+            if (conv || S.outer >= limit) { S.active = 0; S.phase = 2; }
+            else take = true;
+        }
+    }
+    if (take) {
+        for (int i = 0; i < 36; ++i) S.H[i] = H[i];
+        for (int i = 0; i < 6; ++i) S.b[i] = b[i];
+        S.y0 = y;
+        S.nu = 2.0;
+        S.inner = 0;
+        S.phase = 1;
+        propose(S);
+    }
+    if (S.active) atomicAdd(n_active, 1);
+}
+
+// G6: fitness partials: [pair][block][2] = (sum of d^2 <= max_range, count)
+__global__ __launch_bounds__(kNNThreads) void k_fitness(const float4* __restrict__ src_all,
+                                                        const int64_t* __restrict__ src_offs,
+                                                        const float4* __restrict__ tgt_all,
+                                                        const int64_t* __restrict__ tgt_offs,
+                                                        const double* __restrict__ poses /* [pairs][16] */,
+                                                        double max_range, double* __restrict__ partial, int max_blocks)
+{
+    __shared__ float4 tile[kTile];
+    __shared__ double red[kNNThreads / 64][2];
+    const int pair = blockIdx.y;
+    const int64_t so = src_offs[pair], to = tgt_offs[pair];
+    const int n = (int)(src_offs[pair + 1] - so), m = (int)(tgt_offs[pair + 1] - to);
+    const float4* src = src_all + so;
+    const float4* tgt = tgt_all + to;
+    float Tf[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Tf[i] = (float)poses[(size_t)pair * 16 + i];
+    const int per_block = kNNThreads * kPts;
+    double s = 0, c = 0;
+    for (int base = blockIdx.x * per_block; base < n; base += gridDim.x * per_block) {
+        float qx[kPts], qy[kPts], qz[kPts];
+        int si[kPts];
+#pragma unroll
+        for (int p = 0; p < kPts; ++p) {
+            si[p] = base + p * kNNThreads + threadIdx.x;
+            const float4 a = src[si[p] < n ? si[p] : 0];
+            qx[p] = Tf[0] * a.x + Tf[1] * a.y + Tf[2] * a.z + Tf[3];
+            qy[p] = Tf[4] * a.x + Tf[5] * a.y + Tf[6] * a.z + Tf[7];
+            qz[p] = Tf[8] * a.x + Tf[9] * a.y + Tf[10] * a.z + Tf[11];
+        }
+        float best[kPts];
+        int bidx[kPts];
+        nn_scan<kPts>(tgt, m, qx, qy, qz, tile, best, bidx);
+#pragma unroll
+        for (int p = 0; p < kPts; ++p)
+            if (si[p] < n && bidx[p] >= 0 && (double)best[p] <= max_range) { s += (double)best[p]; c += 1.0; }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    s = wave_sum_d(s); c = wave_sum_d(c);
+    if (lane == 0) { red[wave][0] = s; red[wave][1] = c; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double v = 0;
+        for (int w = 0; w < kNNThreads / 64; ++w) v += red[w][threadIdx.x];
+        partial[((size_t)pair * max_blocks + blockIdx.x) * 2 + threadIdx.x] = v;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+struct mrs_gicp_batch {
+    mrs_ctx* ctx = nullptr;
+    int n_pairs = 0;
+    GicpParams prm;
+    std::vector<int64_t> offs[2];   // host copies: [0] source, [1] target
+    int64_t* d_offs[2] = {nullptr, nullptr};
+    float4* d_pts[2] = {nullptr, nullptr};
+    double* d_cov[2] = {nullptr, nullptr};
+    bool cov_valid[2] = {false, false};
+    LmState* d_state = nullptr;
+    double* d_partial = nullptr;
+    int* d_nblocks = nullptr;
+    int* d_nactive = nullptr;
+    int max_blocks = 0;
+    double last_nn_passes = 0;
+};
+
+namespace {
+
+void free_cloud(mrs_gicp_batch* h, int w)
+{
+    if (h->d_offs[w]) (void)hipFree(h->d_offs[w]);
+    if (h->d_pts[w]) (void)hipFree(h->d_pts[w]);
+    if (h->d_cov[w]) (void)hipFree(h->d_cov[w]);
+    h->d_offs[w] = nullptr; h->d_pts[w] = nullptr; h->d_cov[w] = nullptr;
+    h->cov_valid[w] = false;
+}
+
+int blocks_for_points(int n) { return (n + kNNThreads * kPts - 1) / (kNNThreads * kPts); }
+
+}  // namespace
+
+extern "C" {
+
+void mrs_gicp_default_params(mrs_gicp_params* p)
+{
+    if (!p) return;
+    p->k_correspondences = 20;          // fast_gicp default; Mapping sets 15 (global_manager.cpp:2442)
+    p->max_correspondence_distance = DBL_MAX;
+    p->max_iterations = 64;
+    p->rotation_epsilon = 2e-3;
+    p->transformation_epsilon = 5e-4;
+    p->lm_max_iterations = 10;
+    p->lm_init_lambda_factor = 1e-9;
+    p->force_iterations = 0;
+}
+
+int mrs_gicp_batch_create(mrs_ctx* ctx, int32_t n_pairs, mrs_gicp_batch** out)
+{
+    MRS_REQUIRE(ctx && out, "null pointer");
+    MRS_REQUIRE(n_pairs > 0, "n_pairs must be positive");
+    *out = nullptr;
+    MRS_HIP_TRY(hipSetDevice(ctx->device));
+    mrs_gicp_batch* h = new mrs_gicp_batch();
+    h->ctx = ctx;
+    h->n_pairs = n_pairs;
+    mrs_gicp_params d;
+    mrs_gicp_default_params(&d);
+    *out = h;
+    return mrs_gicp_batch_set_params(h, &d);
+}
+
+int mrs_gicp_batch_destroy(mrs_gicp_batch* h)
+{
+    if (!h) return MRS_OK;
+    (void)hipSetDevice(h->ctx->device);
+    free_cloud(h, 0);
+    free_cloud(h, 1);
+    if (h->d_state) (void)hipFree(h->d_state);
+    if (h->d_partial) (void)hipFree(h->d_partial);
+    if (h->d_nblocks) (void)hipFree(h->d_nblocks);
+    if (h->d_nactive) (void)hipFree(h->d_nactive);
+    delete h;
+    return MRS_OK;
+}
+
+int mrs_gicp_batch_set_params(mrs_gicp_batch* h, const mrs_gicp_params* p)
+{
+    MRS_REQUIRE(h && p, "null pointer");
+    MRS_REQUIRE(p->k_correspondences >= 3 && p->k_correspondences <= 32, "k_correspondences must be in [3, 32]");
+    MRS_REQUIRE(p->max_iterations > 0 && p->lm_max_iterations > 0, "iteration limits must be positive");
+    MRS_REQUIRE(p->max_correspondence_distance > 0, "max_correspondence_distance must be positive");
+    if (p->k_correspondences != h->prm.k) { h->cov_valid[0] = h->cov_valid[1] = false; }
+    h->prm.k = p->k_correspondences;
+    h->prm.max_corr2 = p->max_correspondence_distance >= 1e150 ? INFINITY
+                                                               : p->max_correspondence_distance * p->max_correspondence_distance;
+    h->prm.max_iter = p->max_iterations;
+    h->prm.rot_eps = p->rotation_epsilon;
+    h->prm.trans_eps = p->transformation_epsilon;
+    h->prm.lm_max_iter = p->lm_max_iterations;
+    h->prm.lm_init_factor = p->lm_init_lambda_factor;
+    h->prm.force_iters = p->force_iterations;
+    return MRS_OK;
+}
+
+int mrs_gicp_batch_set_clouds(mrs_gicp_batch* h, int32_t which, const float* d_points, int32_t stride_floats,
+                              const int64_t* h_offsets, mrs_stream stream)
+{
+    MRS_REQUIRE(h && d_points && h_offsets, "null pointer");
+    MRS_REQUIRE(which == 0 || which == 1, "which must be 0 (source) or 1 (target)");
+    MRS_REQUIRE(stride_floats >= 3, "stride_floats must be >= 3");
+    MRS_REQUIRE(h_offsets[0] == 0, "offsets[0] must be 0");
+    for (int i = 0; i < h->n_pairs; ++i) {
+        MRS_REQUIRE(h_offsets[i + 1] > h_offsets[i], "every cloud needs at least one point");
+        MRS_REQUIRE(h_offsets[i + 1] - h_offsets[i] < (1ll << 30), "cloud too large");
+    }
+    MRS_HIP_TRY(hipSetDevice(h->ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    free_cloud(h, which);
+    const int64_t total = h_offsets[h->n_pairs];
+    h->offs[which].assign(h_offsets, h_offsets + h->n_pairs + 1);
+    MRS_HIP_TRY(hipMalloc(&h->d_offs[which], (h->n_pairs + 1) * sizeof(int64_t)));
+    MRS_HIP_TRY(hipMalloc(&h->d_pts[which], (size_t)total * sizeof(float4)));
+    MRS_HIP_TRY(hipMalloc(&h->d_cov[which], (size_t)total * 6 * sizeof(double)));
+    MRS_HIP_TRY(hipMemcpyAsync(h->d_offs[which], h_offsets, (h->n_pairs + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_pack_points, dim3(blocks), dim3(256), 0, s, d_points, stride_floats, (size_t)total, h->d_pts[which]);
+    MRS_HIP_TRY(hipGetLastError());
+    MRS_HIP_TRY(hipStreamSynchronize(s));  // h_offsets may be a temporary
+    return MRS_OK;
+}
+
+int mrs_gicp_batch_compute_covariances(mrs_gicp_batch* h, int32_t which, int32_t* d_knn_out, mrs_stream stream)
+{
+    MRS_REQUIRE(h, "null handle");
+    MRS_REQUIRE(which == 0 || which == 1, "which must be 0 or 1");
+    MRS_REQUIRE(h->d_pts[which] != nullptr, "set_clouds first");
+    MRS_HIP_TRY(hipSetDevice(h->ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    int64_t longest = 0;
+    for (int i = 0; i < h->n_pairs; ++i) longest = std::max(longest, h->offs[which][i + 1] - h->offs[which][i]);
+    const dim3 grid((unsigned)((longest + kNNThreads - 1) / kNNThreads), h->n_pairs);
+    const int k = h->prm.k;
+    if (k <= 16)
+        hipLaunchKernelGGL(k_knn_cov<16>, grid, dim3(kNNThreads), 0, s, h->d_pts[which], h->d_offs[which], k, h->d_cov[which], d_knn_out);
+    else if (k <= 20)
+        hipLaunchKernelGGL(k_knn_cov<20>, grid, dim3(kNNThreads), 0, s, h->d_pts[which], h->d_offs[which], k, h->d_cov[which], d_knn_out);
+    else
+        hipLaunchKernelGGL(k_knn_cov<32>, grid, dim3(kNNThreads), 0, s, h->d_pts[which], h->d_offs[which], k, h->d_cov[which], d_knn_out);
+    MRS_HIP_TRY(hipGetLastError());
+    h->cov_valid[which] = true;
+    return MRS_OK;
+}
+
+int mrs_gicp_batch_get_covariances(mrs_gicp_batch* h, int32_t which, double* h_cov6)
+{
+    MRS_REQUIRE(h && h_cov6, "null pointer");
+    MRS_REQUIRE(which == 0 || which == 1, "which must be 0 or 1");
+    MRS_REQUIRE(h->cov_valid[which], "covariances not computed");
+    MRS_HIP_TRY(hipSetDevice(h->ctx->device));
+    MRS_HIP_TRY(hipDeviceSynchronize());
+    MRS_HIP_TRY(hipMemcpy(h_cov6, h->d_cov[which], (size_t)h->offs[which][h->n_pairs] * 6 * sizeof(double), hipMemcpyDeviceToHost));
+    return MRS_OK;
+}
+
+static int ensure_state(mrs_gicp_batch* h)
+{
+    int64_t longest = 0;
+    for (int i = 0; i < h->n_pairs; ++i) longest = std::max(longest, h->offs[0][i + 1] - h->offs[0][i]);
+    const int mb = blocks_for_points((int)longest);
+    if (!h->d_state) {
+        MRS_HIP_TRY(hipMalloc(&h->d_state, h->n_pairs * sizeof(LmState)));
+        MRS_HIP_TRY(hipMalloc(&h->d_nblocks, h->n_pairs * sizeof(int)));
+        MRS_HIP_TRY(hipMalloc(&h->d_nactive, sizeof(int)));
+    }
+    if (mb > h->max_blocks) {
+        if (h->d_partial) (void)hipFree(h->d_partial);
+        MRS_HIP_TRY(hipMalloc(&h->d_partial, (size_t)h->n_pairs * mb * kTerms * sizeof(double)));
+        h->max_blocks = mb;
+    }
+    std::vector<int> nb(h->n_pairs);
+    for (int i = 0; i < h->n_pairs; ++i) nb[i] = blocks_for_points((int)(h->offs[0][i + 1] - h->offs[0][i]));
+    MRS_HIP_TRY(hipMemcpy(h->d_nblocks, nb.data(), nb.size() * sizeof(int), hipMemcpyHostToDevice));
+    return MRS_OK;
+}
+
+int mrs_gicp_batch_align(mrs_gicp_batch* h, const double* h_guess, double* h_final, int32_t* h_converged,
+                         int32_t* h_iterations, double* h_hessian, mrs_stream stream)
+{
+    MRS_REQUIRE(h && h_final, "null pointer");
+    MRS_REQUIRE(h->d_pts[0] && h->d_pts[1], "set source and target clouds first");
+    MRS_HIP_TRY(hipSetDevice(h->ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    int st;
+    for (int w = 0; w < 2; ++w)
+        if (!h->cov_valid[w]) { st = mrs_gicp_batch_compute_covariances(h, w, nullptr, stream); if (st != MRS_OK) return st; }
+    st = ensure_state(h);
+    if (st != MRS_OK) return st;
+    std::vector<LmState> init(h->n_pairs);
+    for (int p = 0; p < h->n_pairs; ++p) {
+        LmState& S = init[p];
+        memset(&S, 0, sizeof(S));
+        for (int i = 0; i < 16; ++i) {
+            const double g = h_guess ? h_guess[(size_t)p * 16 + i] : (i % 5 == 0 ? 1.0 : 0.0);
+            S.x[i] = S.xi[i] = (double)(float)g;  // the reference passes an Eigen::Matrix4f guess
+        }
+        S.lambda = -1.0; S.nu = 2.0; S.active = 1;
+    }
+    MRS_HIP_TRY(hipMemcpyAsync(h->d_state, init.data(), init.size() * sizeof(LmState), hipMemcpyHostToDevice, s));
+    const dim3 grid(h->max_blocks, h->n_pairs);
+    const int limit = h->prm.force_iters > 0 ? h->prm.force_iters : h->prm.max_iter;
+    const long max_ticks = 1 + (long)limit * (h->prm.lm_max_iter + 1);
+    long ticks = 0;
+    int active = h->n_pairs;
+    while (active > 0 && ticks < max_ticks) {
+        MRS_HIP_TRY(hipMemsetAsync(h->d_nactive, 0, sizeof(int), s));
+        hipLaunchKernelGGL(k_nn_linearize, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_cov[0],
+                           h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->prm, h->d_partial, h->max_blocks,
+                           (int*)nullptr);
+        hipLaunchKernelGGL(k_lm_update, dim3(h->n_pairs), dim3(64), 0, s, h->d_state, h->d_partial, h->d_nblocks,
+                           h->max_blocks, h->prm, h->d_nactive);
+        MRS_HIP_TRY(hipGetLastError());
+        MRS_HIP_TRY(hipMemcpyAsync(&active, h->d_nactive, sizeof(int), hipMemcpyDeviceToHost, s));
+        MRS_HIP_TRY(hipStreamSynchronize(s));
+        ++ticks;
+    }
+    h->last_nn_passes = (double)ticks;
+    MRS_HIP_TRY(hipMemcpy(init.data(), h->d_state, init.size() * sizeof(LmState), hipMemcpyDeviceToHost));
+    for (int p = 0; p < h->n_pairs; ++p) {
+        const LmState& S = init[p];
+        for (int i = 0; i < 16; ++i) h_final[(size_t)p * 16 + i] = (double)(float)S.x[i];  // final_transformation_ is float
+        if (h_converged) h_converged[p] = S.converged;
+        if (h_iterations) h_iterations[p] = S.outer;
+        if (h_hessian) memcpy(h_hessian + (size_t)p * 36, S.final_H, sizeof(S.final_H));
+    }
+    return MRS_OK;
+}
+
+int mrs_gicp_batch_linearize(mrs_gicp_batch* h, const double* h_poses, double* h_H, double* h_b, double* h_err,
+                             int32_t* d_corr, mrs_stream stream)
+{
+    MRS_REQUIRE(h && h_poses && h_H && h_b && h_err, "null pointer");
+    MRS_REQUIRE(h->d_pts[0] && h->d_pts[1], "set source and target clouds first");
+    MRS_HIP_TRY(hipSetDevice(h->ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    int st;
+    for (int w = 0; w < 2; ++w)
+        if (!h->cov_valid[w]) { st = mrs_gicp_batch_compute_covariances(h, w, nullptr, stream); if (st != MRS_OK) return st; }
+    st = ensure_state(h);
+    if (st != MRS_OK) return st;
+    std::vector<LmState> init(h->n_pairs);
+    for (int p = 0; p < h->n_pairs; ++p) {
+        memset(&init[p], 0, sizeof(LmState));
+        for (int i = 0; i < 16; ++i) init[p].x[i] = init[p].xi[i] = h_poses[(size_t)p * 16 + i];
+        init[p].active = 1;
+    }
+    MRS_HIP_TRY(hipMemcpyAsync(h->d_state, init.data(), init.size() * sizeof(LmState), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_nn_linearize, dim3(h->max_blocks, h->n_pairs), dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0],
+                       h->d_cov[0], h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->prm, h->d_partial,
+                       h->max_blocks, d_corr);
+    MRS_HIP_TRY(hipGetLastError());
+    std::vector<double> part((size_t)h->n_pairs * h->max_blocks * kTerms);
+    MRS_HIP_TRY(hipMemcpyAsync(part.data(), h->d_partial, part.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    MRS_HIP_TRY(hipStreamSynchronize(s));
+    for (int p = 0; p < h->n_pairs; ++p) {
+        double sum[kTerms] = {0};
+        const int nb = blocks_for_points((int)(h->offs[0][p + 1] - h->offs[0][p]));
+        for (int b = 0; b < nb; ++b)
+            for (int t = 0; t < kTerms; ++t) sum[t] += part[((size_t)p * h->max_blocks + b) * kTerms + t];
+        int t = 0;
+        for (int r = 0; r < 6; ++r)
+            for (int c = r; c < 6; ++c) { h_H[(size_t)p * 36 + 6 * r + c] = sum[t]; h_H[(size_t)p * 36 + 6 * c + r] = sum[t]; ++t; }
+        for (int r = 0; r < 6; ++r) h_b[(size_t)p * 6 + r] = sum[21 + r];
+        h_err[p] = sum[27];
+    }
+    return MRS_OK;
+}
+
+int mrs_gicp_batch_fitness(mrs_gicp_batch* h, const double* h_poses, double max_range, double* h_scores,
+                           mrs_stream stream)
+{
+    MRS_REQUIRE(h && h_poses && h_scores, "null pointer");
+    MRS_REQUIRE(h->d_pts[0] && h->d_pts[1], "set source and target clouds first");
+    MRS_HIP_TRY(hipSetDevice(h->ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    int st = ensure_state(h);
+    if (st != MRS_OK) return st;
+    mrs::Scratch poses, part;
+    st = poses.alloc((size_t)h->n_pairs * 16 * sizeof(double), s);
+    if (st != MRS_OK) return st;
+    st = part.alloc((size_t)h->n_pairs * h->max_blocks * 2 * sizeof(double), s);
+    if (st != MRS_OK) return st;
+    MRS_HIP_TRY(hipMemcpyAsync(poses.p, h_poses, (size_t)h->n_pairs * 16 * sizeof(double), hipMemcpyHostToDevice, s));
+    MRS_HIP_TRY(hipMemsetAsync(part.p, 0, (size_t)h->n_pairs * h->max_blocks * 2 * sizeof(double), s));
+    hipLaunchKernelGGL(k_fitness, dim3(h->max_blocks, h->n_pairs), dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0],
+                       h->d_pts[1], h->d_offs[1], poses.as<double>(), max_range, part.as<double>(), h->max_blocks);
+    MRS_HIP_TRY(hipGetLastError());
+    std::vector<double> hp((size_t)h->n_pairs * h->max_blocks * 2);
+    MRS_HIP_TRY(hipMemcpyAsync(hp.data(), part.p, hp.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    MRS_HIP_TRY(hipStreamSynchronize(s));
+    for (int p = 0; p < h->n_pairs; ++p) {
+        double sum = 0, cnt = 0;
+        for (int b = 0; b < h->max_blocks; ++b) { sum += hp[((size_t)p * h->max_blocks + b) * 2]; cnt += hp[((size_t)p * h->max_blocks + b) * 2 + 1]; }
+        h_scores[p] = cnt > 0 ? sum / cnt : DBL_MAX;  // pcl: std::numeric_limits<double>::max() when empty
+    }
+    return MRS_OK;
+}
+
+double mrs_gicp_batch_last_nn_passes(const mrs_gicp_batch* h) { return h ? h->last_nn_passes : 0.0; }
+
+}  // extern "C"

@@ -189,3 +189,70 @@ class RefSymbolicFunction:
         out = np.zeros((ang.size, det), np.float32)
         self._l.ref_sym_forward(self._f, det, C.c_float(spacing), _p(ang), ang.size, _p(out))
         return out
+
+
+# ----------------------------------------------------------------------------------- GICP
+class Gicp:
+    """ctypes handle on oracle/gicp_oracle.cpp (restated fast_gicp FastGICP; parity unpinned)."""
+
+    def __init__(self, k=20, max_corr=1e300, max_iter=64, rot_eps=2e-3, trans_eps=5e-4, threads=None):
+        L = lib()
+        L.orc_gicp_create.restype = C.c_void_p
+        L.orc_gicp_linearize.restype = C.c_double
+        L.orc_gicp_fitness.restype = C.c_double
+        self._l = L
+        self._h = C.c_void_p(L.orc_gicp_create())
+        self.set_params(k, max_corr, max_iter, rot_eps, trans_eps, threads or os.cpu_count() or 1)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._l.orc_gicp_destroy(self._h)
+
+    def set_params(self, k, max_corr, max_iter, rot_eps, trans_eps, threads):
+        self._l.orc_gicp_set_params(self._h, int(k), C.c_double(max_corr), int(max_iter), C.c_double(rot_eps),
+                                    C.c_double(trans_eps), int(threads))
+
+    def set_source(self, pts):
+        p = _f32(np.asarray(pts)[:, :3]); self._ns = p.shape[0]
+        self._l.orc_gicp_set_source(self._h, _p(p), p.shape[0])
+
+    def set_target(self, pts):
+        p = _f32(np.asarray(pts)[:, :3]); self._nt = p.shape[0]
+        self._l.orc_gicp_set_target(self._h, _p(p), p.shape[0])
+
+    def covariances(self, which):
+        n = self._nt if which else self._ns
+        out = np.empty((n, 3, 3), np.float64)
+        self._l.orc_gicp_covariances(self._h, int(which), _p(out))
+        return out
+
+    def align(self, guess=None, force_iters=0):
+        g = np.ascontiguousarray(np.eye(4) if guess is None else guess, dtype=np.float64)
+        out = np.empty((4, 4), np.float64)
+        conv = self._l.orc_gicp_align(self._h, _p(g), _p(out), int(force_iters))
+        return out, bool(conv), int(self._l.orc_gicp_iterations(self._h)), int(self._l.orc_gicp_lm_trials(self._h))
+
+    def linearize(self, T):
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        H = np.empty((6, 6), np.float64); b = np.empty(6, np.float64)
+        corr = np.empty(self._ns, np.int32)
+        e = self._l.orc_gicp_linearize(self._h, _p(T), _p(H), _p(b), _p(corr))
+        return float(e), H, b, corr
+
+    def fitness(self, T, max_range):
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        return float(self._l.orc_gicp_fitness(self._h, _p(T), C.c_double(max_range)))
+
+
+def knn(pts, k):
+    p = _f32(np.asarray(pts)[:, :3])
+    out = np.empty((p.shape[0], k), np.int32)
+    lib().orc_knn(_p(p), p.shape[0], int(k), _p(out))
+    return out
+
+
+def se3_exp(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    T = np.empty((4, 4), np.float64)
+    lib().orc_se3_exp(_p(a), _p(T))
+    return T

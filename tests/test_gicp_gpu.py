@@ -1,0 +1,171 @@
+"""GPU parity suite for the batched GICP (HIP through the C ABI) vs the CPU restatement.
+Tolerance from BASELINE.json north_star: transforms within 1e-4 m / 1e-4 rad."""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation as Rot
+
+pytestmark = pytest.mark.gpu
+
+TOL_T = 1e-4   # metres
+TOL_R = 1e-4   # radians
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available()
+    from mr_slam_amd import _lib
+    _lib.load()
+    return "cuda:0"
+
+
+def _pair(seed, n, rotvec=(0.02, -0.03, 0.08), t=(0.6, -0.4, 0.1), noise=0.01):
+    from mr_slam_amd import synth
+    rng = np.random.default_rng(seed)
+    base = synth.lidar_scan(seed, n, metric=True).astype(np.float64)
+    R = Rot.from_rotvec(rotvec).as_matrix()
+    src = (base + rng.normal(0, noise, base.shape)).astype(np.float32)
+    tgt = (base @ R.T + np.asarray(t) + rng.normal(0, noise, base.shape)).astype(np.float32)
+    T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t
+    return src, tgt, T
+
+
+def _pose_err(A, B):
+    dt = np.linalg.norm(A[:3, 3] - B[:3, 3])
+    dr = np.linalg.norm(Rot.from_matrix(A[:3, :3] @ B[:3, :3].T).as_rotvec())
+    return dt, dr
+
+
+def test_knn_and_covariances_match_oracle(dev, oracle):
+    from mr_slam_amd import gicp
+    src, tgt, _ = _pair(1, 7000)
+    for k in (20, 15):
+        b = gicp.GicpBatch(2)
+        b.set_params(k_correspondences=k)
+        b.set_sources([src, tgt[:3001]])
+        knn = b.compute_covariances(0, want_knn=True).cpu().numpy()
+        want = np.concatenate([oracle.knn(src, k), oracle.knn(tgt[:3001], k)])
+        assert (np.sort(knn, 1) == np.sort(want, 1)).all(1).mean() > 0.999   # exact ties aside
+        g = oracle.Gicp(k=k)
+        g.set_source(src); g.set_target(tgt[:3001])
+        want_cov = np.concatenate([g.covariances(0), g.covariances(1)])
+        got = b.covariances(0)
+        bad = np.abs(got - want_cov).reshape(-1, 9).max(1) > 1e-9
+        assert bad.mean() < 1e-3
+
+
+def test_linearize_matches_oracle(dev, oracle):
+    from mr_slam_amd import gicp
+    src, tgt, Ttrue = _pair(2, 9000)
+    T = Ttrue.copy(); T[:3, 3] += [0.25, -0.1, 0.05]
+    for max_corr in (5.0, 0.5):
+        b = gicp.GicpBatch(1)
+        b.set_params(max_correspondence_distance=max_corr)
+        b.set_sources([src]); b.set_targets([tgt])
+        e, H, bb, corr = b.linearize(T[None], want_corr=True)
+        g = oracle.Gicp(k=20, max_corr=max_corr)
+        g.set_source(src); g.set_target(tgt)
+        we, wH, wb, wcorr = g.linearize(T)
+        assert (corr == wcorr).mean() > 0.9995
+        assert (wcorr >= 0).sum() > 100
+        assert abs(e[0] - we) < 2e-3 * abs(we)
+        np.testing.assert_allclose(H[0], wH, rtol=2e-3, atol=2e-3 * np.abs(wH).max())
+        np.testing.assert_allclose(bb[0], wb, rtol=2e-3, atol=2e-3 * np.abs(wb).max())
+        if (corr == wcorr).all():
+            assert abs(e[0] - we) < 1e-9 * abs(we)
+            np.testing.assert_allclose(H[0], wH, rtol=1e-9, atol=1e-9 * np.abs(wH).max())
+
+
+def test_align_batch_within_north_star_tolerance(dev, oracle):
+    """Ragged batch of three pairs; every transform within 1e-4 m / 1e-4 rad of the restatement."""
+    from mr_slam_amd import gicp
+    cfgs = [(3, 9000, (0.02, -0.03, 0.08), (0.6, -0.4, 0.1)),
+            (4, 6001, (0.0, 0.0, -0.05), (-0.8, 0.3, 0.0)),
+            (5, 12000, (0.01, 0.01, 0.0), (0.1, 0.1, -0.05))]
+    pairs = [_pair(s, n, r, t) for (s, n, r, t) in cfgs]
+    b = gicp.GicpBatch(3)
+    b.set_params(max_correspondence_distance=5.0)
+    b.set_sources([p[0] for p in pairs]); b.set_targets([p[1] for p in pairs])
+    guess = np.stack([np.eye(4)] * 3)
+    guess[1, :3, 3] = [-0.5, 0.2, 0.0]
+    T, conv, its = b.align(guess)
+    fit = b.fitness(T, 1.0)
+    for i, (src, tgt, Ttrue) in enumerate(pairs):
+        g = oracle.Gicp(k=20, max_corr=5.0)
+        g.set_source(src); g.set_target(tgt)
+        wT, wconv, wits, _ = g.align(guess[i])
+        dt, dr = _pose_err(T[i], wT)
+        assert dt < TOL_T and dr < TOL_R, (i, dt, dr)
+        assert conv[i] == wconv and abs(int(its[i]) - wits) <= 1
+        assert abs(fit[i] - g.fitness(wT, 1.0)) < 1e-5
+        gt, gr = _pose_err(T[i], Ttrue)
+        assert gt < 3e-3 and gr < 5e-4
+
+
+def test_mapping_side_configuration(dev, oracle):
+    """global_manager.cpp:2437-2442: k = 15, transEps 1e-3, maxIter 50, maxCorrDist 100."""
+    from mr_slam_amd import gicp
+    src, tgt, _ = _pair(6, 8000)
+    b = gicp.GicpBatch(1)
+    b.set_params(k_correspondences=15, max_correspondence_distance=100.0, max_iterations=50,
+                 transformation_epsilon=1e-3)
+    b.set_sources([src]); b.set_targets([tgt])
+    T, conv, its = b.align()
+    g = oracle.Gicp(k=15, max_corr=100.0, max_iter=50, trans_eps=1e-3)
+    g.set_source(src); g.set_target(tgt)
+    wT, wconv, wits, _ = g.align()
+    dt, dr = _pose_err(T[0], wT)
+    assert dt < TOL_T and dr < TOL_R and conv[0] == wconv
+
+
+def test_pygicp_drop_in(dev, oracle):
+    """The call sequence of main_RING.py:81-104."""
+    from mr_slam_amd.compat import pygicp
+    src, tgt, Ttrue = _pair(7, 30000, (0.0, 0.0, 0.1), (1.0, 0.5, 0.0))
+    source = pygicp.downsample(src.astype(np.float64), 0.2)
+    target = pygicp.downsample(tgt.astype(np.float64), 0.2)
+    assert 1000 < source.shape[0] < src.shape[0]
+    gicp = pygicp.FastGICP()
+    gicp.set_input_target(target)
+    gicp.set_input_source(source)
+    gicp.set_num_threads(4)
+    gicp.set_max_correspondence_distance(5.0)
+    T = gicp.align(initial_guess=np.eye(4))
+    fitness = gicp.get_fitness_score(1.0)
+    assert np.array_equal(T, gicp.get_final_transformation())
+    g = oracle.Gicp(k=20, max_corr=5.0)
+    g.set_source(source); g.set_target(target)
+    wT, _, _, _ = g.align()
+    dt, dr = _pose_err(T, wT)
+    assert dt < TOL_T and dr < TOL_R
+    assert abs(fitness - g.fitness(wT, 1.0)) < 1e-5
+    assert _pose_err(T, Ttrue)[0] < 0.05
+
+
+def test_force_iterations_and_failure_modes(dev):
+    from mr_slam_amd import gicp, _lib
+    src, tgt, _ = _pair(8, 5000)
+    b = gicp.GicpBatch(1)
+    b.set_params(force_iterations=7)
+    b.set_sources([src]); b.set_targets([tgt])
+    T, conv, its = b.align()
+    assert its[0] == 7 and not conv[0]
+    with pytest.raises(_lib.MrsError):
+        b.set_params(k_correspondences=100)
+    with pytest.raises(_lib.MrsError):
+        gicp.GicpBatch(1).align()               # no clouds set
+
+
+def test_full_size_pair(dev):
+    """BASELINE size (120k x 120k): recovers a known transform to the noise floor and the fitness
+    improves; brute-force NN needs no size-dependent structure."""
+    from mr_slam_amd import gicp
+    src, tgt, Ttrue = _pair(9, 120000, (0.01, -0.02, 0.05), (0.5, -0.3, 0.05), noise=0.02)
+    b = gicp.GicpBatch(1)
+    b.set_params(max_correspondence_distance=5.0)
+    b.set_sources([src]); b.set_targets([tgt])
+    f0 = b.fitness(np.eye(4)[None], 1.0)[0]
+    T, conv, its = b.align()
+    f1 = b.fitness(T, 1.0)[0]
+    dt, dr = _pose_err(T[0], Ttrue)
+    assert conv[0] and dt < 5e-3 and dr < 5e-4 and f1 < f0
