@@ -83,6 +83,49 @@ def cpu_baseline(scans, n_sample=4):
     return out
 
 
+def gicp_leg(device_index, rank, n_pairs, iters):
+    """BASELINE configs[2] shape: submap pairs x 120k points, `iters` outer iterations with the
+    convergence test disabled; covariances are timed separately (they are cached per submap)."""
+    from mr_slam_amd import gicp
+    from scipy.spatial.transform import Rotation as Rot
+    rng = np.random.default_rng(2000 + rank)
+    base = [synth.lidar_scan(500 + 10 * rank + s, N_POINTS, metric=True) for s in range(2)]
+    srcs, tgts = [], []
+    for i in range(n_pairs):
+        p = base[i % 2].astype(np.float64)
+        ang = np.deg2rad(rng.uniform(0, 5))
+        axis = rng.normal(size=3); axis /= np.linalg.norm(axis)
+        R = Rot.from_rotvec(ang * axis).as_matrix()
+        t = rng.normal(size=3); t *= rng.uniform(0, 1) / np.linalg.norm(t)
+        srcs.append((p + rng.normal(0, 0.02, p.shape)).astype(np.float32))
+        tgts.append((p @ R.T + t + rng.normal(0, 0.02, p.shape)).astype(np.float32))
+    b = gicp.GicpBatch(n_pairs, device_index)
+    b.set_params(k_correspondences=15, max_correspondence_distance=5.0, force_iterations=iters)
+    b.set_sources(srcs)
+    b.set_targets(tgts)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    b.compute_covariances(0)
+    b.compute_covariances(1)
+    torch.cuda.synchronize()
+    t_cov = time.perf_counter() - t0
+    b.set_params(force_iterations=2)
+    b.align()                                   # warm-up (2 iterations)
+    b.set_params(force_iterations=iters)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    T, conv, its = b.align()
+    torch.cuda.synchronize()
+    t_align = time.perf_counter() - t0
+    assert (its == iters).all()
+    nn_flop = 8.0 * N_POINTS * N_POINTS          # SURVEY 8(d): ~8 flop per (source, target) pair
+    return {"pairs": n_pairs, "iterations": iters, "points": N_POINTS,
+            "iters_per_s": n_pairs * iters / t_align, "align_s": t_align,
+            "nn_passes": b.nn_passes, "nn_tflops": n_pairs * b.nn_passes * nn_flop / t_align / 1e12,
+            "covariance_s": t_cov, "covariance_clouds_per_s": 2 * n_pairs / t_cov, "k": 15,
+            "max_correspondence_distance": 5.0}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,6 +133,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=512, help="scan pairs per rank per step")
     ap.add_argument("--db", type=int, default=4096, help="database size for the sweep-rate leg")
+    ap.add_argument("--gicp-pairs", type=int, default=16, help="120k-pt pairs per rank in the GICP leg (0 = skip)")
+    ap.add_argument("--gicp-iters", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -174,6 +219,16 @@ def main():
         sweep = {"pairs_per_s": nq * args.db / ms * 1e3, "db": args.db, "queries": nq, "ms": ms,
                  "hbm_gbs": args.db * 57600 / ms / 1e6}
 
+    gicp_res = None
+    if args.gicp_pairs > 0:
+        fence()
+        gicp_res = gicp_leg(local_rank, rank, args.gicp_pairs, args.gicp_iters)
+        if dist_on:   # whole-job GICP rate: all ranks' iterations / slowest rank's time
+            t = torch.tensor([gicp_res["align_s"]], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            gicp_res["iters_per_s"] = world * args.gicp_pairs * args.gicp_iters / float(t.item())
+            gicp_res["pairs"] = world * args.gicp_pairs
+
     if rank == 0:
         cells = 120 * 120
         bev_bytes = B * (12 * N_POINTS + 4 * cells)          # 12 B/point + 4 B/cell
@@ -200,6 +255,7 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "algorithmic_bytes_per_launch": bev_bytes},
             "sweep": sweep,
+            "gicp": gicp_res,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scans)

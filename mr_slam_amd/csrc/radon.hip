@@ -8,8 +8,9 @@
 // Design: CDNA has no texture sampler, so the image lives in LDS with a 2-texel zero border
 // (border address mode) and an odd row stride (bank-conflict-free for rays marching along
 // either axis); one workgroup per image, one ray per lane with lanes = consecutive detectors,
-// software bilinear in fp32 (lerp form, 3 FMA).  HBM traffic is 4*H*W in + 4*A*D out per image;
-// the kernel is LDS-read bound (4 ds_read per sample), not HBM bound.
+// samples aligned exactly to texel centres along the ray's dominant axis (integer stepping), 2-tap
+// fp32 interpolation along the minor axis (~14 VALU + 2 ds_read per sample).  HBM traffic is
+// 4*H*W in + 4*A*D out per image; the kernel is VALU/LDS bound, not HBM bound.
 // Numerics are shared with oracle/radon_oracle.c op for op (cos/sin evaluated on the host in
 // double when the plan is built), so HIP == oracle bit for bit.
 #include <cmath>
@@ -35,24 +36,48 @@ struct RadonP {
     const float* cs;
 };
 
-__device__ __forceinline__ float tex2d(const float* img, int stride, int W, int H, float x, float y)
+// Sample loop of one ray.  line: LDS address of (dominant texel line, minor index 0); lstep: its
+// increment per sample; mc/vm: minor-axis coordinate and increment.  STRIDE > 0: compile-time row
+// stride.  Accumulation order is strictly sequential (matches the oracle bit for bit).
+template <bool YDOM, int STRIDE>
+__device__ __forceinline__ float march(const float* line, int lstep, float mc, float vm, int n_steps, int rstride)
 {
-    const float xb = x - 0.5f, yb = y - 0.5f;
-    const float fi = floorf(xb), fj = floorf(yb);
-    const float fx = xb - fi, fy = yb - fj;
-    int i = (int)fi, j = (int)fj;
-    i = min(max(i, -kPad), W);  // texels outside [0,W) read the zero border
-    j = min(max(j, -kPad), H);
-    const float* p = img + (j + kPad) * stride + (i + kPad);
-    const float t00 = p[0], t10 = p[1], t01 = p[stride], t11 = p[stride + 1];
-    const float top = __builtin_fmaf(fx, t10 - t00, t00);
-    const float bot = __builtin_fmaf(fx, t11 - t01, t01);
-    return __builtin_fmaf(fy, bot - top, top);
+    const int unit = YDOM ? 1 : (STRIDE > 0 ? STRIDE : rstride);  // distance between the two taps
+    float acc = 0.0f;
+    int j = 0;
+    for (; j + 4 <= n_steps; j += 4) {   // 4 samples in flight: addresses first, then the taps
+        float fr[4], t0[4], t1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float mb = mc - 0.5f;
+            const float fl = floorf(mb);
+            fr[u] = mb - fl;
+            const float* q = line + (int)fl * unit;
+            t0[u] = q[0];
+            t1[u] = q[unit];
+            mc += vm;
+            line += lstep;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += __builtin_fmaf(fr[u], t1[u] - t0[u], t0[u]);
+    }
+    for (; j < n_steps; ++j) {
+        const float mb = mc - 0.5f;
+        const float fl = floorf(mb);
+        const float* q = line + (int)fl * unit;
+        const float t0 = q[0], t1 = q[unit];
+        acc += __builtin_fmaf(mb - fl, t1 - t0, t0);
+        mc += vm;
+        line += lstep;
+    }
+    return acc;
 }
 
 // forward.cu:18-123 for one ray (a, r)
+template <int STRIDE>
 __device__ __forceinline__ float trace_ray(const float* img, const RadonP& p, int a, int r)
 {
+    const int stride = STRIDE > 0 ? STRIDE : p.stride;
     const float cs = p.cs[2 * a], sn = p.cs[2 * a + 1];
     const float sx = ((float)r - (float)p.D * 0.5f + 0.5f) * p.spacing;
     const float sy = p.L, ex = sx, ey = -p.L;
@@ -89,12 +114,20 @@ __device__ __forceinline__ float trace_ray(const float* img, const RadonP& p, in
     }
     rsx += step * vx;
     rsy += step * vy;
+    // dominant axis: integer texel line stepping by +-1; minor axis: cumulative float coordinate,
+    // 2-tap interpolation.  The two orientations get their own loop (wave-uniform branch except
+    // for the one wave in 15 that straddles the 45-degree switch) so that both taps come from one
+    // ds_read2_b32 and no per-sample integer multiply is needed.  Indices stay inside the 2-texel
+    // zero border: the alignment step is in [0,1] and n_steps = rint(length), so a ray overshoots
+    // its exit point by at most half a texel.
+    const bool ydom = fabsf(rdy) >= fabsf(rdx);
+    const int major = (int)floorf(ydom ? rsy : rsx);
+    const bool neg = (ydom ? vy : vx) < 0;
     float acc = 0.0f;
-    for (int j = 0; j < n_steps; ++j) {
-        acc += tex2d(img, p.stride, p.W, p.H, rsx, rsy);
-        rsx += vx;
-        rsy += vy;
-    }
+    if (ydom)
+        acc = march<true, STRIDE>(img + (major + kPad) * stride + kPad, neg ? -stride : stride, rsx, vx, n_steps, stride);
+    else
+        acc = march<false, STRIDE>(img + kPad * stride + (major + kPad), neg ? -1 : 1, rsy, vy, n_steps, stride);
     return acc * n;
 }
 
@@ -107,7 +140,7 @@ __device__ __forceinline__ double wave_sum(double v)
 // One workgroup per image.  sino_raw / sino_norm may each be null.
 // sino_norm = (S - mean(S)) / std(S) with the unbiased std over the whole sinogram
 // (util.py:197: fn.normalize(pc_RING, mean=pc_RING.mean(), std=pc_RING.std())).
-template <int MAX_RAYS_PER_LANE>
+template <int MAX_RAYS_PER_LANE, int STRIDE>
 __global__ __launch_bounds__(kRadonWG) void k_radon(const float* __restrict__ img, RadonP p,
                                                     float* __restrict__ sino_raw,
                                                     float* __restrict__ sino_norm)
@@ -134,7 +167,7 @@ __global__ __launch_bounds__(kRadonWG) void k_radon(const float* __restrict__ im
         float v = 0.0f;
         if (ray < rays) {
             const int a = ray / p.D, r = ray - a * p.D;
-            v = trace_ray(tile, p, a, r);
+            v = trace_ray<STRIDE>(tile, p, a, r);
             if (sino_raw) sino_raw[(size_t)b * rays + ray] = v;
             s1 += (double)v;
         }
@@ -191,7 +224,7 @@ __global__ __launch_bounds__(kRadonWG) void k_radon_big(const float* __restrict_
     const int rays = p.A * p.D;
     for (int ray = threadIdx.x; ray < rays; ray += kRadonWG) {
         const int a = ray / p.D, r = ray - a * p.D;
-        sino_raw[(size_t)b * rays + ray] = trace_ray(tile, p, a, r);
+        sino_raw[(size_t)b * rays + ray] = trace_ray<0>(tile, p, a, r);
     }
 }
 
@@ -301,7 +334,7 @@ int mrs_radon_forward(mrs_radon_plan* plan, const float* d_img, int32_t batch, f
     const int rays = p.A * p.D;
     const int per_lane = (rays + kRadonWG - 1) / kRadonWG;
     if (per_lane <= 16) {
-        auto kern = per_lane <= 15 ? k_radon<15> : k_radon<16>;
+        auto kern = per_lane <= 15 ? (p.stride == 125 ? k_radon<15, 125> : k_radon<15, 0>) : k_radon<16, 0>;
         if (lds > 48 * 1024)
             MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -12,7 +12,12 @@
  * construction (hardware 8-bit bilinear weights, __sinf/__cosf); the deviations chosen here
  * are stated in DESIGN.md and shared with the HIP kernel so that HIP == oracle bit for bit:
  *   - cos/sin of the angle: (float)cos((double)a), (float)sin((double)a)   [ref: __cosf/__sinf]
- *   - bilinear weights in full fp32, lerp form with fused multiply-add      [ref: 1.8 fixed point]
+ *   - interpolation weights in full fp32, lerp form with fused multiply-add [ref: 1.8 fixed point]
+ *   - the reference aligns the samples of a ray to pixel centres along its dominant axis
+ *     (forward.cu:100-112), so the bilinear weight along that axis is 0 up to float drift
+ *     (1e-6, far below the texture unit's 1/256 weight resolution).  The alignment is made
+ *     exact here: the dominant-axis texel index is an integer that steps by +-1, and each sample
+ *     is a 2-tap linear interpolation along the minor axis.                [ref: 4-tap HW fetch]
  *   - hypot(a,b) -> sqrtf(a*a + b*b)                                        [ref: CUDA hypot]
  */
 #include <math.h>
@@ -24,18 +29,17 @@ static inline float orc_texel(const float *img, int W, int H, int i, int j)
     return (i < 0 || j < 0 || i >= W || j >= H) ? 0.0f : img[(size_t)j * W + i];
 }
 
-/* tex2D at unnormalised (x, y): texel (i,j) is centred at (i+0.5, j+0.5) */
-static inline float orc_tex2d(const float *img, int W, int H, float x, float y)
+/* linear interpolation along the minor axis at minor coordinate m (texel centres at +0.5),
+ * on the texel line `major` of the dominant axis; ydom selects which image axis is which */
+static inline float orc_tex1d(const float *img, int W, int H, int ydom, int major, float m)
 {
-    const float xb = x - 0.5f, yb = y - 0.5f;
-    const float fi = floorf(xb), fj = floorf(yb);
-    const float fx = xb - fi, fy = yb - fj;
-    const int i = (int)fi, j = (int)fj;
-    const float t00 = orc_texel(img, W, H, i, j), t10 = orc_texel(img, W, H, i + 1, j);
-    const float t01 = orc_texel(img, W, H, i, j + 1), t11 = orc_texel(img, W, H, i + 1, j + 1);
-    const float top = fmaf(fx, t10 - t00, t00);
-    const float bot = fmaf(fx, t11 - t01, t01);
-    return fmaf(fy, bot - top, top);
+    const float mb = m - 0.5f;
+    const float fl = floorf(mb);
+    const float fr = mb - fl;
+    const int i = (int)fl;
+    const float t0 = ydom ? orc_texel(img, W, H, i, major) : orc_texel(img, W, H, major, i);
+    const float t1 = ydom ? orc_texel(img, W, H, i + 1, major) : orc_texel(img, W, H, major, i + 1);
+    return fmaf(fr, t1 - t0, t0);
 }
 
 /* One sinogram: img [H][W] -> sino [n_angles][det].  Volume centre 0, voxel size 1
@@ -85,11 +89,17 @@ void orc_radon_parallel(const float *img, int H, int W, const float *angles, int
             }
             rsx += step * vx;
             rsy += step * vy;
+            /* dominant axis: integer texel line stepping by +-1; minor axis: cumulative float */
+            const int ydom = fabsf(rdy) >= fabsf(rdx);
+            int major = (int)floorf(ydom ? rsy : rsx);
+            const int mstep = (ydom ? vy : vx) < 0 ? -1 : 1;
+            float mc = ydom ? rsx : rsy;      /* minor-axis coordinate */
+            const float vm = ydom ? vx : vy;
             float acc = 0.0f;
             for (int j = 0; j < n_steps; ++j) {
-                acc += orc_tex2d(img, W, H, rsx, rsy);
-                rsx += vx;
-                rsy += vy;
+                acc += orc_tex1d(img, W, H, ydom, major, mc);
+                mc += vm;
+                major += mstep;
             }
             *dst = acc * n;
         }
