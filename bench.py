@@ -233,6 +233,14 @@ def main():
         cells = 120 * 120
         bev_bytes = B * (12 * N_POINTS + 4 * cells)          # 12 B/point + 4 B/cell
         achieved = bev_bytes / (kern_ms["bev"] * 1e-3) / 1e9
+        # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected
+        # per MI355X_MICROARCH.md; counters cannot be read from inside this process)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            traffic = pmc.get(f"k_cart_lds@grid{B * 1024}", {}).get("hbm_bytes")
+        except OSError:
+            pass
         line = {
             "metric": "loop-candidate pairs/sec (BEV+Radon+corr), 120k-pt scans",
             "value": world * B * args.steps / elapsed,
@@ -253,7 +261,8 @@ def main():
             "kernel_ms": kern_ms,
             "roofline": {"kernel": "k_cart_lds (BEV scatter)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": bev_bytes},
+                         "traffic": traffic, "algorithmic_bytes_per_launch": bev_bytes,
+                         "traffic_source": "profiles/r01_pmc_traffic.json (PMC pass of this command)" if traffic else None},
             "sweep": sweep,
             "gicp": gicp_res,
         }

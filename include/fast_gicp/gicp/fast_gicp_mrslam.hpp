@@ -1,0 +1,135 @@
+// fast_gicp_mrslam.hpp -- C++ host-side mirror of fast_gicp::FastGICP for the Mapping workspace.
+//
+// Drop-in for the class Mapping/src/global_manager/src/global_manager.cpp:2435-2443 instantiates
+// (`fast_gicp::FastGICP<pcl::PointXYZI, pcl::PointXYZI>` returned as
+// `pcl::Registration<pcl::PointXYZI, pcl::PointXYZI>::Ptr`) and drives at :2016-2021
+// (setInputSource / setInputTarget / align) and :2058-2071 (hasConverged / getFitnessScore /
+// getFinalTransformation).  All arithmetic happens in libmrslam_hip.so through the C ABI
+// (include/mrslam_hip.h); this header only adapts types.  It needs PCL + Eigen, which are not in
+// the build image: tests/cpp/ compiles it against a minimal mock of the pcl::Registration
+// surface it touches.  A maintainer installs it as <fast_gicp/gicp/fast_gicp.hpp> (see
+// INTEGRATION.md).
+#pragma once
+#include <cfloat>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "mrslam_hip.h"
+
+#include <hip/hip_runtime_api.h>  // hipMalloc / hipMemcpy for the point upload
+
+namespace fast_gicp {
+
+enum class RegularizationMethod { NONE, MIN_EIG, NORMALIZED_MIN_EIG, PLANE, FROBENIUS };
+enum class NeighborSearchMethod { DIRECT27, DIRECT7, DIRECT1, DIRECT_RADIUS };
+
+template <typename PointSource, typename PointTarget>
+class FastGICP : public pcl::Registration<PointSource, PointTarget, float> {
+public:
+    using Base = pcl::Registration<PointSource, PointTarget, float>;
+    using PointCloudSource = typename Base::PointCloudSource;
+    using PointCloudSourceConstPtr = typename Base::PointCloudSourceConstPtr;
+    using PointCloudTargetConstPtr = typename Base::PointCloudTargetConstPtr;
+    using Matrix4 = typename Base::Matrix4;
+
+    FastGICP()
+    {
+        this->reg_name_ = "FastGICP(mrslam_hip)";
+        mrs_gicp_default_params(&prm_);
+        this->max_iterations_ = prm_.max_iterations;
+        this->transformation_epsilon_ = prm_.transformation_epsilon;
+        check(mrs_ctx_create(0, &ctx_), "mrs_ctx_create");
+        check(mrs_gicp_batch_create(ctx_, 1, &h_), "mrs_gicp_batch_create");
+    }
+    ~FastGICP() override
+    {
+        mrs_gicp_batch_destroy(h_);
+        mrs_ctx_destroy(ctx_);
+    }
+    FastGICP(const FastGICP&) = delete;
+    FastGICP& operator=(const FastGICP&) = delete;
+
+    void setNumThreads(int) {}  // OpenMP width of the CPU implementation; no meaning on the GPU
+    void setCorrespondenceRandomness(int k) { prm_.k_correspondences = k; }
+    void setRotationEpsilon(double e) { prm_.rotation_epsilon = e; }
+    void setRegularizationMethod(RegularizationMethod m)
+    {
+        if (m != RegularizationMethod::PLANE) throw std::invalid_argument("only PLANE regularisation is implemented");
+    }
+
+    void setInputSource(const PointCloudSourceConstPtr& cloud) override
+    {
+        Base::setInputSource(cloud);
+        upload(0, *cloud);
+    }
+    void setInputTarget(const PointCloudTargetConstPtr& cloud) override
+    {
+        Base::setInputTarget(cloud);
+        upload(1, *cloud);
+    }
+
+    // pcl::Registration::getFitnessScore(max_range): routed to the GPU NN pass (G6)
+    double getFitnessScore(double max_range = DBL_MAX)
+    {
+        double pose[16], score = DBL_MAX;
+        to_row_major(this->final_transformation_, pose);
+        check(mrs_gicp_batch_fitness(h_, pose, max_range, &score, nullptr), "mrs_gicp_batch_fitness");
+        return score;
+    }
+
+    const double* getFinalHessian() const { return hessian_; }
+
+protected:
+    void computeTransformation(PointCloudSource& output, const Matrix4& guess) override
+    {
+        prm_.max_iterations = this->max_iterations_;
+        prm_.transformation_epsilon = this->transformation_epsilon_;
+        prm_.max_correspondence_distance = this->corr_dist_threshold_;
+        check(mrs_gicp_batch_set_params(h_, &prm_), "mrs_gicp_batch_set_params");
+        double g[16], f[16];
+        to_row_major(guess, g);
+        int32_t conv = 0, iters = 0;
+        check(mrs_gicp_batch_align(h_, g, f, &conv, &iters, hessian_, nullptr), "mrs_gicp_batch_align");
+        for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < 4; ++c) this->final_transformation_(r, c) = static_cast<float>(f[4 * r + c]);
+        this->converged_ = conv != 0;
+        this->nr_iterations_ = iters;
+        pcl::transformPointCloud(*this->input_, output, this->final_transformation_);
+    }
+
+private:
+    template <class Cloud>
+    void upload(int which, const Cloud& cloud)
+    {
+        // PCL points are 16-byte aligned structs whose first three floats are x, y, z
+        const int stride = static_cast<int>(sizeof(typename Cloud::PointType) / sizeof(float));
+        const size_t bytes = cloud.points.size() * sizeof(typename Cloud::PointType);
+        float* d = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&d), bytes) != hipSuccess ||
+            hipMemcpy(d, cloud.points.data(), bytes, hipMemcpyHostToDevice) != hipSuccess)
+            throw std::runtime_error("FastGICP(mrslam_hip): point upload failed");
+        const int64_t offs[2] = {0, static_cast<int64_t>(cloud.points.size())};
+        const int st = mrs_gicp_batch_set_clouds(h_, which, d, stride, offs, nullptr);
+        (void)hipFree(d);
+        check(st, "mrs_gicp_batch_set_clouds");
+    }
+    template <class M>
+    static void to_row_major(const M& m, double* out)
+    {
+        for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < 4; ++c) out[4 * r + c] = static_cast<double>(m(r, c));
+    }
+    static void check(int st, const char* what)
+    {
+        if (st != MRS_OK)
+            throw std::runtime_error(std::string(what) + ": " + mrs_status_str(st) + ": " + mrs_last_error());
+    }
+
+    mrs_ctx* ctx_ = nullptr;
+    mrs_gicp_batch* h_ = nullptr;
+    mrs_gicp_params prm_;
+    double hessian_[36] = {0};
+};
+
+}  // namespace fast_gicp

@@ -1,0 +1,35 @@
+"""The C++ `fast_gicp::FastGICP` adapter (include/fast_gicp/gicp/fast_gicp_mrslam.hpp) compiled
+against a mock of the pcl::Registration surface (PCL/Eigen are not in the image)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "cpp", "build", "adapter_test")
+
+
+def _compile():
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    lib_dir = os.path.join(ROOT, "mr_slam_amd")
+    if not os.path.exists(os.path.join(lib_dir, "libmrslam_hip.so")):
+        import __graft_entry__
+        __graft_entry__.build()
+    cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+           "-I" + os.path.join(ROOT, "tests", "cpp"), os.path.join(ROOT, "tests", "cpp", "adapter_main.cpp"),
+           "-o", OUT, "-L" + lib_dir, "-lmrslam_hip", "-Wl,-rpath," + lib_dir]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_adapter_compiles_and_links():
+    _compile()
+    assert os.path.exists(OUT)
+
+
+@pytest.mark.gpu
+def test_adapter_runs_icpcheck_call_sequence():
+    _compile()
+    r = subprocess.run([OUT], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "converged=1" in r.stdout
