@@ -271,6 +271,35 @@ int mrs_gicp_batch_fitness(mrs_gicp_batch* h, const double* h_poses, double max_
 /* number of brute-force NN passes the last align() issued (for iterations/s accounting) */
 double mrs_gicp_batch_last_nn_passes(const mrs_gicp_batch* h);
 
+/* ------------------------------------------------------------------------------------
+ * rocFFT-backed 2-D correlations: DiSCO (rows D1, D2) and RING++ BEV translation (row C4)
+ * ---------------------------------------------------------------------------------- */
+
+/* D1: DiSCO.forward with the UNet bypassed, as the ROS node runs it
+ * (disco_ros/models/DiSCO.py:315-334, fftshift2d :280-294).
+ * d_bev float[batch][num_height][num_ring][num_sector] (polar occupancy, mrs_bev_polar_batch COMPACT)
+ * -> d_signature float[batch][4*col*col] (shifted magnitude, centre crop; col = 16 -> 1024-d) and
+ *    d_spectrum interleaved complex64 [batch][num_ring][num_sector] (ortho fft2 of the height sum). */
+int mrs_disco_descriptor(mrs_ctx* ctx, const float* d_bev, int32_t batch, int32_t num_height, int32_t num_ring,
+                         int32_t num_sector, int32_t col, float* d_signature, float* d_spectrum, mrs_stream stream);
+
+/* D2: phase_corr(a, b) (disco_ros/main.py:260-272) for n_pairs spectra pairs.
+ * d_flat_argmax int32[n_pairs] = flat argmax of the shifted magnitude map (the reference then takes
+ * `% num_sector`; the host mirror does that); d_corr (optional) float[n_pairs][num_ring][num_sector]. */
+int mrs_disco_phase_corr(mrs_ctx* ctx, const float* d_a, const float* d_b, int32_t n_pairs, int32_t num_ring,
+                         int32_t num_sector, int32_t* d_flat_argmax, float* d_corr, mrs_stream stream);
+
+/* C4: solve_translation_bev(a, b) (RING_ros/util.py:427-450): d_a, d_b float[n_pairs][channels][H][W];
+ * d_arg int32[n_pairs] = flat (row-major) index of the first maximum of the shifted correlation map,
+ * d_max (optional) float[n_pairs] its value, d_corr (optional) float[n_pairs][H][W] the map. */
+int mrs_bev_translation(mrs_ctx* ctx, const float* d_a, const float* d_b, int32_t n_pairs, int32_t channels,
+                        int32_t height, int32_t width, int32_t* d_arg, float* d_max, float* d_corr, mrs_stream stream);
+
+/* rotate_bev (RING_ros/util.py:67-70 -> torchvision rotate: nearest, about the centre, zero fill).
+ * d_img float[n_images][H][W]; image i uses d_angle_deg[i / images_per_angle] (degrees, counter-clockwise). */
+int mrs_rotate_nearest(mrs_ctx* ctx, const float* d_img, int32_t n_images, int32_t images_per_angle, int32_t height,
+                       int32_t width, const float* d_angle_deg, float* d_out, mrs_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

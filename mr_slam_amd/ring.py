@@ -195,3 +195,44 @@ def solve_translation(query, positive, rot_angle, device="cuda:0", want_shifts=F
     r = res.cpu().numpy()
     out = (r[0:1].copy(), r[1:2].copy(), r[2])
     return out + (sh.cpu().numpy(),) if want_shifts else out
+
+
+def rotate_bev(bev_img, angle):
+    """util.py:67-70: rotate a [C,H,W] (or [N,C,H,W] with one angle per N) BEV by `angle` radians
+    (torchvision rotate defaults: nearest, about the centre, zero fill)."""
+    d = _dev(bev_img)
+    x = bev_img.contiguous()
+    single = x.dim() == 3
+    if single:
+        x = x[None]
+    N, Cc, H, W = x.shape
+    ang = torch.as_tensor(np.atleast_1d(np.asarray(angle, dtype=np.float64)) * 180.0 / np.pi, dtype=torch.float32).to(x.device)
+    assert ang.numel() == N
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().mrs_rotate_nearest(_lib.ctx(d), _lib.ptr(x), N * Cc, Cc, H, W, _lib.ptr(ang), _lib.ptr(out),
+                                              _lib.current_stream(d)))
+    return out[0] if single else out
+
+
+def solve_translation_bev(a, b, want_corr=False, num_ring=NUM_RING, num_sector=NUM_SECTOR):
+    """util.py:427-450 for P pairs: a, b float32 [P,C,H,W] (device) or [C,H,W].
+    Returns (y, x, -max) per pair exactly like the reference's return order."""
+    single = a.dim() == 3
+    if single:
+        a, b = a[None], b[None]
+    d = _dev(a)
+    a, b = a.contiguous(), b.contiguous()
+    P, Cc, H, W = a.shape
+    arg = torch.empty(P, dtype=torch.int32, device=a.device)
+    mx = torch.empty(P, dtype=torch.float32, device=a.device)
+    corr = torch.empty((P, H, W), dtype=torch.float32, device=a.device) if want_corr else None
+    _lib.check(_lib.load().mrs_bev_translation(_lib.ctx(d), _lib.ptr(a), _lib.ptr(b), P, Cc, H, W, _lib.ptr(arg),
+                                               _lib.ptr(mx), _lib.ptr(corr) if want_corr else None,
+                                               _lib.current_stream(d)))
+    arg = arg.cpu().numpy()
+    idx_x, idx_y = arg // W, arg % W
+    x = idx_x - num_sector // 2
+    y = num_ring // 2 - idx_y
+    neg = -mx.cpu().numpy()
+    out = (y[0], x[0], neg[0]) if single else (y, x, neg)
+    return out + (corr,) if want_corr else out
