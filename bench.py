@@ -118,10 +118,10 @@ def gicp_leg(device_index, rank, n_pairs, iters):
     torch.cuda.synchronize()
     t_align = time.perf_counter() - t0
     assert (its == iters).all()
-    nn_flop = 8.0 * N_POINTS * N_POINTS          # ~8 flop per (source, target) pair
     return {"pairs": n_pairs, "iterations": iters, "points": N_POINTS,
             "iters_per_s": n_pairs * iters / t_align, "align_s": t_align,
-            "nn_passes": b.nn_passes, "nn_tflops": n_pairs * b.nn_passes * nn_flop / t_align / 1e12,
+            "nn_passes": b.nn_passes, "nn_pass_ms": 1e3 * t_align / (n_pairs * b.nn_passes),
+            "nn_search": "exact brute force over Morton-ordered LDS tiles with conservative bounding-box culling",
             "covariance_s": t_cov, "covariance_clouds_per_s": 2 * n_pairs / t_cov, "k": 15,
             "max_correspondence_distance": 5.0}
 

@@ -13,14 +13,22 @@
 //
 // Design: kd-tree-free.  Every nearest-neighbour query is an exact brute-force scan: target
 // points are staged through LDS in tiles of 1024 float4 and read back as wave-wide broadcasts
-// (one ds_read_b128 per candidate per wave), two source points per lane, ~7 VALU ops per
-// (source, target) pair.  That scan is VALU-bound (N*M*7 lane-ops per pass, 1.0e11 at 120k x 120k);
+// (one ds_read_b128 per candidate per wave), four source points per lane, ~7 VALU ops per
+// (source, target) pair; at 120k x 120k the un-culled scan runs at ~95 % of the VALU issue peak.
+// Both clouds are stored in Morton order (rocPRIM radix sort at set_clouds time), so a tile of 1024
+// consecutive points is spatially compact and carries an axis-aligned bounding box: a workgroup
+// (1024 consecutive, i.e. equally compact, queries) visits the tiles in order of increasing
+// box-to-box distance and skips every tile whose box is farther than what all of its lanes already
+// have (or than max_correspondence_distance).  The culling is conservative, so the neighbours are
+// still the exact ones.  The scan is VALU-bound (7 lane-ops per surviving (source, target) pair);
 // the per-point 3x3 algebra and the 28-term fp64 reductions (wave __shfl butterflies -> one
 // partial per workgroup -> fixed-order final sum) are noise next to it.  All pairs of a batch
 // advance together; the Levenberg-Marquardt bookkeeping runs on the device (one lane per
 // pair), so the host only polls a "pairs still active" counter.  The evaluation at an accepted
 // candidate is reused as the next iteration's linearisation, which halves the number of NN
 // passes per iteration relative to the reference without changing results.
+#include <hipcub/hipcub.hpp>
+
 #include <cfloat>
 #include <cmath>
 
@@ -30,8 +38,9 @@ namespace {
 
 constexpr int kTile = 1024;      // target points per LDS tile
 constexpr int kNNThreads = 256;  // lanes per workgroup
-constexpr int kPts = 2;          // source points per lane
+constexpr int kPts = 4;          // source points per lane
 constexpr int kTerms = 28;       // 21 (H upper) + 6 (b) + 1 (error)
+constexpr int kMaxOrder = 512;   // tiles per cloud that get distance-ordered traversal (512k points)
 
 struct LmState {
     double x[16];      // accepted pose (row-major 4x4)
@@ -76,27 +85,109 @@ __device__ __forceinline__ float dist2(float qx, float qy, float qz, const float
     return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
 }
 
-// Exact 1-NN of P query points per lane over tgt[0..m): returns squared distance + index
-// (ties -> the smaller index).  Whole workgroup must call it together.
+struct TileBoxes {
+    const float4* lo;  // [ntiles] min corner of tile t (points [1024 t, 1024 t + 1024) of the cloud)
+    const float4* hi;
+    int ntiles;
+};
+
+struct ScanShared {
+    float4 tile[kTile];
+    float lb[kMaxOrder];
+    short order[kMaxOrder];
+    float qlo[4][3], qhi[4][3];
+};
+
+__device__ __forceinline__ float box_point_d2(const float4& lo, const float4& hi, float x, float y, float z)
+{
+    const float dx = fmaxf(fmaxf(lo.x - x, x - hi.x), 0.0f);
+    const float dy = fmaxf(fmaxf(lo.y - y, y - hi.y), 0.0f);
+    const float dz = fmaxf(fmaxf(lo.z - z, z - hi.z), 0.0f);
+    return dx * dx + dy * dy + dz * dz;
+}
+
+// Orders the target tiles of one cloud by their distance to the bounding box of the workgroup's
+// live queries (sh.order / sh.lb, ascending; tiles beyond `maxc2` get lb = +inf and sort last).
+// (lo, hi): this lane's own query bounds (+inf / -inf when it has no live query).
+__device__ __forceinline__ void order_tiles(ScanShared& sh, const TileBoxes& tb, float maxc2, float lo[3], float hi[3])
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64));
+        }
+        if (lane == 0) { sh.qlo[wave][a] = lo[a]; sh.qhi[wave][a] = hi[a]; }
+    }
+    __syncthreads();
+    float blo[3], bhi[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        blo[a] = fminf(fminf(sh.qlo[0][a], sh.qlo[1][a]), fminf(sh.qlo[2][a], sh.qlo[3][a]));
+        bhi[a] = fmaxf(fmaxf(sh.qhi[0][a], sh.qhi[1][a]), fmaxf(sh.qhi[2][a], sh.qhi[3][a]));
+    }
+    const int nt = min(tb.ntiles, kMaxOrder);
+    for (int t = threadIdx.x; t < nt; t += kNNThreads) {
+        const float4 l = tb.lo[t], h = tb.hi[t];
+        const float dx = fmaxf(fmaxf(l.x - bhi[0], blo[0] - h.x), 0.0f);
+        const float dy = fmaxf(fmaxf(l.y - bhi[1], blo[1] - h.y), 0.0f);
+        const float dz = fmaxf(fmaxf(l.z - bhi[2], blo[2] - h.z), 0.0f);
+        const float d = dx * dx + dy * dy + dz * dz;
+        sh.lb[t] = d * 0.9999f > maxc2 ? INFINITY : d;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < nt; t += kNNThreads) {  // rank sort (ntiles is ~120 for a 120k cloud)
+        const float mine = sh.lb[t];
+        int rank = 0;
+        for (int u = 0; u < nt; ++u) {
+            const float o = sh.lb[u];
+            rank += (o < mine || (o == mine && u < t)) ? 1 : 0;
+        }
+        sh.order[rank] = (short)t;
+    }
+    __syncthreads();
+}
+
+// Exact 1-NN of P query points per lane over the Morton-ordered cloud tgt[0..m): squared distance
+// and (sorted-space) index.  Tiles are culled conservatively with their bounding boxes; `maxc2` is
+// the rejection radius (inf = none).  The whole workgroup must call it together.
 template <int P>
-__device__ __forceinline__ void nn_scan(const float4* __restrict__ tgt, int m, const float (&qx)[P],
-                                        const float (&qy)[P], const float (&qz)[P], float4* tile,
-                                        float (&best)[P], int (&bidx)[P])
+__device__ __forceinline__ void nn_scan(const float4* __restrict__ tgt, int m, const TileBoxes& tb, float maxc2,
+                                        const float (&qx)[P], const float (&qy)[P], const float (&qz)[P],
+                                        const bool (&live)[P], ScanShared& sh, float (&best)[P], int (&bidx)[P])
 {
     int grp[P];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-    for (int p = 0; p < P; ++p) { best[p] = INFINITY; grp[p] = -1; }
-    for (int t0 = 0; t0 < m; t0 += kTile) {
+    for (int p = 0; p < P; ++p) {
+        best[p] = INFINITY; grp[p] = -1;
+        if (live[p]) {
+            lo[0] = fminf(lo[0], qx[p]); hi[0] = fmaxf(hi[0], qx[p]);
+            lo[1] = fminf(lo[1], qy[p]); hi[1] = fmaxf(hi[1], qy[p]);
+            lo[2] = fminf(lo[2], qz[p]); hi[2] = fmaxf(hi[2], qz[p]);
+        }
+    }
+    order_tiles(sh, tb, maxc2, lo, hi);
+    for (int k = 0; k < tb.ntiles; ++k) {
+        const int t = k < kMaxOrder ? (int)sh.order[k] : k;
+        if (k < kMaxOrder && sh.lb[t] == INFINITY) break;  // this and every later tile: beyond maxc2
+        const float4 blo = tb.lo[t], bhi = tb.hi[t];
+        bool need = false;
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+            need |= live[p] && box_point_d2(blo, bhi, qx[p], qy[p], qz[p]) * 0.9999f <= fminf(best[p], maxc2);
+        if (!__syncthreads_or(need)) continue;
+        const int t0 = t * kTile;
         const int cnt = min(kTile, m - t0);
-        __syncthreads();
         for (int i = threadIdx.x; i < kTile; i += kNNThreads)
-            tile[i] = i < cnt ? tgt[t0 + i] : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
+            sh.tile[i] = i < cnt ? tgt[t0 + i] : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
         __syncthreads();
         const int groups = (cnt + 7) >> 3;
         for (int g = 0; g < groups; ++g) {
             float4 c[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) c[u] = tile[8 * g + u];
+            for (int u = 0; u < 8; ++u) c[u] = sh.tile[8 * g + u];
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 float d[8];
@@ -106,6 +197,7 @@ __device__ __forceinline__ void nn_scan(const float4* __restrict__ tgt, int m, c
                 if (mn < best[p]) { best[p] = mn; grp[p] = t0 + 8 * g; }
             }
         }
+        // the next __syncthreads_or also protects sh.tile against early overwriting
     }
     // resolve the index inside the winning group of 8
 #pragma unroll
@@ -120,10 +212,127 @@ __device__ __forceinline__ void nn_scan(const float4* __restrict__ tgt, int m, c
     }
 }
 
-__global__ void k_pack_points(const float* __restrict__ src, int stride, size_t n, float4* __restrict__ dst)
+// ---- Morton ordering of the clouds (set_clouds) ------------------------------------------------
+__device__ __forceinline__ int float_to_ordered(float f)
 {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        dst[i] = make_float4(src[i * stride], src[i * stride + 1], src[i * stride + 2], 0.f);
+    const int i = __float_as_int(f);
+    return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__device__ __forceinline__ float ordered_to_float(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+// per-cloud bounding box: bbox[c] = {min x,y,z, max x,y,z} as ordered ints (pre-set to +-max)
+__global__ void k_cloud_bbox(const float* __restrict__ src, int stride, const int64_t* __restrict__ offs, int* __restrict__ bbox)
+{
+    const int c = blockIdx.y;
+    const int64_t o = offs[c];
+    const int n = (int)(offs[c + 1] - o);
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float* p = src + (size_t)(o + i) * stride;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], p[a]); hi[a] = fmaxf(hi[a], p[a]); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        for (int s = 32; s > 0; s >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], s, 64));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], s, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&bbox[6 * c + a], float_to_ordered(lo[a]));
+            atomicMax(&bbox[6 * c + 3 + a], float_to_ordered(hi[a]));
+        }
+    }
+}
+
+__device__ __forceinline__ unsigned long long spread3(unsigned v)  // 14 bits -> every third bit
+{
+    unsigned long long x = v & 0x3fffu;
+    x = (x | (x << 32)) & 0x1f00000000ffffull;
+    x = (x | (x << 16)) & 0x1f0000ff0000ffull;
+    x = (x | (x << 8)) & 0x100f00f00f00f00full;
+    x = (x | (x << 4)) & 0x10c30c30c30c30c3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+
+// key = cloud id (high bits) | 42-bit Morton code on a cubic grid spanning the cloud's bounding box
+__global__ void k_morton_keys(const float* __restrict__ src, int stride, const int64_t* __restrict__ offs,
+                              const int* __restrict__ bbox, unsigned long long* __restrict__ keys, int* __restrict__ vals)
+{
+    const int c = blockIdx.y;
+    const int64_t o = offs[c];
+    const int n = (int)(offs[c + 1] - o);
+    float lo[3], ext = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = ordered_to_float(bbox[6 * c + a]);
+        ext = fmaxf(ext, ordered_to_float(bbox[6 * c + 3 + a]) - lo[a]);
+    }
+    const float sc = ext > 0.0f ? 16383.0f / ext : 0.0f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float* p = src + (size_t)(o + i) * stride;
+        unsigned q[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = (p[a] - lo[a]) * sc;
+            q[a] = v >= 0.0f ? (unsigned)fminf(v, 16383.0f) : 0u;  // NaN -> 0
+        }
+        keys[o + i] = ((unsigned long long)c << 42) | spread3(q[0]) | (spread3(q[1]) << 1) | (spread3(q[2]) << 2);
+        vals[o + i] = (int)(o + i);
+    }
+}
+
+// dst[k] = point perm[k]; .w carries its ORIGINAL cloud-local index
+__global__ void k_gather_sorted(const float* __restrict__ src, int stride, const int64_t* __restrict__ offs,
+                                const int* __restrict__ perm, float4* __restrict__ dst)
+{
+    const int c = blockIdx.y;
+    const int64_t o = offs[c];
+    const int n = (int)(offs[c + 1] - o);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int g = perm[o + i];
+        const float* p = src + (size_t)g * stride;
+        dst[o + i] = make_float4(p[0], p[1], p[2], __int_as_float(g - (int)o));
+    }
+}
+
+// bounding box of every 1024-point tile; tile_base[c] = first tile of cloud c
+__global__ __launch_bounds__(256) void k_tile_boxes(const float4* __restrict__ pts, const int64_t* __restrict__ offs,
+                                                    const int* __restrict__ tile_base, float4* __restrict__ tlo,
+                                                    float4* __restrict__ thi)
+{
+    __shared__ float red[4][6];
+    const int c = blockIdx.y;
+    const int64_t o = offs[c];
+    const int n = (int)(offs[c + 1] - o);
+    const int t = blockIdx.x;
+    if (t * kTile >= n) return;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = t * kTile + threadIdx.x; i < min(n, (t + 1) * kTile); i += 256) {
+        const float4 p = pts[o + i];
+        lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
+        lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
+        lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        for (int s = 32; s > 0; s >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], s, 64));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], s, 64));
+        }
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][a] = lo[a]; red[threadIdx.x >> 6][3 + a] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float l[3], h[3];
+        for (int a = 0; a < 3; ++a) {
+            l[a] = fminf(fminf(red[0][a], red[1][a]), fminf(red[2][a], red[3][a]));
+            h[a] = fmaxf(fmaxf(red[0][3 + a], red[1][3 + a]), fmaxf(red[2][3 + a], red[3][3 + a]));
+        }
+        tlo[tile_base[c] + t] = make_float4(l[0], l[1], l[2], 0.f);
+        thi[tile_base[c] + t] = make_float4(h[0], h[1], h[2], 0.f);
+    }
 }
 
 // eigenvector of the smallest eigenvalue of a symmetric 3x3 (cyclic Jacobi, double)
@@ -169,19 +378,26 @@ __device__ void smallest_eigvec(const double* c, double* n_out)
     n_out[0] = v[s]; n_out[1] = v[3 + s]; n_out[2] = v[6 + s];
 }
 
-// G2: brute-force kNN (KMAX slots, the first k are used) + covariance + PLANE regularisation.
+// G2: exact kNN (KMAX slots, the first k are used) + covariance + PLANE regularisation, on the
+// Morton-ordered cloud with tile culling (bound = the lane's current KMAX-th distance).
 // grid = (blocks, clouds); cloud c spans pts[offs[c] .. offs[c+1]).
-// cov out: 6 doubles per point (xx, xy, xz, yy, yz, zz).  knn_out optional [n][k].
+// cov out (sorted space): 6 doubles per point (xx, xy, xz, yy, yz, zz).
+// knn_out optional, ORIGINAL indexing: knn_out[(offs[c] + orig_i) * k + s] = original neighbour index.
 template <int KMAX>
 __global__ __launch_bounds__(kNNThreads) void k_knn_cov(const float4* __restrict__ pts_all,
-                                                        const int64_t* __restrict__ offs, int k,
-                                                        double* __restrict__ cov_all, int* __restrict__ knn_out)
+                                                        const int64_t* __restrict__ offs, const int* __restrict__ tile_base,
+                                                        const float4* __restrict__ tlo, const float4* __restrict__ thi,
+                                                        int k, double* __restrict__ cov_all, int* __restrict__ knn_out)
 {
-    __shared__ float4 tile[kTile];
+    __shared__ ScanShared sh;
     const int c = blockIdx.y;
     const int64_t o = offs[c];
     const int n = (int)(offs[c + 1] - o);
     const float4* pts = pts_all + o;
+    TileBoxes tb;
+    tb.lo = tlo + tile_base[c];
+    tb.hi = thi + tile_base[c];
+    tb.ntiles = (n + kTile - 1) / kTile;
     for (int base = blockIdx.x * kNNThreads; base < n; base += gridDim.x * kNNThreads) {
         const int i = base + threadIdx.x;
         const bool live = i < n;
@@ -190,13 +406,20 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_cov(const float4* __restrict
         int ik[KMAX];
 #pragma unroll
         for (int s = 0; s < KMAX; ++s) { dk[s] = INFINITY; ik[s] = -1; }
-        for (int t0 = 0; t0 < n; t0 += kTile) {
+        float lo[3] = {live ? q.x : INFINITY, live ? q.y : INFINITY, live ? q.z : INFINITY};
+        float hi[3] = {live ? q.x : -INFINITY, live ? q.y : -INFINITY, live ? q.z : -INFINITY};
+        __syncthreads();  // previous round done with sh
+        order_tiles(sh, tb, INFINITY, lo, hi);
+        for (int kk = 0; kk < tb.ntiles; ++kk) {
+            const int t = kk < kMaxOrder ? (int)sh.order[kk] : kk;
+            const bool need = live && box_point_d2(tb.lo[t], tb.hi[t], q.x, q.y, q.z) * 0.9999f <= dk[KMAX - 1];
+            if (!__syncthreads_or(need)) continue;
+            const int t0 = t * kTile;
             const int cnt = min(kTile, n - t0);
-            __syncthreads();
-            for (int u = threadIdx.x; u < cnt; u += kNNThreads) tile[u] = pts[t0 + u];
+            for (int u = threadIdx.x; u < cnt; u += kNNThreads) sh.tile[u] = pts[t0 + u];
             __syncthreads();
             for (int u = 0; u < cnt; ++u) {
-                const float d = dist2(q.x, q.y, q.z, tile[u]);
+                const float d = dist2(q.x, q.y, q.z, sh.tile[u]);
                 if (d < dk[KMAX - 1]) {  // sorted insertion, static register indices
                     const int j = t0 + u;
 #pragma unroll
@@ -242,9 +465,10 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_cov(const float4* __restrict
         out[4] = -0.999 * nrm[1] * nrm[2];
         out[5] = 1.0 - 0.999 * nrm[2] * nrm[2];
         if (knn_out) {
+            const int oi = __float_as_int(q.w);
 #pragma unroll
             for (int s = 0; s < KMAX; ++s)
-                if (s < k) knn_out[(size_t)(o + i) * k + s] = ik[s];
+                if (s < k) knn_out[(size_t)(o + oi) * k + s] = ik[s] >= 0 ? __float_as_int(pts[ik[s]].w) : -1;
         }
     }
 }
@@ -262,16 +486,16 @@ __device__ __forceinline__ bool inv3_sym(const double* a, double* r)
     return true;
 }
 
-// G3 + G4 at the candidate pose of every active pair.  grid = (blocks, pairs).
-// partial[pair][block][28].  corr_out optional (per source point NN index or -1).
-__global__ __launch_bounds__(kNNThreads) void k_nn_linearize(
-    const float4* __restrict__ src_all, const int64_t* __restrict__ src_offs, const double* __restrict__ src_cov,
-    const float4* __restrict__ tgt_all, const int64_t* __restrict__ tgt_offs, const double* __restrict__ tgt_cov,
-    const LmState* __restrict__ st, GicpParams prm, double* __restrict__ partial, int max_blocks,
-    int* __restrict__ corr_out)
+// G3a: exact 1-NN of every (float-)transformed source point (tile-culled brute force).
+// grid = (blocks, pairs).  Kept free of the fp64 algebra so that it runs at full occupancy.
+// corr[so + i] = target index (sorted space), or -1 when d^2 >= max_corr^2.
+__global__ __launch_bounds__(kNNThreads) void k_nn_scan(
+    const float4* __restrict__ src_all, const int64_t* __restrict__ src_offs,
+    const float4* __restrict__ tgt_all, const int64_t* __restrict__ tgt_offs,
+    const int* __restrict__ tgt_tile_base, const float4* __restrict__ tlo, const float4* __restrict__ thi,
+    const LmState* __restrict__ st, GicpParams prm, int* __restrict__ corr)
 {
-    __shared__ float4 tile[kTile];
-    __shared__ double red[kNNThreads / 64][kTerms];
+    __shared__ ScanShared sh;
     const int pair = blockIdx.y;
     const LmState& S = st[pair];
     if (!S.active) return;
@@ -279,45 +503,73 @@ __global__ __launch_bounds__(kNNThreads) void k_nn_linearize(
     const int n = (int)(src_offs[pair + 1] - so), m = (int)(tgt_offs[pair + 1] - to);
     const float4* src = src_all + so;
     const float4* tgt = tgt_all + to;
-    const int per_block = kNNThreads * kPts;
-    double* pout = partial + ((size_t)pair * max_blocks + blockIdx.x) * kTerms;
-    double T[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) T[i] = S.xi[i];
+    TileBoxes tb;
+    tb.lo = tlo + tgt_tile_base[pair];
+    tb.hi = thi + tgt_tile_base[pair];
+    tb.ntiles = (m + kTile - 1) / kTile;
+    const float maxc2 = prm.max_corr2 < 3.0e38 ? (float)prm.max_corr2 * 1.0001f : INFINITY;
     float Tf[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) Tf[i] = (float)T[i];
-
-    double acc[kTerms];
-#pragma unroll
-    for (int i = 0; i < kTerms; ++i) acc[i] = 0.0;
-
+    for (int i = 0; i < 12; ++i) Tf[i] = (float)S.xi[i];
+    const int per_block = kNNThreads * kPts;
     for (int base = blockIdx.x * per_block; base < n; base += gridDim.x * per_block) {
         float qx[kPts], qy[kPts], qz[kPts];
         int si[kPts];
+        bool live[kPts];
 #pragma unroll
         for (int p = 0; p < kPts; ++p) {
             si[p] = base + p * kNNThreads + threadIdx.x;
-            const float4 a = src[si[p] < n ? si[p] : 0];
+            live[p] = si[p] < n;
+            const float4 a = src[live[p] ? si[p] : 0];
             qx[p] = Tf[0] * a.x + Tf[1] * a.y + Tf[2] * a.z + Tf[3];
             qy[p] = Tf[4] * a.x + Tf[5] * a.y + Tf[6] * a.z + Tf[7];
             qz[p] = Tf[8] * a.x + Tf[9] * a.y + Tf[10] * a.z + Tf[11];
         }
         float best[kPts];
         int bidx[kPts];
-        nn_scan<kPts>(tgt, m, qx, qy, qz, tile, best, bidx);
+        __syncthreads();
+        nn_scan<kPts>(tgt, m, tb, maxc2, qx, qy, qz, live, sh, best, bidx);
 #pragma unroll
+        for (int p = 0; p < kPts; ++p)
+            if (live[p]) corr[so + si[p]] = (bidx[p] >= 0 && (double)best[p] < prm.max_corr2) ? bidx[p] : -1;
+    }
+}
+
+// G3b + G4: Mahalanobis matrices, residuals and the 28 fp64 sums for the correspondences found by
+// k_nn_scan.  grid = (blocks, pairs), one source point per lane; partial[pair][block][28].
+__global__ __launch_bounds__(kNNThreads) void k_linearize(
+    const float4* __restrict__ src_all, const int64_t* __restrict__ src_offs, const double* __restrict__ src_cov,
+    const float4* __restrict__ tgt_all, const int64_t* __restrict__ tgt_offs, const double* __restrict__ tgt_cov,
+    const LmState* __restrict__ st, const int* __restrict__ corr, double* __restrict__ partial, int max_blocks)
+{
+    __shared__ double red[kNNThreads / 64][kTerms];
+    const int pair = blockIdx.y;
+    const LmState& S = st[pair];
+    if (!S.active) return;
+    const int64_t so = src_offs[pair], to = tgt_offs[pair];
+    const int n = (int)(src_offs[pair + 1] - so);
+    const float4* src = src_all + so;
+    const float4* tgt = tgt_all + to;
+    double* pout = partial + ((size_t)pair * max_blocks + blockIdx.x) * kTerms;
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = S.xi[i];
+    double acc[kTerms];
+#pragma unroll
+    for (int i = 0; i < kTerms; ++i) acc[i] = 0.0;
+    const int per_block = kNNThreads * kPts;  // same point -> block mapping as the scan (fixed summation order)
+    for (int base = blockIdx.x * per_block; base < n; base += gridDim.x * per_block) {
+#pragma unroll 1
         for (int p = 0; p < kPts; ++p) {
-            if (si[p] >= n) continue;
-            const int j = (bidx[p] >= 0 && (double)best[p] < prm.max_corr2) ? bidx[p] : -1;
-            if (corr_out) corr_out[so + si[p]] = j;
+            const int i = base + p * kNNThreads + threadIdx.x;
+            if (i >= n) continue;
+            const int j = corr[so + i];
             if (j < 0) continue;
-            const float4 a = src[si[p]];
+            const float4 a = src[i];
             const float4 bb = tgt[j];
-            const double* ca = src_cov + 6 * (size_t)(so + si[p]);
+            const double* ca = src_cov + 6 * (size_t)(so + i);
             const double* cb = tgt_cov + 6 * (size_t)(to + j);
             const double CA[9] = {ca[0], ca[1], ca[2], ca[1], ca[3], ca[4], ca[2], ca[4], ca[5]};
-            // RCR = C_B + R C_A R^T
             double RC[9], RCR[9], M[9];
 #pragma unroll
             for (int r = 0; r < 3; ++r)
@@ -546,16 +798,23 @@ __global__ __launch_bounds__(kNNThreads) void k_fitness(const float4* __restrict
                                                         const int64_t* __restrict__ src_offs,
                                                         const float4* __restrict__ tgt_all,
                                                         const int64_t* __restrict__ tgt_offs,
+                                                        const int* __restrict__ tgt_tile_base,
+                                                        const float4* __restrict__ tlo, const float4* __restrict__ thi,
                                                         const double* __restrict__ poses /* [pairs][16] */,
                                                         double max_range, double* __restrict__ partial, int max_blocks)
 {
-    __shared__ float4 tile[kTile];
+    __shared__ ScanShared sh;
     __shared__ double red[kNNThreads / 64][2];
     const int pair = blockIdx.y;
     const int64_t so = src_offs[pair], to = tgt_offs[pair];
     const int n = (int)(src_offs[pair + 1] - so), m = (int)(tgt_offs[pair + 1] - to);
     const float4* src = src_all + so;
     const float4* tgt = tgt_all + to;
+    TileBoxes tb;
+    tb.lo = tlo + tgt_tile_base[pair];
+    tb.hi = thi + tgt_tile_base[pair];
+    tb.ntiles = (m + kTile - 1) / kTile;
+    const float maxc2 = max_range < 3.0e38 ? (float)max_range * 1.0001f : INFINITY;
     float Tf[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) Tf[i] = (float)poses[(size_t)pair * 16 + i];
@@ -564,20 +823,23 @@ __global__ __launch_bounds__(kNNThreads) void k_fitness(const float4* __restrict
     for (int base = blockIdx.x * per_block; base < n; base += gridDim.x * per_block) {
         float qx[kPts], qy[kPts], qz[kPts];
         int si[kPts];
+        bool live[kPts];
 #pragma unroll
         for (int p = 0; p < kPts; ++p) {
             si[p] = base + p * kNNThreads + threadIdx.x;
-            const float4 a = src[si[p] < n ? si[p] : 0];
+            live[p] = si[p] < n;
+            const float4 a = src[live[p] ? si[p] : 0];
             qx[p] = Tf[0] * a.x + Tf[1] * a.y + Tf[2] * a.z + Tf[3];
             qy[p] = Tf[4] * a.x + Tf[5] * a.y + Tf[6] * a.z + Tf[7];
             qz[p] = Tf[8] * a.x + Tf[9] * a.y + Tf[10] * a.z + Tf[11];
         }
         float best[kPts];
         int bidx[kPts];
-        nn_scan<kPts>(tgt, m, qx, qy, qz, tile, best, bidx);
+        __syncthreads();
+        nn_scan<kPts>(tgt, m, tb, maxc2, qx, qy, qz, live, sh, best, bidx);
 #pragma unroll
         for (int p = 0; p < kPts; ++p)
-            if (si[p] < n && bidx[p] >= 0 && (double)best[p] <= max_range) { s += (double)best[p]; c += 1.0; }
+            if (live[p] && bidx[p] >= 0 && (double)best[p] <= max_range) { s += (double)best[p]; c += 1.0; }
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     s = wave_sum_d(s); c = wave_sum_d(c);
@@ -587,6 +849,20 @@ __global__ __launch_bounds__(kNNThreads) void k_fitness(const float4* __restrict
         double v = 0;
         for (int w = 0; w < kNNThreads / 64; ++w) v += red[w][threadIdx.x];
         partial[((size_t)pair * max_blocks + blockIdx.x) * 2 + threadIdx.x] = v;
+    }
+}
+
+// corr (sorted space) -> caller's indexing: out[so + orig_src] = orig_tgt (or -1)
+__global__ void k_corr_to_original(const float4* __restrict__ src_all, const int64_t* __restrict__ src_offs,
+                                   const float4* __restrict__ tgt_all, const int64_t* __restrict__ tgt_offs,
+                                   const int* __restrict__ corr, int* __restrict__ out)
+{
+    const int pair = blockIdx.y;
+    const int64_t so = src_offs[pair], to = tgt_offs[pair];
+    const int n = (int)(src_offs[pair + 1] - so);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int j = corr[so + i];
+        out[so + __float_as_int(src_all[so + i].w)] = j >= 0 ? __float_as_int(tgt_all[to + j].w) : -1;
     }
 }
 
@@ -600,12 +876,17 @@ struct mrs_gicp_batch {
     std::vector<int64_t> offs[2];   // host copies: [0] source, [1] target
     int64_t* d_offs[2] = {nullptr, nullptr};
     float4* d_pts[2] = {nullptr, nullptr};
-    double* d_cov[2] = {nullptr, nullptr};
+    double* d_cov[2] = {nullptr, nullptr};   // sorted space
+    int* d_tile_base[2] = {nullptr, nullptr};  // [n_pairs] first tile of each cloud
+    float4* d_tlo[2] = {nullptr, nullptr};     // tile bounding boxes
+    float4* d_thi[2] = {nullptr, nullptr};
+    int max_tiles[2] = {0, 0};                 // tiles of the largest cloud
     bool cov_valid[2] = {false, false};
     LmState* d_state = nullptr;
     double* d_partial = nullptr;
     int* d_nblocks = nullptr;
     int* d_nactive = nullptr;
+    int* d_corr = nullptr;          // [total source points] correspondences of the current evaluation
     int max_blocks = 0;
     double last_nn_passes = 0;
 };
@@ -617,7 +898,11 @@ void free_cloud(mrs_gicp_batch* h, int w)
     if (h->d_offs[w]) (void)hipFree(h->d_offs[w]);
     if (h->d_pts[w]) (void)hipFree(h->d_pts[w]);
     if (h->d_cov[w]) (void)hipFree(h->d_cov[w]);
+    if (h->d_tile_base[w]) (void)hipFree(h->d_tile_base[w]);
+    if (h->d_tlo[w]) (void)hipFree(h->d_tlo[w]);
+    if (h->d_thi[w]) (void)hipFree(h->d_thi[w]);
     h->d_offs[w] = nullptr; h->d_pts[w] = nullptr; h->d_cov[w] = nullptr;
+    h->d_tile_base[w] = nullptr; h->d_tlo[w] = nullptr; h->d_thi[w] = nullptr;
     h->cov_valid[w] = false;
 }
 
@@ -665,6 +950,7 @@ int mrs_gicp_batch_destroy(mrs_gicp_batch* h)
     if (h->d_partial) (void)hipFree(h->d_partial);
     if (h->d_nblocks) (void)hipFree(h->d_nblocks);
     if (h->d_nactive) (void)hipFree(h->d_nactive);
+    if (h->d_corr) (void)hipFree(h->d_corr);
     delete h;
     return MRS_OK;
 }
@@ -703,15 +989,68 @@ int mrs_gicp_batch_set_clouds(mrs_gicp_batch* h, int32_t which, const float* d_p
     hipStream_t s = (hipStream_t)stream;
     free_cloud(h, which);
     const int64_t total = h_offsets[h->n_pairs];
+    MRS_REQUIRE(total < (1ll << 31), "more than 2^31 points in one batch");
+    MRS_REQUIRE(h->n_pairs < (1 << 21), "too many pairs for the 64-bit sort key");
     h->offs[which].assign(h_offsets, h_offsets + h->n_pairs + 1);
+    std::vector<int> tile_base(h->n_pairs);
+    int tiles = 0, longest_tiles = 0;
+    int64_t longest = 0;
+    for (int i = 0; i < h->n_pairs; ++i) {
+        const int64_t n = h_offsets[i + 1] - h_offsets[i];
+        const int nt = (int)((n + kTile - 1) / kTile);
+        tile_base[i] = tiles;
+        tiles += nt;
+        longest_tiles = std::max(longest_tiles, nt);
+        longest = std::max(longest, n);
+    }
+    h->max_tiles[which] = longest_tiles;
     MRS_HIP_TRY(hipMalloc(&h->d_offs[which], (h->n_pairs + 1) * sizeof(int64_t)));
     MRS_HIP_TRY(hipMalloc(&h->d_pts[which], (size_t)total * sizeof(float4)));
     MRS_HIP_TRY(hipMalloc(&h->d_cov[which], (size_t)total * 6 * sizeof(double)));
+    MRS_HIP_TRY(hipMalloc(&h->d_tile_base[which], h->n_pairs * sizeof(int)));
+    MRS_HIP_TRY(hipMalloc(&h->d_tlo[which], (size_t)tiles * sizeof(float4)));
+    MRS_HIP_TRY(hipMalloc(&h->d_thi[which], (size_t)tiles * sizeof(float4)));
+    if (which == 0) {
+        if (h->d_corr) (void)hipFree(h->d_corr);
+        h->d_corr = nullptr;
+        MRS_HIP_TRY(hipMalloc(&h->d_corr, (size_t)total * sizeof(int)));
+    }
     MRS_HIP_TRY(hipMemcpyAsync(h->d_offs[which], h_offsets, (h->n_pairs + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
-    int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
-    hipLaunchKernelGGL(k_pack_points, dim3(blocks), dim3(256), 0, s, d_points, stride_floats, (size_t)total, h->d_pts[which]);
+    MRS_HIP_TRY(hipMemcpyAsync(h->d_tile_base[which], tile_base.data(), h->n_pairs * sizeof(int), hipMemcpyHostToDevice, s));
+
+    // Morton order: per-cloud bounding box -> 64-bit keys (cloud id | Morton code) -> stable radix sort
+    mrs::Scratch bbox, keys_in, keys_out, vals_in, vals_out, tmp;
+    int st = bbox.alloc((size_t)h->n_pairs * 6 * sizeof(int), s);
+    if (st != MRS_OK) return st;
+    if ((st = keys_in.alloc((size_t)total * 8, s)) != MRS_OK) return st;
+    if ((st = keys_out.alloc((size_t)total * 8, s)) != MRS_OK) return st;
+    if ((st = vals_in.alloc((size_t)total * 4, s)) != MRS_OK) return st;
+    if ((st = vals_out.alloc((size_t)total * 4, s)) != MRS_OK) return st;
+    {
+        std::vector<int> init((size_t)h->n_pairs * 6);
+        for (int i = 0; i < h->n_pairs; ++i)
+            for (int a = 0; a < 3; ++a) { init[6 * i + a] = INT32_MAX; init[6 * i + 3 + a] = INT32_MIN; }
+        MRS_HIP_TRY(hipMemcpyAsync(bbox.p, init.data(), init.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        MRS_HIP_TRY(hipStreamSynchronize(s));  // `init`, `tile_base`, h_offsets are temporaries
+    }
+    const dim3 pg((unsigned)std::min<int64_t>((longest + 255) / 256, 1024), h->n_pairs);
+    hipLaunchKernelGGL(k_cloud_bbox, pg, dim3(256), 0, s, d_points, stride_floats, h->d_offs[which], bbox.as<int>());
+    hipLaunchKernelGGL(k_morton_keys, pg, dim3(256), 0, s, d_points, stride_floats, h->d_offs[which], bbox.as<int>(),
+                       keys_in.as<unsigned long long>(), vals_in.as<int>());
+    size_t tmp_bytes = 0;
+    MRS_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in.as<unsigned long long>(),
+                                                   keys_out.as<unsigned long long>(), vals_in.as<int>(), vals_out.as<int>(),
+                                                   (int)total, 0, 64, s));
+    if ((st = tmp.alloc(tmp_bytes, s)) != MRS_OK) return st;
+    MRS_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, keys_in.as<unsigned long long>(),
+                                                   keys_out.as<unsigned long long>(), vals_in.as<int>(), vals_out.as<int>(),
+                                                   (int)total, 0, 64, s));
+    hipLaunchKernelGGL(k_gather_sorted, pg, dim3(256), 0, s, d_points, stride_floats, h->d_offs[which], vals_out.as<int>(),
+                       h->d_pts[which]);
+    hipLaunchKernelGGL(k_tile_boxes, dim3(longest_tiles, h->n_pairs), dim3(256), 0, s, h->d_pts[which], h->d_offs[which],
+                       h->d_tile_base[which], h->d_tlo[which], h->d_thi[which]);
     MRS_HIP_TRY(hipGetLastError());
-    MRS_HIP_TRY(hipStreamSynchronize(s));  // h_offsets may be a temporary
+    MRS_HIP_TRY(hipStreamSynchronize(s));
     return MRS_OK;
 }
 
@@ -727,11 +1066,14 @@ int mrs_gicp_batch_compute_covariances(mrs_gicp_batch* h, int32_t which, int32_t
     const dim3 grid((unsigned)((longest + kNNThreads - 1) / kNNThreads), h->n_pairs);
     const int k = h->prm.k;
     if (k <= 16)
-        hipLaunchKernelGGL(k_knn_cov<16>, grid, dim3(kNNThreads), 0, s, h->d_pts[which], h->d_offs[which], k, h->d_cov[which], d_knn_out);
+        hipLaunchKernelGGL(k_knn_cov<16>, grid, dim3(kNNThreads), 0, s, h->d_pts[which], h->d_offs[which], h->d_tile_base[which],
+                           h->d_tlo[which], h->d_thi[which], k, h->d_cov[which], d_knn_out);
     else if (k <= 20)
-        hipLaunchKernelGGL(k_knn_cov<20>, grid, dim3(kNNThreads), 0, s, h->d_pts[which], h->d_offs[which], k, h->d_cov[which], d_knn_out);
+        hipLaunchKernelGGL(k_knn_cov<20>, grid, dim3(kNNThreads), 0, s, h->d_pts[which], h->d_offs[which], h->d_tile_base[which],
+                           h->d_tlo[which], h->d_thi[which], k, h->d_cov[which], d_knn_out);
     else
-        hipLaunchKernelGGL(k_knn_cov<32>, grid, dim3(kNNThreads), 0, s, h->d_pts[which], h->d_offs[which], k, h->d_cov[which], d_knn_out);
+        hipLaunchKernelGGL(k_knn_cov<32>, grid, dim3(kNNThreads), 0, s, h->d_pts[which], h->d_offs[which], h->d_tile_base[which],
+                           h->d_tlo[which], h->d_thi[which], k, h->d_cov[which], d_knn_out);
     MRS_HIP_TRY(hipGetLastError());
     h->cov_valid[which] = true;
     return MRS_OK;
@@ -744,7 +1086,19 @@ int mrs_gicp_batch_get_covariances(mrs_gicp_batch* h, int32_t which, double* h_c
     MRS_REQUIRE(h->cov_valid[which], "covariances not computed");
     MRS_HIP_TRY(hipSetDevice(h->ctx->device));
     MRS_HIP_TRY(hipDeviceSynchronize());
-    MRS_HIP_TRY(hipMemcpy(h_cov6, h->d_cov[which], (size_t)h->offs[which][h->n_pairs] * 6 * sizeof(double), hipMemcpyDeviceToHost));
+    const size_t total = (size_t)h->offs[which][h->n_pairs];
+    std::vector<double> sorted(total * 6);
+    std::vector<float4> pts(total);
+    MRS_HIP_TRY(hipMemcpy(sorted.data(), h->d_cov[which], total * 6 * sizeof(double), hipMemcpyDeviceToHost));
+    MRS_HIP_TRY(hipMemcpy(pts.data(), h->d_pts[which], total * sizeof(float4), hipMemcpyDeviceToHost));
+    for (int c = 0; c < h->n_pairs; ++c) {  // the library stores clouds in Morton order; .w = original index
+        const int64_t o = h->offs[which][c];
+        for (int64_t i = o; i < h->offs[which][c + 1]; ++i) {
+            int orig;
+            memcpy(&orig, &pts[i].w, sizeof(int));
+            memcpy(h_cov6 + (size_t)(o + orig) * 6, &sorted[(size_t)i * 6], 6 * sizeof(double));
+        }
+    }
     return MRS_OK;
 }
 
@@ -799,9 +1153,10 @@ int mrs_gicp_batch_align(mrs_gicp_batch* h, const double* h_guess, double* h_fin
     int active = h->n_pairs;
     while (active > 0 && ticks < max_ticks) {
         MRS_HIP_TRY(hipMemsetAsync(h->d_nactive, 0, sizeof(int), s));
-        hipLaunchKernelGGL(k_nn_linearize, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_cov[0],
-                           h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->prm, h->d_partial, h->max_blocks,
-                           (int*)nullptr);
+        hipLaunchKernelGGL(k_nn_scan, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_pts[1], h->d_offs[1],
+                           h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_state, h->prm, h->d_corr);
+        hipLaunchKernelGGL(k_linearize, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_cov[0],
+                           h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->d_corr, h->d_partial, h->max_blocks);
         hipLaunchKernelGGL(k_lm_update, dim3(h->n_pairs), dim3(64), 0, s, h->d_state, h->d_partial, h->d_nblocks,
                            h->max_blocks, h->prm, h->d_nactive);
         MRS_HIP_TRY(hipGetLastError());
@@ -840,9 +1195,14 @@ int mrs_gicp_batch_linearize(mrs_gicp_batch* h, const double* h_poses, double* h
         init[p].active = 1;
     }
     MRS_HIP_TRY(hipMemcpyAsync(h->d_state, init.data(), init.size() * sizeof(LmState), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_nn_linearize, dim3(h->max_blocks, h->n_pairs), dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0],
-                       h->d_cov[0], h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->prm, h->d_partial,
-                       h->max_blocks, d_corr);
+    hipLaunchKernelGGL(k_nn_scan, dim3(h->max_blocks, h->n_pairs), dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0],
+                       h->d_pts[1], h->d_offs[1], h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_state, h->prm, h->d_corr);
+    hipLaunchKernelGGL(k_linearize, dim3(h->max_blocks, h->n_pairs), dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0],
+                       h->d_cov[0], h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->d_corr, h->d_partial,
+                       h->max_blocks);
+    if (d_corr)
+        hipLaunchKernelGGL(k_corr_to_original, dim3(64, h->n_pairs), dim3(256), 0, s, h->d_pts[0], h->d_offs[0], h->d_pts[1],
+                           h->d_offs[1], h->d_corr, d_corr);
     MRS_HIP_TRY(hipGetLastError());
     std::vector<double> part((size_t)h->n_pairs * h->max_blocks * kTerms);
     MRS_HIP_TRY(hipMemcpyAsync(part.data(), h->d_partial, part.size() * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -878,7 +1238,8 @@ int mrs_gicp_batch_fitness(mrs_gicp_batch* h, const double* h_poses, double max_
     MRS_HIP_TRY(hipMemcpyAsync(poses.p, h_poses, (size_t)h->n_pairs * 16 * sizeof(double), hipMemcpyHostToDevice, s));
     MRS_HIP_TRY(hipMemsetAsync(part.p, 0, (size_t)h->n_pairs * h->max_blocks * 2 * sizeof(double), s));
     hipLaunchKernelGGL(k_fitness, dim3(h->max_blocks, h->n_pairs), dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0],
-                       h->d_pts[1], h->d_offs[1], poses.as<double>(), max_range, part.as<double>(), h->max_blocks);
+                       h->d_pts[1], h->d_offs[1], h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], poses.as<double>(), max_range,
+                       part.as<double>(), h->max_blocks);
     MRS_HIP_TRY(hipGetLastError());
     std::vector<double> hp((size_t)h->n_pairs * h->max_blocks * 2);
     MRS_HIP_TRY(hipMemcpyAsync(hp.data(), part.p, hp.size() * sizeof(double), hipMemcpyDeviceToHost, s));
