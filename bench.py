@@ -159,7 +159,10 @@ def main():
     cand = cand.roll(1, 0).contiguous().view(B, 1, 120, 120)
     out_dist = torch.empty(B, dtype=torch.float32, device=device)
     out_ang = torch.empty(B, dtype=torch.int32, device=device)
-    gathered = torch.empty((world * B, 120, 120), dtype=torch.float32, device=device) if dist_on else None
+    # N > 1: the all-gather of step i overlaps the kernels of step i+1 (async RCCL op on its own stream,
+    # double-buffered destination; the gathered descriptors only feed the database, not the next step)
+    gathered = [torch.empty((world * B, 120, 120), dtype=torch.float32, device=device) for _ in range(2)] if dist_on else None
+    pending = {"work": None, "keep": None, "n": 0}
 
     ev = {k: [] for k in ("bev", "radon", "corr")}
 
@@ -176,12 +179,19 @@ def main():
         ring.corr_pairs(norm.view(B, 1, 120, 120), cand, out=(out_dist, out_ang))
         e3 = mark() if record else None
         if dist_on:
-            dist.all_gather_into_tensor(gathered, norm)
+            if pending["work"] is not None:
+                pending["work"].wait()
+            pending["keep"] = norm                      # keep the source alive until the op completes
+            pending["work"] = dist.all_gather_into_tensor(gathered[pending["n"] & 1], norm, async_op=True)
+            pending["n"] += 1
         if record:
             ev["bev"].append((e0, e1)); ev["radon"].append((e1, e2)); ev["corr"].append((e2, e3))
 
     def fence():
         if dist_on:
+            if pending["work"] is not None:
+                pending["work"].wait()
+                pending["work"] = None
             dist.barrier()
         torch.cuda.synchronize()
 
