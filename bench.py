@@ -141,13 +141,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1
+    dist_on = world > 1 or os.environ.get("MRS_BENCH_FORCE_DIST") == "1"   # the env var exercises the RCCL path on 1 GPU
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device(device))
 
     B = args.batch
@@ -278,9 +281,15 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scans)
-        print(json.dumps(line), flush=True)
+    else:
+        line = None
     if dist_on:
+        dist.barrier()
         dist.destroy_process_group()
+    if line is not None:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        print(json.dumps(line), flush=True)     # the ONE JSON line, last thing on stdout
 
 
 if __name__ == "__main__":

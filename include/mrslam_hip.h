@@ -300,6 +300,31 @@ int mrs_bev_translation(mrs_ctx* ctx, const float* d_a, const float* d_b, int32_
 int mrs_rotate_nearest(mrs_ctx* ctx, const float* d_img, int32_t n_images, int32_t images_per_angle, int32_t height,
                        int32_t width, const float* d_angle_deg, float* d_out, mrs_stream stream);
 
+/* ------------------------------------------------------------------------------------
+ * RING++ point-feature front-end
+ * ---------------------------------------------------------------------------------- */
+
+/* Replaces voxelfeat.GPUFeatureExtractor(point, size, 13, k, neighbors_indices, eigens).get_features()
+ * (generate_bev_pointfeat_cython/wrapper.pyx:43-59, src/kernel.cu:16-104): d_points float[n][3]
+ * row-major, d_knn int32[n][k], d_eigens float[n][5] (3-D then 2-D eigenvalues, descending),
+ * d_features float[n][13] = C,O,L,E,P,S,A,X,D,S2,L2,dZ,vZ.  k <= 32. */
+int mrs_pointfeat_from_neighbors(mrs_ctx* ctx, const float* d_points, int32_t n, int32_t k, const int32_t* d_knn,
+                                 const float* d_eigens, float* d_features, mrs_stream stream);
+int mrs_pointfeat_from_neighbors_host(mrs_ctx* ctx, const float* h_points, int32_t n, int32_t k, const int32_t* h_knn,
+                                      const float* h_eigens, float* h_features);
+
+/* The whole front-end of generate_RINGplusplus on the GPU (RING_ros/util.py:163-170 build_neighbors_NN
+ * [sklearn kd-tree kNN, k = 30], :123-160 covariation_eigenvalue [CPU eigvalsh], :218-228 features):
+ * exact kNN (self included), covariance / (k-1), eigenvalues, 13 features, for `batch` clouds.
+ * d_points: packed device points, xyz in the first 3 of every stride_floats floats; h_offsets HOST
+ * int64[batch+1].  Outputs (each optional) in the caller's point order: d_knn int32[N][k],
+ * d_eigens float[N][5], d_features float[N][13], d_feat_planes float[9*N]: per scan the channel-major
+ * planes x,y,z,C,O,E,L2,dZ,vZ, i.e. exactly the input of mrs_bev_feat_batch with featsize 9.
+ * Synchronises `stream`. */
+int mrs_pointfeat_batch(mrs_ctx* ctx, const float* d_points, int32_t stride_floats, const int64_t* h_offsets,
+                        int32_t batch, int32_t k, int32_t* d_knn, float* d_eigens, float* d_features,
+                        float* d_feat_planes, mrs_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,3 +15,26 @@ class GPUTransformer(HostTransformer):
     def _out_size(self):
         c = self._cfg
         return c.n0 * c.n1 * c.num_height * c.enough_large
+
+
+class GPUFeatureExtractor:
+    """GPUFeatureExtractor(point[3*size] row-major, size, featsize=13, k, neighbors_indices int32[size*k],
+    eigens float32[size*5]); get_features() -> float32[size*13]
+    (generate_bev_pointfeat_cython/wrapper.pyx:43-59)."""
+
+    def __init__(self, point, size, featsize, k, neighbors_indices, eigens):
+        import numpy as np
+        if int(featsize) != 13:
+            raise ValueError("featsize must be 13")
+        self._p = np.ascontiguousarray(point, dtype=np.float32)
+        self._k = np.ascontiguousarray(neighbors_indices, dtype=np.int32)
+        self._e = np.ascontiguousarray(eigens, dtype=np.float32)
+        self._n, self._kk = int(size), int(k)
+
+    def get_features(self):
+        import numpy as np
+        from .. import _lib
+        out = np.zeros(self._n * 13, dtype=np.float32)
+        _lib.check(_lib.load().mrs_pointfeat_from_neighbors_host(_lib.ctx(0), _lib.ptr(self._p), self._n, self._kk,
+                                                                 _lib.ptr(self._k), _lib.ptr(self._e), _lib.ptr(out)))
+        return out

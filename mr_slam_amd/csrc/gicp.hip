@@ -473,6 +473,202 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_cov(const float4* __restrict
     }
 }
 
+
+// ---- RING++ point-feature front-end -----------------------------------
+// calculate_features (generate_bev_pointfeat_cython/src/kernel.cu:16-104) for one point, given its
+// 5 eigenvalues (3-D descending, 2-D descending) and the z of its k neighbours.
+__device__ __forceinline__ void point_features(const float* e, const float* nz, int k, float* f)
+{
+    const float e0 = e[0], e1 = e[1], e2 = e[2];
+    const float sum = e0 + e1 + e2, prod = e0 * e1 * e2, sum2 = e[3] + e[4];
+    f[0] = e2 / sum;                                                  // C_
+    f[1] = (float)pow((double)(prod / (sum * sum * sum)), 1.0 / 3.0);  // O_
+    f[2] = (e0 - e1) / e0;                                            // L_
+    float ent = 0.0f;
+    ent += (e0 / sum) * logf(e0 / sum);
+    ent += (e1 / sum) * logf(e1 / sum);
+    ent += (e2 / sum) * logf(e2 / sum);
+    f[3] = -ent;                                                      // E_
+    f[4] = (e1 - e2) / e0;                                            // P_
+    f[5] = e2 / e0;                                                   // S_
+    f[6] = (e0 - e2) / e0;                                            // A_
+    f[7] = sum;                                                       // X_
+    f[8] = (float)((double)(3 * k) / (4.0 * M_PI * (double)prod));    // D_
+    f[9] = sum2;                                                      // S_2
+    f[10] = e[4] / e[3];                                              // L_2
+    float mean = 0.0f, mn = 10000.0f;
+    for (int i = 0; i < k; ++i) { mean += nz[i]; mn = fminf(mn, nz[i]); }
+    mean /= (float)k;
+    float dz = -100000.0f, vz = 0.0f;
+    for (int i = 0; i < k; ++i) {
+        dz = fmaxf(dz, nz[i] - mn);
+        const float d = fabsf(nz[i] - mean);
+        vz += d * d;
+    }
+    f[11] = dz;                                                       // dZ_
+    f[12] = vz / (float)k;                                            // vZ_
+}
+
+// drop-in kernel of voxelfeat.GPUFeatureExtractor: neighbours and eigenvalues supplied by the caller
+__global__ void k_features_from_neighbors(const float* __restrict__ pts /* [n][3] */, int n, int k,
+                                          const int* __restrict__ knn, const float* __restrict__ eig,
+                                          float* __restrict__ feat /* [n][13] */)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float nz[32];
+        for (int j = 0; j < k; ++j) nz[j] = pts[(size_t)knn[(size_t)i * k + j] * 3 + 2];
+        float f[13];
+        point_features(eig + (size_t)i * 5, nz, k, f);
+        for (int j = 0; j < 13; ++j) feat[(size_t)i * 13 + j] = f[j];
+    }
+}
+
+// eigenvalues (descending) of a symmetric 3x3 by cyclic Jacobi in double
+__device__ void sym3_eigvals(const double* c, double* w)
+{
+    double a[9];
+    for (int i = 0; i < 9; ++i) a[i] = c[i];
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        const double off = a[1] * a[1] + a[2] * a[2] + a[5] * a[5];
+        if (off < 1e-300) break;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) {
+                const double apq = a[3 * p + q];
+                if (apq == 0.0) continue;
+                const double theta = (a[3 * q + q] - a[3 * p + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk) {
+                    const double akp = a[3 * kk + p], akq = a[3 * kk + q];
+                    a[3 * kk + p] = cs * akp - sn * akq;
+                    a[3 * kk + q] = sn * akp + cs * akq;
+                }
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk) {
+                    const double apk = a[3 * p + kk], aqk = a[3 * q + kk];
+                    a[3 * p + kk] = cs * apk - sn * aqk;
+                    a[3 * q + kk] = sn * apk + cs * aqk;
+                }
+            }
+    }
+    double x = a[0], y = a[4], z = a[8], t;
+    if (x < y) { t = x; x = y; y = t; }
+    if (y < z) { t = y; y = z; z = t; }
+    if (x < y) { t = x; x = y; y = t; }
+    w[0] = x; w[1] = y; w[2] = z;
+}
+
+// N1 fused: exact kNN (k <= 32, the point itself included, like sklearn's kneighbors on the fitted
+// set: util.py:163-170) -> covariance P^T P / (k-1) (util.py:123-131) -> eigenvalues of the 3x3 and
+// of its xy 2x2 block, both descending (util.py:134-158) -> the 13 hand-crafted features.
+// Outputs are in the caller's ORIGINAL point order; feat_planes (optional) receives the channel-major
+// [9][n] planes x,y,z,C,O,E,L2,dZ,vZ that generate_RINGplusplus feeds to the feature BEV
+// (util.py:220-228: features [0,1,3,10,11,12]).
+template <int KMAX>
+__global__ __launch_bounds__(kNNThreads) void k_knn_features(const float4* __restrict__ pts_all,
+                                                             const int64_t* __restrict__ offs, const int* __restrict__ tile_base,
+                                                             const float4* __restrict__ tlo, const float4* __restrict__ thi,
+                                                             int k, int* __restrict__ knn_out, float* __restrict__ eig_out,
+                                                             float* __restrict__ feat_out, float* __restrict__ feat_planes)
+{
+    __shared__ ScanShared sh;
+    const int c = blockIdx.y;
+    const int64_t o = offs[c];
+    const int n = (int)(offs[c + 1] - o);
+    const float4* pts = pts_all + o;
+    TileBoxes tb;
+    tb.lo = tlo + tile_base[c];
+    tb.hi = thi + tile_base[c];
+    tb.ntiles = (n + kTile - 1) / kTile;
+    for (int base = blockIdx.x * kNNThreads; base < n; base += gridDim.x * kNNThreads) {
+        const int i = base + threadIdx.x;
+        const bool live = i < n;
+        const float4 q = pts[live ? i : 0];
+        float dk[KMAX];
+        int ik[KMAX];
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) { dk[s] = INFINITY; ik[s] = -1; }
+        float lo[3] = {live ? q.x : INFINITY, live ? q.y : INFINITY, live ? q.z : INFINITY};
+        float hi[3] = {live ? q.x : -INFINITY, live ? q.y : -INFINITY, live ? q.z : -INFINITY};
+        __syncthreads();
+        order_tiles(sh, tb, INFINITY, lo, hi);
+        for (int kk = 0; kk < tb.ntiles; ++kk) {
+            const int t = kk < kMaxOrder ? (int)sh.order[kk] : kk;
+            const bool need = live && box_point_d2(tb.lo[t], tb.hi[t], q.x, q.y, q.z) * 0.9999f <= dk[KMAX - 1];
+            if (!__syncthreads_or(need)) continue;
+            const int t0 = t * kTile;
+            const int cnt = min(kTile, n - t0);
+            for (int u = threadIdx.x; u < cnt; u += kNNThreads) sh.tile[u] = pts[t0 + u];
+            __syncthreads();
+            for (int u = 0; u < cnt; ++u) {
+                const float d = dist2(q.x, q.y, q.z, sh.tile[u]);
+                if (d < dk[KMAX - 1]) {
+                    const int j = t0 + u;
+#pragma unroll
+                    for (int s = KMAX - 1; s > 0; --s) {
+                        const bool up = dk[s - 1] > d;
+                        const bool here = !up && dk[s] > d;
+                        dk[s] = up ? dk[s - 1] : (here ? d : dk[s]);
+                        ik[s] = up ? ik[s - 1] : (here ? j : ik[s]);
+                    }
+                    if (dk[0] > d) { dk[0] = d; ik[0] = j; }
+                }
+            }
+        }
+        if (!live) continue;
+        const int oi = __float_as_int(q.w);
+        double mean[3] = {0, 0, 0};
+        float nz[KMAX];
+        int cnt = 0;
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) {
+            nz[s] = 0.0f;
+            if (s < k && ik[s] >= 0) {
+                const float4 p = pts[ik[s]];
+                mean[0] += (double)p.x; mean[1] += (double)p.y; mean[2] += (double)p.z;
+                nz[s] = p.z;
+                ++cnt;
+            }
+        }
+        mean[0] /= cnt; mean[1] /= cnt; mean[2] /= cnt;
+        double cv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s)
+            if (s < k && ik[s] >= 0) {
+                const float4 p = pts[ik[s]];
+                const double dx = (double)p.x - mean[0], dy = (double)p.y - mean[1], dz = (double)p.z - mean[2];
+                cv[0] += dx * dx; cv[1] += dx * dy; cv[2] += dx * dz;
+                cv[4] += dy * dy; cv[5] += dy * dz; cv[8] += dz * dz;
+            }
+        cv[3] = cv[1]; cv[6] = cv[2]; cv[7] = cv[5];
+        for (int a = 0; a < 9; ++a) cv[a] /= (double)(cnt - 1);
+        double w[3];
+        sym3_eigvals(cv, w);
+        const double hm = 0.5 * (cv[0] + cv[4]), hd = 0.5 * (cv[0] - cv[4]);
+        const double rad = sqrt(hd * hd + cv[1] * cv[1]);
+        float e[5] = {(float)w[0], (float)w[1], (float)w[2], (float)(hm + rad), (float)(hm - rad)};
+        float f[13];
+        point_features(e, nz, k, f);
+        const size_t gi = (size_t)(o + oi);
+        if (knn_out) {
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s)
+                if (s < k) knn_out[gi * k + s] = ik[s] >= 0 ? __float_as_int(pts[ik[s]].w) : -1;
+        }
+        if (eig_out) for (int j = 0; j < 5; ++j) eig_out[gi * 5 + j] = e[j];
+        if (feat_out) for (int j = 0; j < 13; ++j) feat_out[gi * 13 + j] = f[j];
+        if (feat_planes) {
+            float* pl = feat_planes + (size_t)9 * o;  // scan-local channel-major planes
+            pl[0 * (size_t)n + oi] = q.x; pl[1 * (size_t)n + oi] = q.y; pl[2 * (size_t)n + oi] = q.z;
+            pl[3 * (size_t)n + oi] = f[0]; pl[4 * (size_t)n + oi] = f[1]; pl[5 * (size_t)n + oi] = f[3];
+            pl[6 * (size_t)n + oi] = f[10]; pl[7 * (size_t)n + oi] = f[11]; pl[8 * (size_t)n + oi] = f[12];
+        }
+    }
+}
+
 __device__ __forceinline__ bool inv3_sym(const double* a, double* r)
 {
     // a: full 3x3 symmetric, r: full 3x3
@@ -1250,6 +1446,82 @@ int mrs_gicp_batch_fitness(mrs_gicp_batch* h, const double* h_poses, double max_
         h_scores[p] = cnt > 0 ? sum / cnt : DBL_MAX;  // pcl: std::numeric_limits<double>::max() when empty
     }
     return MRS_OK;
+}
+
+
+/* ---- RING++ point-feature front-end (row N1) ---- */
+int mrs_pointfeat_from_neighbors(mrs_ctx* ctx, const float* d_points, int32_t n, int32_t k, const int32_t* d_knn,
+                                 const float* d_eigens, float* d_features, mrs_stream stream)
+{
+    MRS_REQUIRE(ctx && d_points && d_knn && d_eigens && d_features, "null pointer");
+    MRS_REQUIRE(n >= 0, "n must be >= 0");
+    MRS_REQUIRE(k >= 1 && k <= 32, "k must be in [1, 32]");
+    MRS_HIP_TRY(hipSetDevice(ctx->device));
+    if (n == 0) return MRS_OK;
+    hipLaunchKernelGGL(k_features_from_neighbors, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_points, n, k,
+                       d_knn, d_eigens, d_features);
+    MRS_HIP_TRY(hipGetLastError());
+    return MRS_OK;
+}
+
+int mrs_pointfeat_from_neighbors_host(mrs_ctx* ctx, const float* h_points, int32_t n, int32_t k, const int32_t* h_knn,
+                                      const float* h_eigens, float* h_features)
+{
+    MRS_REQUIRE(ctx && h_points && h_knn && h_eigens && h_features, "null pointer");
+    MRS_REQUIRE(n > 0, "n must be positive");
+    MRS_HIP_TRY(hipSetDevice(ctx->device));
+    float *dp = nullptr, *de = nullptr, *df = nullptr;
+    int* dk = nullptr;
+    int st = MRS_OK;
+    if (hipMalloc(&dp, (size_t)n * 3 * 4) != hipSuccess || hipMalloc(&dk, (size_t)n * k * 4) != hipSuccess ||
+        hipMalloc(&de, (size_t)n * 5 * 4) != hipSuccess || hipMalloc(&df, (size_t)n * 13 * 4) != hipSuccess) {
+        mrs::set_error("hipMalloc failed in pointfeat host path");
+        st = MRS_ERR_HIP;
+    } else if (hipMemcpy(dp, h_points, (size_t)n * 3 * 4, hipMemcpyHostToDevice) != hipSuccess ||
+               hipMemcpy(dk, h_knn, (size_t)n * k * 4, hipMemcpyHostToDevice) != hipSuccess ||
+               hipMemcpy(de, h_eigens, (size_t)n * 5 * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        mrs::set_error("H2D copy failed");
+        st = MRS_ERR_HIP;
+    } else {
+        st = mrs_pointfeat_from_neighbors(ctx, dp, n, k, dk, de, df, nullptr);
+        if (st == MRS_OK && hipMemcpy(h_features, df, (size_t)n * 13 * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+            mrs::set_error("D2H copy failed");
+            st = MRS_ERR_HIP;
+        }
+    }
+    if (dp) (void)hipFree(dp);
+    if (dk) (void)hipFree(dk);
+    if (de) (void)hipFree(de);
+    if (df) (void)hipFree(df);
+    return st;
+}
+
+int mrs_pointfeat_batch(mrs_ctx* ctx, const float* d_points, int32_t stride_floats, const int64_t* h_offsets,
+                        int32_t batch, int32_t k, int32_t* d_knn, float* d_eigens, float* d_features,
+                        float* d_feat_planes, mrs_stream stream)
+{
+    MRS_REQUIRE(ctx && d_points && h_offsets, "null pointer");
+    MRS_REQUIRE(batch > 0, "batch must be positive");
+    MRS_REQUIRE(k >= 2 && k <= 32, "k must be in [2, 32]");
+    MRS_REQUIRE(d_knn || d_eigens || d_features || d_feat_planes, "no output requested");
+    mrs_gicp_batch* h = nullptr;   // reuse the Morton-ordered cloud container of the GICP front-end
+    int st = mrs_gicp_batch_create(ctx, batch, &h);
+    if (st != MRS_OK) return st;
+    st = mrs_gicp_batch_set_clouds(h, 0, d_points, stride_floats, h_offsets, stream);
+    if (st == MRS_OK) {
+        hipStream_t s = (hipStream_t)stream;
+        int64_t longest = 0;
+        for (int i = 0; i < batch; ++i) longest = std::max(longest, h_offsets[i + 1] - h_offsets[i]);
+        const dim3 grid((unsigned)((longest + kNNThreads - 1) / kNNThreads), batch);
+        hipLaunchKernelGGL(k_knn_features<32>, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_tile_base[0],
+                           h->d_tlo[0], h->d_thi[0], k, d_knn, d_eigens, d_features, d_feat_planes);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            mrs::set_error("k_knn_features launch failed");
+            st = MRS_ERR_HIP;
+        }
+    }
+    mrs_gicp_batch_destroy(h);
+    return st;
 }
 
 double mrs_gicp_batch_last_nn_passes(const mrs_gicp_batch* h) { return h ? h->last_nn_passes : 0.0; }

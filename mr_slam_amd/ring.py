@@ -236,3 +236,27 @@ def solve_translation_bev(a, b, want_corr=False, num_ring=NUM_RING, num_sector=N
     neg = -mx.cpu().numpy()
     out = (y[0], x[0], neg[0]) if single else (y, x, neg)
     return out + (corr,) if want_corr else out
+
+
+def ringpp_descriptors(points, offsets, k=30, num_ring=NUM_RING, num_sector=NUM_SECTOR):
+    """Batched generate_RINGplusplus (util.py:204-250), everything on the device:
+    kNN + eigen features (row N1) -> 9-channel feature BEV -> Radon of the 6 feature channels ->
+    |FFT along the detector axis|.  points: float32 device tensor [N, s>=3] of pre-processed clouds,
+    offsets: host int64 [B+1].  Returns (bev [B,6,R,S], ring [B,6,A,D], tiring [B,6,A,D])."""
+    from . import pointfeat
+    d = _dev(points)
+    planes = pointfeat.point_features(points, offsets, k, want=("planes",))["planes"]
+    offs_dev = torch.as_tensor(np.asarray(offsets, dtype=np.int64)).to(points.device)
+    fb = bev.feat_bev(planes, offs_dev, 9, MAX_LENGTH, MAX_HEIGHT, num_ring, num_sector, 1, layout=OUT_COMPACT)
+    B = fb.shape[0]
+    sino, _ = ring_plan(d, num_ring, num_sector).forward(fb.reshape(B * 6, num_ring, num_sector))
+    sino = sino.view(B, 6, num_ring, num_sector)
+    return fb, sino, forward_row_fft(sino)
+
+
+def generate_RINGplusplus(pc, device="cuda:0"):
+    """util.py:204-250 for one pre-processed cloud [n,3]: (pc_bev_tensor [6,R,S] device,
+    pc_RING [6,A,D] cpu, pc_TIRING [6,A,D] cpu)."""
+    pts = torch.from_numpy(np.ascontiguousarray(np.asarray(pc, dtype=np.float32)[:, 0:3])).to(device)
+    fb, sino, tiring = ringpp_descriptors(pts, np.array([0, pts.shape[0]], np.int64))
+    return fb[0], sino[0].cpu(), tiring[0].cpu()
