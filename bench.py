@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=512, help="scan pairs per rank per step")
-    ap.add_argument("--db", type=int, default=4096, help="database size for the sweep-rate leg")
+    ap.add_argument("--db", type=int, default=16384, help="database size for the sweep-rate leg (x 58 560 B)")
     ap.add_argument("--gicp-pairs", type=int, default=16, help="120k-pt pairs per rank in the GICP leg (0 = skip)")
     ap.add_argument("--gicp-iters", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -158,13 +158,14 @@ def main():
     plan = ring.ring_plan(local_rank)
     img = torch.empty((B, 1, 120, 120), dtype=torch.float32, device=device)
     # resident database of candidate descriptors (one candidate per new scan)
+    # database entries are Hermitian half spectra [61][120] complex64 (58 560 B) of the normalised sinograms
     _, _, cand = ring.ring_descriptors(xyz, offs)
-    cand = cand.roll(1, 0).contiguous().view(B, 1, 120, 120)
+    cand = ring.half_spectrum(cand).roll(1, 0).contiguous()
     out_dist = torch.empty(B, dtype=torch.float32, device=device)
     out_ang = torch.empty(B, dtype=torch.int32, device=device)
     # N > 1: the all-gather of step i overlaps the kernels of step i+1 (async RCCL op on its own stream,
     # double-buffered destination; the gathered descriptors only feed the database, not the next step)
-    gathered = [torch.empty((world * B, 120, 120), dtype=torch.float32, device=device) for _ in range(2)] if dist_on else None
+    gathered = [torch.empty((world * B, 61, 120, 2), dtype=torch.float32, device=device) for _ in range(2)] if dist_on else None
     pending = {"work": None, "keep": None, "n": 0}
 
     ev = {k: [] for k in ("bev", "radon", "corr")}
@@ -179,13 +180,15 @@ def main():
         e1 = mark() if record else None
         _, norm = plan.forward(img.view(B, 120, 120), raw=False, normalized=True)
         e2 = mark() if record else None
-        ring.corr_pairs(norm.view(B, 1, 120, 120), cand, out=(out_dist, out_ang))
+        spec = ring.half_spectrum(norm)
+        ring.corr_pairs_fft(spec, cand, out=(out_dist, out_ang))
         e3 = mark() if record else None
         if dist_on:
             if pending["work"] is not None:
                 pending["work"].wait()
-            pending["keep"] = norm                      # keep the source alive until the op completes
-            pending["work"] = dist.all_gather_into_tensor(gathered[pending["n"] & 1], norm, async_op=True)
+            src = torch.view_as_real(spec)
+            pending["keep"] = src                       # keep the source alive until the op completes
+            pending["work"] = dist.all_gather_into_tensor(gathered[pending["n"] & 1], src, async_op=True)
             pending["n"] += 1
         if record:
             ev["bev"].append((e0, e1)); ev["radon"].append((e1, e2)); ev["corr"].append((e2, e3))
@@ -216,21 +219,22 @@ def main():
     # database sweep leg (descriptors resident): 8 queries against a DB of args.db entries
     sweep = None
     if rank == 0:
-        nq = 8
-        db = cand[torch.arange(args.db, device=device) % B].contiguous()
+        nq = 4
+        db = cand[torch.arange(args.db, device=device) % B].contiguous()   # args.db * 58 560 B (> 256 MB L3 by default)
         q = cand[:nq].contiguous()
         for _ in range(2):
-            ring.corr_sweep(q, db)
+            ring.corr_sweep_fft(q, db)
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(5):
-            ring.corr_sweep(q, db)
+            ring.corr_sweep_fft(q, db)
         b.record()
         torch.cuda.synchronize()
         ms = a.elapsed_time(b) / 5
         sweep = {"pairs_per_s": nq * args.db / ms * 1e3, "db": args.db, "queries": nq, "ms": ms,
-                 "hbm_gbs": args.db * 57600 / ms / 1e6}
+                 "bytes_per_pair": 58560, "algorithmic_gbs": nq * args.db * 58560 / ms / 1e6,
+                 "kernel": "k_ring_corr_fft (half-spectrum DB, in-register real FFT-120)"}
 
     gicp_res = None
     if args.gicp_pairs > 0:
@@ -268,7 +272,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1] batched: 120k-pt synthetic lidar scans -> Cartesian BEV "
-                                   "120x120x1 -> Radon 120x120 -> normalise -> rotation correlation vs 1 candidate",
+                                   "120x120x1 -> Radon 120x120 -> normalise -> half spectrum -> FFT-domain rotation correlation vs 1 candidate",
                        "pairs_per_rank_per_step": B, "points_per_scan": N_POINTS,
                        "parallelism": f"scan-sharded x{world}" + (" + RCCL all-gather of descriptors" if dist_on else "")},
             "kernel_ms": kern_ms,

@@ -325,6 +325,24 @@ int mrs_pointfeat_batch(mrs_ctx* ctx, const float* d_points, int32_t stride_floa
                         int32_t batch, int32_t k, int32_t* d_knn, float* d_eigens, float* d_features,
                         float* d_feat_planes, mrs_stream stream);
 
+/* ------------------------------------------------------------------------------------
+ * FFT-domain RING correlation (rows R2, C1), specialised for num_ring = num_sector = 120
+ * ---------------------------------------------------------------------------------- */
+
+/* Half TIRING: the first n_angles/2+1 = 61 angle-frequency rows of torch.fft.fft2(x, dim=-2, norm="ortho")
+ * (RING_ros/util.py:198) for real input; the remaining rows are their conjugates.
+ * d_norm_sino float[n_img][120][120] -> d_half_spec interleaved complex64 [n_img][61][120].
+ * This is the database format of the FFT-domain sweep (58 560 B per entry). */
+int mrs_ring_half_spectrum(mrs_ctx* ctx, const float* d_norm_sino, int32_t n_img, int32_t n_angles, int32_t det,
+                           float* d_half_spec, mrs_stream stream);
+
+/* C1 sweep / pairs on half spectra: same outputs as mrs_ring_corr_sweep / mrs_ring_corr_pairs
+ * (fast_corr, RING_ros/util.py:362-374; single channel). */
+int mrs_ring_corr_fft_sweep(mrs_ctx* ctx, const float* d_query_spec, int32_t n_query, const float* d_db_spec,
+                            int32_t n_db, float* d_dist, int32_t* d_angle, float* d_corr, mrs_stream stream);
+int mrs_ring_corr_fft_pairs(mrs_ctx* ctx, const float* d_a_spec, const float* d_b_spec, int32_t n_pairs,
+                            float* d_dist, int32_t* d_angle, float* d_corr, mrs_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,290 @@
+// ringfft.hip -- FFT-domain RING rotation correlation for gfx950,
+// specialised for the reference configuration num_ring = num_sector = 120 (RING_ros/config.py:7-8).
+//
+// What the reference does per candidate (RING_ros/util.py:362-374): corr = ifft_angle(a * conj(b)),
+// |corr|, sum over detectors, fftshift, max/argmax, with a, b the TIRING spectra (util.py:198).
+// Here the database holds the Hermitian HALF spectrum of every normalised sinogram
+// ([61][120] complex64, ortho scaled = the first 61 angle-frequency rows of the reference's TIRING,
+// 58 560 B per entry instead of 115 200 B), the query's half spectrum sits in LDS, and every lane
+// owns one detector column: it streams its 61 complex values of the candidate from HBM (coalesced
+// across lanes), forms the conjugate product, and runs a 120-point real inverse transform entirely in
+// registers (half-length trick + generated straight-line complex FFT-60, csrc/fft_codelets.hpp).
+// The 120 |corr| values per lane are summed across the 120 lanes with a wave reduce-scatter.
+// ~0.3 MFLOP and 58.56 KB per pair -> HBM-bound by design (5 flop/byte vs 26 flop/byte machine balance).
+#include <cmath>
+
+#include "common.hpp"
+#include "fft_codelets.hpp"
+
+namespace {
+
+constexpr int kA = 120;        // angles
+constexpr int kD = 120;        // detectors
+constexpr int kHalf = 61;      // kA / 2 + 1
+constexpr int kSlotThreads = 128;
+
+// Z[k] = E + i O for one k, from P[k] = (ar, ai) and P[60-k] = (br, bi):
+// E = P[k] + conj(P[60-k]),  O = (P[k] - conj(P[60-k])) * exp(+2 pi i k / 120)
+template <int K>
+__device__ __forceinline__ void irfft_pre(float ar, float ai, float br, float bi, float& zr, float& zi)
+{
+    const float er = ar + br, ei = ai - bi;
+    const float dr = ar - br, di = ai + bi;
+    const float orr = dr * kCos120[K] - di * kSin120[K];
+    const float oi = dr * kSin120[K] + di * kCos120[K];
+    zr = er - oi;
+    zi = ei + orr;
+}
+
+// Conjugate product of two half spectra streamed straight into the pre-processed FFT input, then the
+// 60-point inverse codelet: on return x[2m] = re[m], x[2m+1] = im[m] with
+// x[n] = sum_{k=0}^{119} P_full[k] exp(+2 pi i k n / 120), P = a * conj(b).
+// load(k, ar, ai, br, bi) fetches a[k] and b[k] of this lane's column.
+template <class Load>
+__device__ __forceinline__ void corr_irfft120(Load load, float (&re)[60], float (&im)[60])
+{
+    auto prod = [&](int k, float& pr, float& pi) {
+        float ar, ai, br, bi;
+        load(k, ar, ai, br, bi);
+        pr = ar * br + ai * bi;   // a * conj(b)
+        pi = ai * br - ar * bi;
+    };
+    {
+        float p0r, p0i, p60r, p60i;
+        prod(0, p0r, p0i);
+        prod(60, p60r, p60i);
+        irfft_pre<0>(p0r, p0i, p60r, p60i, re[0], im[0]);
+    }
+#define MRS_IRFFT_PAIR(J)                                                   \
+    {                                                                       \
+        float ur, ui, wr, wi;                                               \
+        prod(J, ur, ui);                                                    \
+        prod(60 - J, wr, wi);                                               \
+        irfft_pre<J>(ur, ui, wr, wi, re[J], im[J]);                         \
+        irfft_pre<60 - J>(wr, wi, ur, ui, re[60 - J], im[60 - J]);          \
+    }
+    MRS_IRFFT_PAIR(1) MRS_IRFFT_PAIR(2) MRS_IRFFT_PAIR(3) MRS_IRFFT_PAIR(4) MRS_IRFFT_PAIR(5) MRS_IRFFT_PAIR(6)
+    MRS_IRFFT_PAIR(7) MRS_IRFFT_PAIR(8) MRS_IRFFT_PAIR(9) MRS_IRFFT_PAIR(10) MRS_IRFFT_PAIR(11) MRS_IRFFT_PAIR(12)
+    MRS_IRFFT_PAIR(13) MRS_IRFFT_PAIR(14) MRS_IRFFT_PAIR(15) MRS_IRFFT_PAIR(16) MRS_IRFFT_PAIR(17) MRS_IRFFT_PAIR(18)
+    MRS_IRFFT_PAIR(19) MRS_IRFFT_PAIR(20) MRS_IRFFT_PAIR(21) MRS_IRFFT_PAIR(22) MRS_IRFFT_PAIR(23) MRS_IRFFT_PAIR(24)
+    MRS_IRFFT_PAIR(25) MRS_IRFFT_PAIR(26) MRS_IRFFT_PAIR(27) MRS_IRFFT_PAIR(28) MRS_IRFFT_PAIR(29)
+#undef MRS_IRFFT_PAIR
+    {
+        float pr, pi;
+        prod(30, pr, pi);
+        irfft_pre<30>(pr, pi, pr, pi, re[30], im[30]);
+    }
+    cfft60_inv(re, im);
+}
+
+// real x (x[2m] = re[m], x[2m+1] = im[m]) -> X[0..60] = sum_n x[n] exp(-2 pi i k n / 120), handed to
+// store(k, xr, xi) one frequency at a time (keeps the register footprint at the codelet's)
+template <class Store>
+__device__ __forceinline__ void rfft120(float (&re)[60], float (&im)[60], Store store)
+{
+    cfft60_fwd(re, im);
+#pragma unroll
+    for (int k = 0; k <= 60; ++k) {
+        const int k0 = k % 60, k1 = (60 - k) % 60;
+        const float ar = re[k0], ai = im[k0];
+        const float br = re[k1], bi = -im[k1];                     // conj(Z[60-k])
+        const float sr = ar + br, si = ai + bi;
+        const float dr = ar - br, di = ai - bi;
+        // X = 0.5 * S - 0.5 i * exp(-i theta_k) * D,   exp(-i theta) = cos - i sin
+        const float tr = dr * kCos120[k] + di * kSin120[k];
+        const float ti = di * kCos120[k] - dr * kSin120[k];
+        store(k, 0.5f * (sr + ti), 0.5f * (si - tr));
+    }
+}
+
+// R2: half spectrum (ortho) of normalised sinograms.  grid = images, 128 lanes (120 columns).
+__global__ __launch_bounds__(kSlotThreads) void k_ring_half_spectrum(const float* __restrict__ x, float2* __restrict__ out)
+{
+    const int d = min((int)threadIdx.x, kD - 1);
+    const float* src = x + (size_t)blockIdx.x * kA * kD + d;
+    float re[60], im[60];
+#pragma unroll
+    for (int m = 0; m < 60; ++m) {
+        re[m] = src[(2 * m) * kD];
+        im[m] = src[(2 * m + 1) * kD];
+    }
+    const bool live = threadIdx.x < kD;
+    const float sc = 0.09128709291752769f;  // 1/sqrt(120)
+    float2* dst = out + (size_t)blockIdx.x * kHalf * kD + d;
+    rfft120(re, im, [&](int k, float xr, float xi) {
+        if (live) dst[k * kD] = make_float2(xr * sc, xi * sc);
+    });
+}
+
+// Sum over the 64 lanes of a wave of |x[n]|, n = 0..119, where x[2m] = re[m], x[2m+1] = im[m]
+// (reduce-scatter: 6 halving steps).  On return lane L holds the totals of n = 2L (w0) and 2L+1 (w1).
+__device__ __forceinline__ void wave_abs_reduce_scatter(const float (&re)[60], const float (&im)[60], bool live,
+                                                        float& w0, float& w1)
+{
+    const int lane = threadIdx.x & 63;
+    float w[64];
+    {
+        const bool hi = (lane & 32) != 0;   // step 0: indices [0,64) stay in the low half-wave, [64,128) in the high
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const float lo_v = live ? fabsf((i & 1) ? im[i >> 1] : re[i >> 1]) : 0.0f;
+            const int j = 64 + i;
+            const float hi_v = (j < 120 && live) ? fabsf((j & 1) ? im[(j >> 1) % 60] : re[(j >> 1) % 60]) : 0.0f;
+            const float send = hi ? lo_v : hi_v;
+            const float mine = hi ? hi_v : lo_v;
+            w[i] = mine + __shfl_xor(send, 32, 64);
+        }
+    }
+#pragma unroll
+    for (int step = 1; step < 6; ++step) {
+        const int keep = 64 >> step;
+        const int mask = 32 >> step;
+        const bool hi = (lane & mask) != 0;
+#pragma unroll
+        for (int i = 0; i < keep; ++i) {
+            const float send = hi ? w[i] : w[keep + i];
+            const float mine = hi ? w[keep + i] : w[i];
+            w[i] = mine + __shfl_xor(send, mask, 64);
+        }
+    }
+    w0 = w[0];
+    w1 = w[1];
+}
+
+struct FftCorrP {
+    int nq, ndb, pairwise;
+    float denom;  // 0.15 * C * A * D
+};
+
+// grid = (blocks, nq); NSLOT pair streams of 128 lanes share the LDS-resident query spectrum.
+template <int NSLOT, bool PAIRWISE>
+__global__ __launch_bounds__(NSLOT* kSlotThreads) void k_ring_corr_fft(const float2* __restrict__ Q, const float2* __restrict__ DB,
+                                                                       FftCorrP p, float* __restrict__ dist,
+                                                                       int* __restrict__ angle, float* __restrict__ corr_out)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 qs[];  // [61][120] query half spectrum (sweep mode)
+    __shared__ float xbuf[NSLOT][128];
+    const int q = blockIdx.y;
+    const int slot = threadIdx.x / kSlotThreads;
+    const int t = threadIdx.x % kSlotThreads;
+    const int wave_in_slot = t >> 6, lane = t & 63;
+    const int d = min(t, kD - 1);
+    const bool live_col = t < kD;
+    const float2* qsrc = Q + (size_t)q * kHalf * kD;
+    if (!PAIRWISE) {
+        for (int i = threadIdx.x; i < kHalf * kD; i += NSLOT * kSlotThreads) qs[i] = qsrc[i];
+        __syncthreads();
+    }
+    const int ncand = PAIRWISE ? 1 : p.ndb;
+    const int stride = gridDim.x * NSLOT;
+    const int rounds = (ncand + stride - 1) / stride;
+    for (int r = 0; r < rounds; ++r) {
+        const int cand = (r * gridDim.x + blockIdx.x) * NSLOT + slot;
+        const bool live = cand < ncand;
+        float re[60], im[60];
+        if (live) {
+            const float2* b = DB + ((size_t)(PAIRWISE ? q : cand) * kHalf) * kD + d;
+            corr_irfft120([&](int k, float& ar, float& ai, float& br, float& bi) {
+                const float2 bv = b[k * kD];
+                const float2 av = PAIRWISE ? qsrc[k * kD + d] : qs[k * kD + d];
+                ar = av.x; ai = av.y; br = bv.x; bi = bv.y;
+            }, re, im);
+        } else {
+#pragma unroll
+            for (int m = 0; m < 60; ++m) { re[m] = 0.0f; im[m] = 0.0f; }
+        }
+        float v[2];
+        wave_abs_reduce_scatter(re, im, live && live_col, v[0], v[1]);
+        if (wave_in_slot == 1) { xbuf[slot][2 * lane] = v[0]; xbuf[slot][2 * lane + 1] = v[1]; }
+        __syncthreads();
+        if (wave_in_slot == 0 && live) {
+            const float sc = 0.09128709291752769f;  // ifft ortho factor 1/sqrt(120)
+            const float s0 = (v[0] + xbuf[slot][2 * lane]) * sc, s1 = (v[1] + xbuf[slot][2 * lane + 1]) * sc;
+            // fftshift: shifted index m = (n + 60) % 120; first maximum in m order (util.py:367-371)
+            const int n0 = 2 * lane, n1 = 2 * lane + 1;
+            const int m0 = n0 < 60 ? n0 + 60 : n0 - 60, m1 = n1 < 60 ? n1 + 60 : n1 - 60;
+            const size_t o = (size_t)q * (PAIRWISE ? 1 : p.ndb) + (PAIRWISE ? 0 : cand);
+            float best = -1.0f;
+            int bm = 1 << 30;
+            if (lane < 60) {
+                if (corr_out) { corr_out[o * kA + m0] = s0; corr_out[o * kA + m1] = s1; }
+                best = s0; bm = m0;
+                if (s1 > best || (s1 == best && m1 < bm)) { best = s1; bm = m1; }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                const float ob = __shfl_xor(best, off, 64);
+                const int om = __shfl_xor(bm, off, 64);
+                if (ob > best || (ob == best && om < bm)) { best = ob; bm = om; }
+            }
+            if (lane == 0) {
+                dist[o] = 1.0f - best / p.denom;
+                angle[o] = kA / 2 - bm;
+            }
+        }
+        __syncthreads();  // xbuf reuse
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mrs_ring_half_spectrum(mrs_ctx* ctx, const float* d_norm_sino, int32_t n_img, int32_t n_angles, int32_t det,
+                           float* d_half_spec, mrs_stream stream)
+{
+    MRS_REQUIRE(ctx && d_norm_sino && d_half_spec, "null pointer");
+    MRS_REQUIRE(n_img > 0, "n_img must be positive");
+    if (n_angles != kA || det != kD) {
+        mrs::set_error("ring_half_spectrum is specialised for 120 x 120 (got %d x %d)", n_angles, det);
+        return MRS_ERR_UNSUPPORTED;
+    }
+    MRS_HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_ring_half_spectrum, dim3(n_img), dim3(kSlotThreads), 0, (hipStream_t)stream, d_norm_sino,
+                       reinterpret_cast<float2*>(d_half_spec));
+    MRS_HIP_TRY(hipGetLastError());
+    return MRS_OK;
+}
+
+static int corr_fft_launch(mrs_ctx* ctx, const float* d_q, int32_t n_q, const float* d_db, int32_t n_db, float* d_dist,
+                           int32_t* d_angle, float* d_corr, mrs_stream stream, bool pairwise)
+{
+    MRS_REQUIRE(ctx && d_q && d_db && d_dist && d_angle, "null pointer");
+    MRS_REQUIRE(n_q > 0 && n_db > 0, "counts must be positive");
+    MRS_HIP_TRY(hipSetDevice(ctx->device));
+    FftCorrP p;
+    p.nq = n_q; p.ndb = n_db; p.pairwise = pairwise ? 1 : 0;
+    p.denom = (float)(0.15 * kA * kD);
+    constexpr int NSLOT = 2;
+    hipStream_t s = (hipStream_t)stream;
+    const float2* q2 = reinterpret_cast<const float2*>(d_q);
+    const float2* db2 = reinterpret_cast<const float2*>(d_db);
+    if (pairwise) {
+        hipLaunchKernelGGL((k_ring_corr_fft<1, true>), dim3(1, n_q), dim3(kSlotThreads), 0, s, q2, db2, p, d_dist, d_angle, d_corr);
+    } else {
+        const size_t lds = (size_t)kHalf * kD * sizeof(float2);
+        auto kern = k_ring_corr_fft<NSLOT, false>;
+        MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int blocks = 2 * (ctx->num_cu > 0 ? ctx->num_cu : 256);
+        if (n_q > 1) blocks = (blocks + n_q - 1) / n_q;
+        const int need = (n_db + NSLOT - 1) / NSLOT;
+        if (blocks > need) blocks = need;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(kern, dim3(blocks, n_q), dim3(NSLOT * kSlotThreads), lds, s, q2, db2, p, d_dist, d_angle, d_corr);
+    }
+    MRS_HIP_TRY(hipGetLastError());
+    return MRS_OK;
+}
+
+int mrs_ring_corr_fft_sweep(mrs_ctx* ctx, const float* d_query_spec, int32_t n_query, const float* d_db_spec,
+                            int32_t n_db, float* d_dist, int32_t* d_angle, float* d_corr, mrs_stream stream)
+{
+    return corr_fft_launch(ctx, d_query_spec, n_query, d_db_spec, n_db, d_dist, d_angle, d_corr, stream, false);
+}
+
+int mrs_ring_corr_fft_pairs(mrs_ctx* ctx, const float* d_a_spec, const float* d_b_spec, int32_t n_pairs, float* d_dist,
+                            int32_t* d_angle, float* d_corr, mrs_stream stream)
+{
+    return corr_fft_launch(ctx, d_a_spec, n_pairs, d_b_spec, n_pairs, d_dist, d_angle, d_corr, stream, true);
+}
+
+}  // extern "C"

@@ -260,3 +260,42 @@ def generate_RINGplusplus(pc, device="cuda:0"):
     pts = torch.from_numpy(np.ascontiguousarray(np.asarray(pc, dtype=np.float32)[:, 0:3])).to(device)
     fb, sino, tiring = ringpp_descriptors(pts, np.array([0, pts.shape[0]], np.int64))
     return fb[0], sino[0].cpu(), tiring[0].cpu()
+
+
+def half_spectrum(norm):
+    """Half TIRING (first 61 angle-frequency rows, ortho) of normalised sinograms [..., 120, 120]:
+    the database format of the FFT-domain sweep."""
+    d = _dev(norm)
+    x = norm.contiguous()
+    A, D = x.shape[-2:]
+    n = x.numel() // (A * D)
+    out = torch.empty(x.shape[:-2] + (A // 2 + 1, D, 2), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().mrs_ring_half_spectrum(_lib.ctx(d), _lib.ptr(x), n, A, D, _lib.ptr(out), _lib.current_stream(d)))
+    return torch.view_as_complex(out)
+
+
+def corr_sweep_fft(query_spec, db_spec, want_corr=False):
+    """C1 sweep on half spectra: query_spec [Q,61,120], db_spec [N,61,120] complex64 (device)."""
+    d = _dev(query_spec)
+    q, db = query_spec.contiguous(), db_spec.contiguous()
+    Q, N = q.shape[0], db.shape[0]
+    dist = torch.empty((Q, N), dtype=torch.float32, device=q.device)
+    ang = torch.empty((Q, N), dtype=torch.int32, device=q.device)
+    corr = torch.empty((Q, N, 120), dtype=torch.float32, device=q.device) if want_corr else None
+    _lib.check(_lib.load().mrs_ring_corr_fft_sweep(_lib.ctx(d), _lib.ptr(torch.view_as_real(q)), Q,
+                                                   _lib.ptr(torch.view_as_real(db)), N, _lib.ptr(dist), _lib.ptr(ang),
+                                                   _lib.ptr(corr) if want_corr else None, _lib.current_stream(d)))
+    return (dist, ang, corr) if want_corr else (dist, ang)
+
+
+def corr_pairs_fft(a_spec, b_spec, out=None):
+    """Pairwise C1 on half spectra [P,61,120] complex64 -> (dist [P], angle [P])."""
+    d = _dev(a_spec)
+    a, b = a_spec.contiguous(), b_spec.contiguous()
+    P = a.shape[0]
+    dist, ang = out if out is not None else (torch.empty(P, dtype=torch.float32, device=a.device),
+                                             torch.empty(P, dtype=torch.int32, device=a.device))
+    _lib.check(_lib.load().mrs_ring_corr_fft_pairs(_lib.ctx(d), _lib.ptr(torch.view_as_real(a)),
+                                                   _lib.ptr(torch.view_as_real(b)), P, _lib.ptr(dist), _lib.ptr(ang),
+                                                   None, _lib.current_stream(d)))
+    return dist, ang

@@ -203,3 +203,36 @@ def test_full_size_pipeline_properties(dev):
     # determinism
     d2, a2 = ring.corr_sweep(norm[:1, None], norm[:, None])
     assert np.array_equal(d2.cpu().numpy()[0], d) and np.array_equal(a2.cpu().numpy()[0], a)
+
+
+def test_fft_domain_sweep_matches_reference_and_direct_kernel(dev):
+    """Half-spectrum database + in-register FFT correlation vs fast_corr (util.py:362-374) and vs the
+    direct sinogram-domain kernel."""
+    import torch
+    from mr_slam_amd import ring
+    from oracle import corr_oracle as K
+    db = _ring_db(7, 11)
+    q = np.stack([np.roll(db[2], 21, axis=1), db[5], np.roll(db[6], -7, axis=1)])
+    tq, tdb = torch.from_numpy(q).to(dev), torch.from_numpy(db).to(dev)
+    sq, sdb = ring.half_spectrum(tq[:, 0]), ring.half_spectrum(tdb[:, 0])
+    # the half spectrum is the first 61 rows of the reference's TIRING
+    want_spec = torch.fft.fft2(torch.from_numpy(db[:, 0]), dim=-2, norm="ortho")[:, :61].numpy()
+    assert np.abs(sdb.cpu().numpy() - want_spec).max() < 2e-5 * np.abs(want_spec).max()
+    dist, ang, corr = ring.corr_sweep_fft(sq, sdb, want_corr=True)
+    d2, a2, c2 = ring.corr_sweep(tq, tdb, want_corr=True)
+    np.testing.assert_allclose(corr.cpu().numpy(), c2.cpu().numpy(), rtol=1e-4, atol=1e-3)
+    assert np.abs(dist.cpu().numpy() - d2.cpu().numpy()).max() < 1e-5
+    dist, ang = dist.cpu().numpy(), ang.cpu().numpy()
+    for i in range(q.shape[0]):
+        a = torch.fft.fft2(torch.from_numpy(q[i]), dim=-2, norm="ortho")
+        for j in range(db.shape[0]):
+            b = torch.fft.fft2(torch.from_numpy(db[j]), dim=-2, norm="ortho")
+            wd, wa, wc = K.fast_corr(a, b)
+            assert abs(dist[i, j] - float(wd)) < 1e-5
+            top2 = np.sort(wc)[-2:]
+            if top2[1] - top2[0] > 1e-3 * top2[1]:
+                assert ang[i, j] == wa
+    assert ang[0, 2] == -21 and ang[1, 5] == 0 and ang[2, 6] == 7
+    dp, ap = ring.corr_pairs_fft(sq, sdb[[2, 5, 6]])
+    assert np.array_equal(ap.cpu().numpy(), [-21, 0, 7])
+    assert np.abs(dp.cpu().numpy() - dist[[0, 1, 2], [2, 5, 6]]).max() < 1e-6
