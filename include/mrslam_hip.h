@@ -343,6 +343,26 @@ int mrs_ring_corr_fft_sweep(mrs_ctx* ctx, const float* d_query_spec, int32_t n_q
 int mrs_ring_corr_fft_pairs(mrs_ctx* ctx, const float* d_a_spec, const float* d_b_spec, int32_t n_pairs,
                             float* d_dist, int32_t* d_angle, float* d_corr, mrs_stream stream);
 
+/* ------------------------------------------------------------------------------------
+ * Scan pre-processing
+ * ---------------------------------------------------------------------------------- */
+
+/* open3d PointCloud.voxel_down_sample(voxel_size) as the RING / RING++ / SC nodes call it
+ * (RING_ros/main_RING.py:257-259): d_points [n][stride] float (is_double = 0) or double (1), xyz first;
+ * d_out double[<= n][3] = voxel centroids sorted by voxel index; *h_count = number of voxels.
+ * Synchronises `stream`. */
+int mrs_voxel_downsample(mrs_ctx* ctx, const void* d_points, int32_t is_double, int32_t stride, int32_t n,
+                         double voxel_size, double* d_out, int32_t* h_count, mrs_stream stream);
+
+/* load_pc_infer (RING_ros/util.py:91-112, disco_ros/main.py:94-113) for a batch of raw clouds: float32
+ * cast, keep |x|,|y| < 70 and 0 < z < 30, divide by 70/70/30.  Raw cloud b = points
+ * [raw_offsets[b], raw_offsets[b+1]) (the offsets are needed on both sides: d_ device, h_ host).
+ * d_xyz_soa: float[3 * total_raw] (upper bound); d_out_offsets: int64[batch+1], written on the device.
+ * (d_xyz_soa, d_out_offsets) is exactly the input of mrs_bev_*_batch: no host round trip. */
+int mrs_crop_scale_batch(mrs_ctx* ctx, const void* d_points, int32_t is_double, int32_t stride,
+                         const int64_t* d_raw_offsets, const int64_t* h_raw_offsets, int32_t batch,
+                         float* d_xyz_soa, int64_t* d_out_offsets, mrs_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,234 @@
+// preprocess.hip -- scan pre-processing on the GPU: the steps between the
+// ROS message and the BEV rasteriser in the LoopDetection nodes.
+//
+// Reference behaviour reproduced (never copied):
+//   * voxel_down_sample(0.2): LoopDetection/src/RING_ros/main_RING.py:257-259 (open3d): voxel index =
+//     floor((p - (min_bound - voxel/2)) / voxel) in double, output = mean of the points of each voxel
+//     (double).  open3d's output ORDER is the iteration order of an unordered_map (unspecified);
+//     here voxels come out sorted by (ix, iy, iz), points of a voxel summed in input order.
+//   * load_pc_infer: LoopDetection/src/RING_ros/util.py:91-112: float32 cast, keep |x|,|y| < 70 and
+//     0 < z < 30, divide by 70/70/30 (float32), order preserved.  The output is written straight in the
+//     ragged SoA layout the BEV kernels consume, with device-side offsets: no host round trip.
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ unsigned long long d2ord(double v)  // order-preserving double -> uint64
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double ord2d(unsigned long long u)
+{
+    return __longlong_as_double((long long)((u >> 63) ? (u & 0x7fffffffffffffffull) : ~u));
+}
+
+template <class T>
+__global__ void k_min_bound(const T* __restrict__ pts, int stride, int n, unsigned long long* __restrict__ mn)
+{
+    double lo[3] = {INFINITY, INFINITY, INFINITY};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) lo[a] = fmin(lo[a], (double)pts[(size_t)i * stride + a]);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        for (int s = 32; s > 0; s >>= 1) lo[a] = fmin(lo[a], __shfl_xor(lo[a], s, 64));
+        if ((threadIdx.x & 63) == 0) atomicMin(&mn[a], d2ord(lo[a]));
+    }
+}
+
+// key = 21 bits per axis of floor((p - (min - voxel/2)) / voxel)
+template <class T>
+__global__ void k_voxel_keys(const T* __restrict__ pts, int stride, int n, double voxel,
+                             const unsigned long long* __restrict__ mn, unsigned long long* __restrict__ keys,
+                             int* __restrict__ vals, int* __restrict__ overflow)
+{
+    const double o0 = ord2d(mn[0]) - 0.5 * voxel, o1 = ord2d(mn[1]) - 0.5 * voxel, o2 = ord2d(mn[2]) - 0.5 * voxel;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double x = (double)pts[(size_t)i * stride], y = (double)pts[(size_t)i * stride + 1], z = (double)pts[(size_t)i * stride + 2];
+        const double fx = floor((x - o0) / voxel), fy = floor((y - o1) / voxel), fz = floor((z - o2) / voxel);
+        if (!(fx >= 0 && fx < 2097152.0 && fy >= 0 && fy < 2097152.0 && fz >= 0 && fz < 2097152.0)) {
+            atomicAdd(overflow, 1);  // NaN or an extent beyond 2^21 voxels
+            keys[i] = ~0ull;
+        } else {
+            keys[i] = ((unsigned long long)fx << 42) | ((unsigned long long)fy << 21) | (unsigned long long)fz;
+        }
+        vals[i] = i;
+    }
+}
+
+__global__ void k_segment_heads(const unsigned long long* __restrict__ keys, int n, int* __restrict__ head)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        head[i] = (keys[i] != ~0ull && (i == 0 || keys[i] != keys[i - 1])) ? 1 : 0;
+}
+
+// one thread per voxel head: sequential mean over the voxel's (stable-sorted) points
+template <class T>
+__global__ void k_voxel_means(const T* __restrict__ pts, int stride, const unsigned long long* __restrict__ keys,
+                              const int* __restrict__ perm, const int* __restrict__ head, const int* __restrict__ slot,
+                              int n, double* __restrict__ out)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (!head[i]) continue;
+        double s0 = 0, s1 = 0, s2 = 0;
+        int c = 0;
+        const unsigned long long k = keys[i];
+        for (int j = i; j < n && keys[j] == k; ++j) {
+            const T* p = pts + (size_t)perm[j] * stride;
+            s0 += (double)p[0]; s1 += (double)p[1]; s2 += (double)p[2];
+            ++c;
+        }
+        double* o = out + (size_t)slot[i] * 3;
+        o[0] = s0 / c; o[1] = s1 / c; o[2] = s2 / c;
+    }
+}
+
+// load_pc_infer flags; pts may be float or double ([n][stride], xyz first)
+template <class T>
+__global__ void k_crop_flags(const T* __restrict__ pts, int stride, size_t n, int* __restrict__ flag)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float x = (float)pts[i * stride], y = (float)pts[i * stride + 1], z = (float)pts[i * stride + 2];
+        flag[i] = (fabsf(x) < 70.0f && fabsf(y) < 70.0f && z < 30.0f && z > 0.0f) ? 1 : 0;
+    }
+}
+
+// offsets_out[b] = pos[raw_offs[b]] (b < batch), offsets_out[batch] = total
+__global__ void k_out_offsets(const int* __restrict__ pos, const int* __restrict__ flag, const int64_t* __restrict__ raw_offs,
+                              int batch, int64_t* __restrict__ out_offs)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > batch) return;
+    const int64_t total_raw = raw_offs[batch];
+    if (b < batch) out_offs[b] = raw_offs[b] < total_raw ? pos[raw_offs[b]] : (total_raw ? pos[total_raw - 1] + flag[total_raw - 1] : 0);
+    else out_offs[b] = total_raw ? pos[total_raw - 1] + flag[total_raw - 1] : 0;
+}
+
+template <class T>
+__global__ void k_crop_scatter(const T* __restrict__ pts, int stride, const int64_t* __restrict__ raw_offs,
+                               const int* __restrict__ flag, const int* __restrict__ pos, const int64_t* __restrict__ out_offs,
+                               float* __restrict__ out)
+{
+    const int b = blockIdx.y;
+    const int64_t r0 = raw_offs[b], r1 = raw_offs[b + 1];
+    const int64_t o0 = out_offs[b];
+    const int64_t nb = out_offs[b + 1] - o0;
+    float* px = out + 3 * o0;
+    for (int64_t i = r0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < r1; i += (int64_t)gridDim.x * blockDim.x) {
+        if (!flag[i]) continue;
+        const int64_t l = pos[i] - o0;
+        px[l] = (float)pts[i * stride] / 70.0f;
+        px[nb + l] = (float)pts[i * stride + 1] / 70.0f;
+        px[2 * nb + l] = (float)pts[i * stride + 2] / 30.0f;
+    }
+}
+
+inline int grid_for(size_t n) { size_t b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b ? b : 1)); }
+
+template <class T>
+int voxel_downsample_impl(mrs_ctx* ctx, const T* d_pts, int stride, int n, double voxel, double* d_out, int32_t* h_count,
+                          hipStream_t s)
+{
+    mrs::Scratch mn, keys_in, keys_out, vals_in, vals_out, head, slot, tmp, ovf;
+    int st;
+    if ((st = mn.alloc(3 * 8, s)) != MRS_OK) return st;
+    if ((st = ovf.alloc(4, s)) != MRS_OK) return st;
+    if ((st = keys_in.alloc((size_t)n * 8, s)) != MRS_OK) return st;
+    if ((st = keys_out.alloc((size_t)n * 8, s)) != MRS_OK) return st;
+    if ((st = vals_in.alloc((size_t)n * 4, s)) != MRS_OK) return st;
+    if ((st = vals_out.alloc((size_t)n * 4, s)) != MRS_OK) return st;
+    if ((st = head.alloc((size_t)n * 4, s)) != MRS_OK) return st;
+    if ((st = slot.alloc((size_t)n * 4, s)) != MRS_OK) return st;
+    MRS_HIP_TRY(hipMemsetAsync(mn.p, 0xff, 3 * 8, s));
+    MRS_HIP_TRY(hipMemsetAsync(ovf.p, 0, 4, s));
+    hipLaunchKernelGGL(k_min_bound<T>, dim3(grid_for(n)), dim3(256), 0, s, d_pts, stride, n, mn.as<unsigned long long>());
+    hipLaunchKernelGGL(k_voxel_keys<T>, dim3(grid_for(n)), dim3(256), 0, s, d_pts, stride, n, voxel, mn.as<unsigned long long>(),
+                       keys_in.as<unsigned long long>(), vals_in.as<int>(), ovf.as<int>());
+    size_t bytes = 0;
+    MRS_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys_in.as<unsigned long long>(), keys_out.as<unsigned long long>(),
+                                                   vals_in.as<int>(), vals_out.as<int>(), n, 0, 64, s));
+    size_t bytes2 = 0;
+    MRS_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes2, head.as<int>(), slot.as<int>(), n, s));
+    if ((st = tmp.alloc(std::max(bytes, bytes2), s)) != MRS_OK) return st;
+    MRS_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes, keys_in.as<unsigned long long>(), keys_out.as<unsigned long long>(),
+                                                   vals_in.as<int>(), vals_out.as<int>(), n, 0, 64, s));
+    hipLaunchKernelGGL(k_segment_heads, dim3(grid_for(n)), dim3(256), 0, s, keys_out.as<unsigned long long>(), n, head.as<int>());
+    MRS_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes2, head.as<int>(), slot.as<int>(), n, s));
+    hipLaunchKernelGGL(k_voxel_means<T>, dim3(grid_for(n)), dim3(256), 0, s, d_pts, stride, keys_out.as<unsigned long long>(),
+                       vals_out.as<int>(), head.as<int>(), slot.as<int>(), n, d_out);
+    MRS_HIP_TRY(hipGetLastError());
+    int last_head = 0, last_slot = 0, overflow = 0;
+    MRS_HIP_TRY(hipMemcpyAsync(&last_head, head.as<int>() + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    MRS_HIP_TRY(hipMemcpyAsync(&last_slot, slot.as<int>() + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    MRS_HIP_TRY(hipMemcpyAsync(&overflow, ovf.p, 4, hipMemcpyDeviceToHost, s));
+    MRS_HIP_TRY(hipStreamSynchronize(s));
+    if (overflow) {
+        mrs::set_error("voxel_downsample: %d points are NaN or more than 2^21 voxels from the minimum bound", overflow);
+        return MRS_ERR_UNSUPPORTED;
+    }
+    *h_count = last_slot + last_head;
+    return MRS_OK;
+}
+
+template <class T>
+int crop_scale_impl(mrs_ctx* ctx, const T* d_pts, int stride, const int64_t* d_raw_offs, int64_t total_raw, int longest,
+                    int batch, float* d_xyz_soa, int64_t* d_out_offs, hipStream_t s)
+{
+    mrs::Scratch flag, pos, tmp;
+    int st;
+    if ((st = flag.alloc((size_t)(total_raw ? total_raw : 1) * 4, s)) != MRS_OK) return st;
+    if ((st = pos.alloc((size_t)(total_raw ? total_raw : 1) * 4, s)) != MRS_OK) return st;
+    if (total_raw) {
+        hipLaunchKernelGGL(k_crop_flags<T>, dim3(grid_for((size_t)total_raw)), dim3(256), 0, s, d_pts, stride, (size_t)total_raw, flag.as<int>());
+        size_t bytes = 0;
+        MRS_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, flag.as<int>(), pos.as<int>(), (int)total_raw, s));
+        if ((st = tmp.alloc(bytes, s)) != MRS_OK) return st;
+        MRS_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, flag.as<int>(), pos.as<int>(), (int)total_raw, s));
+    }
+    hipLaunchKernelGGL(k_out_offsets, dim3((batch + 256) / 256), dim3(256), 0, s, pos.as<int>(), flag.as<int>(), d_raw_offs, batch, d_out_offs);
+    if (total_raw)
+        hipLaunchKernelGGL(k_crop_scatter<T>, dim3(grid_for((size_t)longest), batch), dim3(256), 0, s, d_pts, stride, d_raw_offs,
+                           flag.as<int>(), pos.as<int>(), d_out_offs, d_xyz_soa);
+    MRS_HIP_TRY(hipGetLastError());
+    return MRS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mrs_voxel_downsample(mrs_ctx* ctx, const void* d_points, int32_t is_double, int32_t stride, int32_t n,
+                         double voxel_size, double* d_out, int32_t* h_count, mrs_stream stream)
+{
+    MRS_REQUIRE(ctx && d_points && d_out && h_count, "null pointer");
+    MRS_REQUIRE(n > 0 && stride >= 3, "n must be positive and stride >= 3");
+    MRS_REQUIRE(voxel_size > 0.0, "voxel_size must be positive");
+    MRS_HIP_TRY(hipSetDevice(ctx->device));
+    return is_double ? voxel_downsample_impl<double>(ctx, (const double*)d_points, stride, n, voxel_size, d_out, h_count, (hipStream_t)stream)
+                     : voxel_downsample_impl<float>(ctx, (const float*)d_points, stride, n, voxel_size, d_out, h_count, (hipStream_t)stream);
+}
+
+int mrs_crop_scale_batch(mrs_ctx* ctx, const void* d_points, int32_t is_double, int32_t stride, const int64_t* d_raw_offsets,
+                         const int64_t* h_raw_offsets, int32_t batch, float* d_xyz_soa, int64_t* d_out_offsets, mrs_stream stream)
+{
+    MRS_REQUIRE(ctx && d_points && d_raw_offsets && h_raw_offsets && d_xyz_soa && d_out_offsets, "null pointer");
+    MRS_REQUIRE(batch > 0 && stride >= 3, "batch must be positive and stride >= 3");
+    MRS_REQUIRE(h_raw_offsets[batch] < (1ll << 31), "more than 2^31 points");
+    int64_t longest = 0;
+    for (int b = 0; b < batch; ++b) {
+        MRS_REQUIRE(h_raw_offsets[b + 1] >= h_raw_offsets[b], "offsets must be non-decreasing");
+        longest = std::max(longest, h_raw_offsets[b + 1] - h_raw_offsets[b]);
+    }
+    MRS_HIP_TRY(hipSetDevice(ctx->device));
+    return is_double ? crop_scale_impl<double>(ctx, (const double*)d_points, stride, d_raw_offsets, h_raw_offsets[batch], (int)longest, batch,
+                                               d_xyz_soa, d_out_offsets, (hipStream_t)stream)
+                     : crop_scale_impl<float>(ctx, (const float*)d_points, stride, d_raw_offsets, h_raw_offsets[batch], (int)longest, batch,
+                                              d_xyz_soa, d_out_offsets, (hipStream_t)stream);
+}
+
+}  // extern "C"

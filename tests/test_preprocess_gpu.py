@@ -1,0 +1,81 @@
+"""GPU parity for the pre-processing row N2 vs numpy restatements of open3d voxel_down_sample
+(main_RING.py:257-259) and load_pc_infer (util.py:91-112)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available()
+    from mr_slam_amd import _lib
+    _lib.load()
+    return "cuda:0"
+
+
+def _np_voxel_down_sample(p, vs):
+    p = np.asarray(p, np.float64)
+    idx = np.floor((p - (p.min(0) - vs * 0.5)) / vs).astype(np.int64)
+    order = np.lexsort((idx[:, 2], idx[:, 1], idx[:, 0]))
+    idx, ps = idx[order], p[order]
+    head = np.ones(len(p), bool)
+    head[1:] = (idx[1:] != idx[:-1]).any(1)
+    seg = np.cumsum(head) - 1
+    out = np.zeros((seg[-1] + 1, 3))
+    np.add.at(out, seg, ps)
+    return out / np.bincount(seg)[:, None]
+
+
+def _np_load_pc_infer(pc):
+    pc = np.array(pc, dtype=np.float32)
+    keep = (np.abs(pc[:, 0]) < 70.) & (np.abs(pc[:, 1]) < 70.) & (pc[:, 2] < 30.) & (pc[:, 2] > 0.)
+    h = pc[keep][:, :3].copy()
+    h[:, 0] = h[:, 0] / 70.
+    h[:, 1] = h[:, 1] / 70.
+    h[:, 2] = h[:, 2] / 30.
+    return h
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_voxel_down_sample(dev, dtype):
+    import torch
+    from mr_slam_amd import preprocess, synth
+    pts = synth.lidar_scan(70, 60000, metric=True).astype(dtype)
+    got = preprocess.voxel_down_sample(torch.from_numpy(pts).to(dev), 0.2).cpu().numpy()
+    want = _np_voxel_down_sample(pts, 0.2)
+    assert got.shape == want.shape and 2000 < got.shape[0] < pts.shape[0]
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+
+
+def test_load_pc_infer_batch_feeds_bev(dev, oracle):
+    import torch
+    from mr_slam_amd import bev, preprocess, synth
+    rng = np.random.default_rng(5)
+    raws = []
+    for i, n in enumerate((30000, 0, 12345)):
+        p = synth.lidar_scan(80 + i, max(n, 1), metric=True)[:n].astype(np.float64)
+        p[:, 2] -= rng.uniform(0, 0.5)                    # push some points below z = 0
+        raws.append(np.concatenate([p, rng.uniform(size=(n, 1))], 1))   # x, y, z, intensity
+    offs = np.cumsum([0] + [r.shape[0] for r in raws]).astype(np.int64)
+    pts = torch.from_numpy(np.concatenate(raws)).to(dev)
+    xyz, doffs = preprocess.load_pc_infer_batch(pts, offs)
+    h_offs = doffs.cpu().numpy()
+    img = bev.cart_bev(xyz, doffs, 1, 1, 120, 120, 1).cpu().numpy()
+    for b, r in enumerate(raws):
+        want = _np_load_pc_infer(r)
+        assert h_offs[b + 1] - h_offs[b] == want.shape[0]
+        nb = want.shape[0]
+        got = xyz[3 * h_offs[b]: 3 * h_offs[b] + 3 * nb].cpu().numpy().reshape(3, nb).T
+        np.testing.assert_array_equal(got, want)
+        soa = np.ascontiguousarray(want.T).reshape(-1)
+        np.testing.assert_array_equal(img[b].reshape(-1), oracle.bev_cart(soa, 1, 1, 120, 120, 1).reshape(-1, 3)[:, 2])
+
+
+def test_wire_format():
+    from mr_slam_amd import preprocess as P
+    id0, id1 = P.loop_ids(0, 41, 2, 7)
+    assert id0 == (97 << 56) + 42 and id1 == (99 << 56) + 8
+    assert chr(id0 >> 56) == "a" and (id0 & ((1 << 56) - 1)) == 42
+    assert P.loopinfo_line(0, 41, 2, 7, (1.0, 2.0, 3.0), (0.0, 0.0, 0.0, 1.0)) == "0 41 2 7 1.0 2.0 3.0 0.0 0.0 0.0 1.0"
