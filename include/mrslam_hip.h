@@ -363,6 +363,23 @@ int mrs_crop_scale_batch(mrs_ctx* ctx, const void* d_points, int32_t is_double, 
                          const int64_t* d_raw_offsets, const int64_t* h_raw_offsets, int32_t batch,
                          float* d_xyz_soa, int64_t* d_out_offsets, mrs_stream stream);
 
+/* ------------------------------------------------------------------------------------
+ * Mapping-side DiSCO matcher
+ * ---------------------------------------------------------------------------------- */
+
+/* GlobalManager::calcRelOri(newDiSCO, oldDiSCO) (Mapping/src/global_manager/src/global_manager.cpp:2719-2762),
+ * literal including its quirks (non-conjugate cross term, no normalisation, unshifted argmax):
+ * d_a, d_b interleaved complex64 [n_pairs][height][width] -> d_rel_angle_deg float[n_pairs]
+ * = (argmax(real(IFFT2_double(cross))) % width) * 3.0. */
+int mrs_disco_rel_ori_literal(mrs_ctx* ctx, const float* d_a, const float* d_b, int32_t n_pairs, int32_t height,
+                              int32_t width, float* d_rel_angle_deg, mrs_stream stream);
+
+/* Nearest DiSCO signature by squared L2 distance: replaces the kd-tree query over the 1024-d signatures
+ * (global_manager.cpp:993-1188, src/kdtree.cpp; LoopDetection twin: sklearn KDTree k=1 at
+ * disco_ros/main.py:284-285).  d_query float[n_query][dim], d_db float[n_db][dim]. */
+int mrs_signature_search(mrs_ctx* ctx, const float* d_query, int32_t n_query, const float* d_db, int32_t n_db, int32_t dim,
+                         int32_t* d_index, float* d_dist2, mrs_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

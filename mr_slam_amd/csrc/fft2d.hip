@@ -20,7 +20,7 @@
 namespace {
 
 struct PlanKey {
-    int n0, n1, batch, inverse;
+    int n0, n1, batch, inverse;  // inverse: 0 fwd f32, 1 inv f32, 3 inv f64
     bool operator<(const PlanKey& o) const
     {
         if (n0 != o.n0) return n0 < o.n0;
@@ -49,19 +49,19 @@ bool g_setup = false;
     } while (0)
 
 // in-place complex 2-D transform of `batch` contiguous [n0][n1] interleaved-complex images
-int fft2_inplace(mrs_ctx* ctx, float2* d, int n0, int n1, int batch, bool inverse, hipStream_t s)
+int fft2_inplace(mrs_ctx* ctx, void* d, int n0, int n1, int batch, bool inverse, hipStream_t s, bool dbl = false)
 {
     PlanEntry pe;
     {
         std::lock_guard<std::mutex> g(g_mu);
         if (!g_setup) { MRS_FFT_TRY(rocfft_setup()); g_setup = true; }
-        const auto key = std::make_pair((const mrs_ctx*)ctx, PlanKey{n0, n1, batch, inverse ? 1 : 0});
+        const auto key = std::make_pair((const mrs_ctx*)ctx, PlanKey{n0, n1, batch, (inverse ? 1 : 0) | (dbl ? 2 : 0)});
         auto it = g_plans.find(key);
         if (it == g_plans.end()) {
             const size_t lengths[2] = {(size_t)n1, (size_t)n0};  // fastest dimension first
             MRS_FFT_TRY(rocfft_plan_create(&pe.plan, rocfft_placement_inplace,
                                            inverse ? rocfft_transform_type_complex_inverse : rocfft_transform_type_complex_forward,
-                                           rocfft_precision_single, 2, lengths, (size_t)batch, nullptr));
+                                           dbl ? rocfft_precision_double : rocfft_precision_single, 2, lengths, (size_t)batch, nullptr));
             MRS_FFT_TRY(rocfft_plan_get_work_buffer_size(pe.plan, &pe.work));
             it = g_plans.emplace(key, pe).first;
         }
@@ -197,6 +197,69 @@ __global__ void k_rotate_nearest(const float* __restrict__ in, int H, int W, con
     }
 }
 
+
+// N4: GlobalManager::calcRelOri (Mapping/src/global_manager/src/global_manager.cpp:2719-2762), LITERAL:
+// cross = (ra*rb + ia*ib) + i (ra*ib + rb*ia)   [float products; note the + in the imaginary part, which is
+// not a conjugate product -- reproduced on purpose], unnormalised backward 2-D FFT in double, real part
+// narrowed to float, first argmax, relAngle = (argmax % width) * 3.0.
+__global__ void k_relori_cross(const float2* __restrict__ a, const float2* __restrict__ b, size_t n, double2* __restrict__ out)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float2 u = a[i], v = b[i];
+        out[i] = make_double2((double)(u.x * v.x + u.y * v.y), (double)(u.x * v.y + v.x * u.y));
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_relori_argmax(const double2* __restrict__ corr, int R, int S, float* __restrict__ rel_angle)
+{
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    const double2* base = corr + (size_t)blockIdx.x * R * S;
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    for (int m = threadIdx.x; m < R * S; m += 1024) {
+        const float v = (float)base[m].x;
+        if (v > best) { best = v; bidx = m; }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    best = wave_max_arg(best, bidx);
+    if (lane == 0) { bv[wave] = best; bi[wave] = bidx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (bv[w] > best || (bv[w] == best && bi[w] < bidx)) { best = bv[w]; bidx = bi[w]; }
+        rel_angle[blockIdx.x] = (float)(bidx % S) * 3.0f;
+    }
+}
+
+// N4: nearest DiSCO signature (the role of the kd-tree of global_manager.cpp:993-1188 / src/kdtree.cpp):
+// exact brute-force squared-L2 1-NN; one workgroup per query, database streamed once per query.
+__global__ __launch_bounds__(256) void k_signature_nn(const float* __restrict__ q, const float* __restrict__ db, int n, int dim,
+                                                      int* __restrict__ out_idx, float* __restrict__ out_d2)
+{
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const float* qq = q + (size_t)blockIdx.x * dim;
+    float best = INFINITY;
+    int bidx = 0x7fffffff;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int j = wave; j < n; j += 4) {          // one wave per database row, lanes stride the dimension
+        const float* r = db + (size_t)j * dim;
+        float acc = 0.0f;
+        for (int c = lane; c < dim; c += 64) { const float d = qq[c] - r[c]; acc = __builtin_fmaf(d, d, acc); }
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (acc < best) { best = acc; bidx = j; }
+    }
+    if (lane == 0) { bv[wave] = best; bi[wave] = bidx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (bv[w] < best || (bv[w] == best && bi[w] < bidx)) { best = bv[w]; bidx = bi[w]; }
+        out_idx[blockIdx.x] = bidx;
+        out_d2[blockIdx.x] = best;
+    }
+}
+
 inline int grid_for(size_t n) { size_t b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b ? b : 1)); }
 
 }  // namespace
@@ -279,6 +342,38 @@ int mrs_bev_translation(mrs_ctx* ctx, const float* d_a, const float* d_b, int32_
     const float hw = (float)(height * width);
     hipLaunchKernelGGL(k_mag_shift_argmax, dim3(n_pairs), dim3(1024), 0, s, fa.as<float2>(), channels, height, width,
                        1.0f / (hw * sqrtf(hw)), 0.0f, d_arg, d_max, d_corr);
+    MRS_HIP_TRY(hipGetLastError());
+    return MRS_OK;
+}
+
+
+int mrs_disco_rel_ori_literal(mrs_ctx* ctx, const float* d_a, const float* d_b, int32_t n_pairs, int32_t height,
+                              int32_t width, float* d_rel_angle_deg, mrs_stream stream)
+{
+    MRS_REQUIRE(ctx && d_a && d_b && d_rel_angle_deg, "null pointer");
+    MRS_REQUIRE(n_pairs > 0 && height > 0 && width > 0, "sizes must be positive");
+    MRS_HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)n_pairs * height * width;
+    mrs::Scratch cross;
+    int st = cross.alloc(n * sizeof(double2), s);
+    if (st != MRS_OK) return st;
+    hipLaunchKernelGGL(k_relori_cross, dim3(grid_for(n)), dim3(256), 0, s, reinterpret_cast<const float2*>(d_a),
+                       reinterpret_cast<const float2*>(d_b), n, cross.as<double2>());
+    st = fft2_inplace(ctx, cross.p, height, width, n_pairs, true, s, true);
+    if (st != MRS_OK) return st;
+    hipLaunchKernelGGL(k_relori_argmax, dim3(n_pairs), dim3(1024), 0, s, cross.as<double2>(), height, width, d_rel_angle_deg);
+    MRS_HIP_TRY(hipGetLastError());
+    return MRS_OK;
+}
+
+int mrs_signature_search(mrs_ctx* ctx, const float* d_query, int32_t n_query, const float* d_db, int32_t n_db, int32_t dim,
+                         int32_t* d_index, float* d_dist2, mrs_stream stream)
+{
+    MRS_REQUIRE(ctx && d_query && d_db && d_index && d_dist2, "null pointer");
+    MRS_REQUIRE(n_query > 0 && n_db > 0 && dim > 0, "sizes must be positive");
+    MRS_HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_signature_nn, dim3(n_query), dim3(256), 0, (hipStream_t)stream, d_query, d_db, n_db, dim, d_index, d_dist2);
     MRS_HIP_TRY(hipGetLastError());
     return MRS_OK;
 }

@@ -49,3 +49,29 @@ def phase_corr(a, b, num_sector=NUM_SECTOR, want_corr=False):
                                                 _lib.ptr(corr) if want_corr else None, _lib.current_stream(d)))
     yaw = arg % num_sector
     return (yaw, corr) if want_corr else yaw
+
+
+def calc_rel_ori(a, b):
+    """GlobalManager::calcRelOri (global_manager.cpp:2719-2762), literal: a, b complex64 [P,R,S] or
+    [P,1,R,S] (device).  Returns relative angles in degrees, float32 [P]."""
+    d = _dev(a)
+    a, b = a.contiguous(), b.contiguous()
+    R, S = a.shape[-2:]
+    P = a.numel() // (R * S)
+    out = torch.empty(P, dtype=torch.float32, device=a.device)
+    _lib.check(_lib.load().mrs_disco_rel_ori_literal(_lib.ctx(d), _lib.ptr(torch.view_as_real(a)),
+                                                     _lib.ptr(torch.view_as_real(b)), P, R, S, _lib.ptr(out),
+                                                     _lib.current_stream(d)))
+    return out
+
+
+def signature_search(query, db):
+    """Nearest signature (squared L2): query [Q,dim], db [N,dim] float32 device -> (index [Q], dist2 [Q])."""
+    d = _dev(query)
+    query, db = query.contiguous(), db.contiguous()
+    Q, dim = query.shape
+    idx = torch.empty(Q, dtype=torch.int32, device=query.device)
+    d2 = torch.empty(Q, dtype=torch.float32, device=query.device)
+    _lib.check(_lib.load().mrs_signature_search(_lib.ctx(d), _lib.ptr(query), Q, _lib.ptr(db), db.shape[0], dim,
+                                                _lib.ptr(idx), _lib.ptr(d2), _lib.current_stream(d)))
+    return idx, d2

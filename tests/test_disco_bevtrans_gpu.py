@@ -84,3 +84,32 @@ def test_solve_translation_bev_matches_restatement(dev):
         assert abs(neg[i] - wneg) < 2e-4 * abs(wneg)
     y1, x1, n1 = ring.solve_translation_bev(A[0], B[0])
     assert (y1, x1) == (y[0], x[0])
+
+
+def test_mapping_side_calc_rel_ori_and_signature_search(dev):
+    """Row N4: calcRelOri literal (global_manager.cpp:2719-2762) and the kd-tree's job (1-NN over signatures)."""
+    import torch
+    from mr_slam_amd import disco
+    rng = np.random.default_rng(7)
+    base = (rng.uniform(size=(1, 20, 40, 120)) > 0.93).astype(np.float32)
+    bevs = np.concatenate([np.roll(base, k, axis=3) for k in (0, 9, -20)])
+    sig, spec = disco.disco_from_bev(torch.from_numpy(bevs).to(dev))
+    a = spec[:1].expand(3, -1, -1, -1).contiguous()
+    got = disco.calc_rel_ori(a, spec).cpu().numpy()
+    A = a.cpu().numpy()[:, 0]; B = spec.cpu().numpy()[:, 0]
+    for i in range(3):
+        ra, ia, rb, ib = A[i].real, A[i].imag, B[i].real, B[i].imag
+        cross = (ra * rb + ia * ib).astype(np.float64) + 1j * (ra * ib + rb * ia).astype(np.float64)
+        real = (np.fft.ifft2(cross) * cross.size).real.astype(np.float32)
+        assert got[i] == float(int(np.argmax(real)) % 120) * 3.0
+    # signature search: noisy copies of database entries must find their originals (exact brute force)
+    dbn = rng.normal(size=(500, 1024)).astype(np.float32)
+    pick = np.array([17, 499, 0, 256])
+    qn = dbn[pick] + 0.05 * rng.normal(size=(4, 1024)).astype(np.float32)
+    idx, d2 = disco.signature_search(torch.from_numpy(qn).to(dev), torch.from_numpy(dbn).to(dev))
+    np.testing.assert_array_equal(idx.cpu().numpy(), pick)
+    want = ((qn[:, None, :].astype(np.float64) - dbn[None]) ** 2).sum(-1).min(1)
+    np.testing.assert_allclose(d2.cpu().numpy(), want, rtol=1e-5)
+    # rotation invariance of the DiSCO signature: all three rotated copies are (near-)zero distance apart
+    _, d2r = disco.signature_search(sig, sig[:1].contiguous())
+    assert float(d2r.max()) < 1e-3 * float((sig ** 2).sum(1).max())
