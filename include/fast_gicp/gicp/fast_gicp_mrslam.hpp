@@ -81,6 +81,12 @@ public:
     const double* getFinalHessian() const { return hessian_; }
 
 protected:
+    void setVoxelMode(double resolution, int neighbors)
+    {
+        prm_.voxel_resolution = resolution;
+        prm_.voxel_neighbors = neighbors;
+    }
+
     void computeTransformation(PointCloudSource& output, const Matrix4& guess) override
     {
         prm_.max_iterations = this->max_iterations_;
@@ -131,5 +137,31 @@ private:
     mrs_gicp_params prm_;
     double hessian_[36] = {0};
 };
+
+// Drop-in for fast_gicp::FastVGICPCuda (the launch-file default `registration_method=FAST_VGICP_CUDA`,
+// Mapping/src/global_manager/launch/global_manager.launch:51; configured at global_manager.cpp:2445-2455):
+// voxelised GICP, row G7 of SURVEY.md section 8(a).
+template <typename PointSource, typename PointTarget>
+class FastVGICPCuda : public FastGICP<PointSource, PointTarget> {
+public:
+    FastVGICPCuda()
+    {
+        this->reg_name_ = "FastVGICPCuda(mrslam_hip)";
+        this->setVoxelMode(1.0, 1);  // upstream defaults: resolution 1.0, DIRECT1
+    }
+    void setResolution(double r) { res_ = r; this->setVoxelMode(res_, nb_); }
+    void setNeighborSearchMethod(NeighborSearchMethod m, double /*radius*/ = -1.0)
+    {
+        nb_ = m == NeighborSearchMethod::DIRECT27 ? 27 : (m == NeighborSearchMethod::DIRECT7 ? 7 : 1);
+        this->setVoxelMode(res_, nb_);
+    }
+    void setKernelWidth(double) {}   // RBF-kernel covariances are not implemented (kNN covariances are used)
+private:
+    double res_ = 1.0;
+    int nb_ = 1;
+};
+
+template <typename PointSource, typename PointTarget>
+using FastVGICP = FastVGICPCuda<PointSource, PointTarget>;
 
 }  // namespace fast_gicp

@@ -226,6 +226,12 @@ typedef struct mrs_gicp_params {
     double rotation_epsilon;            /* 2e-3                                                */
     double transformation_epsilon;      /* 5e-4 (Mapping: 1e-3)                                */
     double lm_init_lambda_factor;       /* 1e-9                                                */
+    double voxel_resolution;            /* 0 = GICP (FastGICP); > 0 = voxelised GICP, row G7
+                                           (FastVGICP / FastVGICPCuda::setResolution; Mapping: 0.5,
+                                           global_manager.cpp:2450)                            */
+    int32_t voxel_neighbors;            /* 1 / 7 / 27 = DIRECT1 / DIRECT7 / DIRECT27
+                                           (setNeighborSearchMethod, global_manager.cpp:2452)  */
+    int32_t reserved;
 } mrs_gicp_params;
 
 void mrs_gicp_default_params(mrs_gicp_params* p);

@@ -71,6 +71,9 @@ struct GicpParams {
     int lm_max_iter;
     int force_iters;      // >0: run exactly this many outer iterations, no convergence test
     int k;
+    double voxel_res;     // > 0: VGICP (voxelised target, G7); 0: GICP
+    int voxel_neighbors;  // 1, 7 or 27 (DIRECT1 / DIRECT7 / DIRECT27)
+    int pad;
 };
 
 __device__ __forceinline__ double wave_sum_d(double v)
@@ -822,6 +825,167 @@ __global__ __launch_bounds__(kNNThreads) void k_linearize(
     }
 }
 
+
+// ---- G7: voxelised GICP (fast_gicp FastVGICP / FastVGICPCuda; Koide et al., ICRA 2021) ---------------------
+// The target is summarised per voxel of edge `res`: mean of its points and mean of their (regularised)
+// covariances (ADDITIVE accumulation).  A transformed source point corresponds to the voxel that contains it
+// (DIRECT1) and optionally its 6 / 26 neighbours; each correspondence is a distribution-to-distribution term
+// weighted by sqrt(points in the voxel).  max_correspondence_distance is not used.  Parity unpinned: restated
+// from the publication and SURVEY.md row G7 (the submodule is absent).
+__device__ __forceinline__ unsigned long long voxel_key(int cloud, int ix, int iy, int iz)
+{
+    return ((unsigned long long)cloud << 48) | ((unsigned long long)(ix & 0xffff) << 32) |
+           ((unsigned long long)(iy & 0xffff) << 16) | (unsigned long long)(iz & 0xffff);
+}
+
+__global__ void k_vox_keys(const float4* __restrict__ pts, const int64_t* __restrict__ offs, double res,
+                           unsigned long long* __restrict__ keys, int* __restrict__ vals)
+{
+    const int c = blockIdx.y;
+    const int64_t o = offs[c];
+    const int n = (int)(offs[c + 1] - o);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 p = pts[o + i];
+        keys[o + i] = voxel_key(c, (int)floor((double)p.x / res) + 32768, (int)floor((double)p.y / res) + 32768,
+                                (int)floor((double)p.z / res) + 32768);
+        vals[o + i] = (int)(o + i);
+    }
+}
+
+__global__ void k_vox_heads(const unsigned long long* __restrict__ keys, size_t n, int* __restrict__ head)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+}
+
+// one lane per voxel head: key, mean (w = count) and mean covariance of the voxel
+__global__ void k_vox_build(const float4* __restrict__ pts, const double* __restrict__ cov, const unsigned long long* __restrict__ keys,
+                            const int* __restrict__ perm, const int* __restrict__ head, const int* __restrict__ slot, size_t n,
+                            unsigned long long* __restrict__ vkeys, float4* __restrict__ vmean, double* __restrict__ vcov)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (!head[i]) continue;
+        const unsigned long long k = keys[i];
+        double m[3] = {0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0};
+        int cnt = 0;
+        for (size_t j = i; j < n && keys[j] == k; ++j) {
+            const float4 p = pts[perm[j]];
+            m[0] += (double)p.x; m[1] += (double)p.y; m[2] += (double)p.z;
+            for (int a = 0; a < 6; ++a) c[a] += cov[6 * (size_t)perm[j] + a];
+            ++cnt;
+        }
+        const int v = slot[i];
+        vkeys[v] = k;
+        vmean[v] = make_float4((float)(m[0] / cnt), (float)(m[1] / cnt), (float)(m[2] / cnt), (float)cnt);
+        for (int a = 0; a < 6; ++a) vcov[6 * (size_t)v + a] = c[a] / cnt;
+    }
+}
+
+// G7 linearisation: voxel lookup (binary search in the sorted voxel keys) fused with the 28 fp64 sums.
+__global__ __launch_bounds__(kNNThreads) void k_linearize_voxel(
+    const float4* __restrict__ src_all, const int64_t* __restrict__ src_offs, const double* __restrict__ src_cov,
+    const unsigned long long* __restrict__ vkeys, const float4* __restrict__ vmean, const double* __restrict__ vcov,
+    int n_voxels, const LmState* __restrict__ st, GicpParams prm, double* __restrict__ partial, int max_blocks)
+{
+    __shared__ double red[kNNThreads / 64][kTerms];
+    const int pair = blockIdx.y;
+    const LmState& S = st[pair];
+    if (!S.active) return;
+    const int64_t so = src_offs[pair];
+    const int n = (int)(src_offs[pair + 1] - so);
+    const float4* src = src_all + so;
+    double* pout = partial + ((size_t)pair * max_blocks + blockIdx.x) * kTerms;
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = S.xi[i];
+    double acc[kTerms];
+#pragma unroll
+    for (int i = 0; i < kTerms; ++i) acc[i] = 0.0;
+    const int per_block = kNNThreads * kPts;
+    const int nn = prm.voxel_neighbors;
+    for (int base = blockIdx.x * per_block; base < n; base += gridDim.x * per_block) {
+#pragma unroll 1
+        for (int p = 0; p < kPts; ++p) {
+            const int i = base + p * kNNThreads + threadIdx.x;
+            if (i >= n) continue;
+            const float4 a = src[i];
+            double ta[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                ta[r] = T[4 * r] * (double)a.x + T[4 * r + 1] * (double)a.y + T[4 * r + 2] * (double)a.z + T[4 * r + 3];
+            const int cx = (int)floor(ta[0] / prm.voxel_res) + 32768, cy = (int)floor(ta[1] / prm.voxel_res) + 32768,
+                      cz = (int)floor(ta[2] / prm.voxel_res) + 32768;
+            const double* ca = src_cov + 6 * (size_t)(so + i);
+            const double CA[9] = {ca[0], ca[1], ca[2], ca[1], ca[3], ca[4], ca[2], ca[4], ca[5]};
+            double RC[9], RCRa[9];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    RC[3 * r + c] = T[4 * r] * CA[c] + T[4 * r + 1] * CA[3 + c] + T[4 * r + 2] * CA[6 + c];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    RCRa[3 * r + c] = RC[3 * r] * T[4 * c] + RC[3 * r + 1] * T[4 * c + 1] + RC[3 * r + 2] * T[4 * c + 2];
+#pragma unroll 1
+            for (int o = 0; o < 27; ++o) {
+                const int dx = o % 3 - 1, dy = (o / 3) % 3 - 1, dz = o / 9 - 1;
+                const int man = abs(dx) + abs(dy) + abs(dz);
+                if ((nn == 1 && man != 0) || (nn == 7 && man > 1)) continue;
+                const unsigned long long key = voxel_key(pair, cx + dx, cy + dy, cz + dz);
+                int lo = 0, hi = n_voxels;  // first index with vkeys >= key
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (vkeys[mid] < key) lo = mid + 1; else hi = mid;
+                }
+                if (lo >= n_voxels || vkeys[lo] != key) continue;
+                const float4 vm = vmean[lo];
+                const double* cb = vcov + 6 * (size_t)lo;
+                double RCR[9], M[9];
+                RCR[0] = RCRa[0] + cb[0]; RCR[1] = RCRa[1] + cb[1]; RCR[2] = RCRa[2] + cb[2];
+                RCR[3] = RCRa[3] + cb[1]; RCR[4] = RCRa[4] + cb[3]; RCR[5] = RCRa[5] + cb[4];
+                RCR[6] = RCRa[6] + cb[2]; RCR[7] = RCRa[7] + cb[4]; RCR[8] = RCRa[8] + cb[5];
+                if (!inv3_sym(RCR, M)) continue;
+                const double w = sqrt((double)vm.w);
+                double e[3] = {(double)vm.x - ta[0], (double)vm.y - ta[1], (double)vm.z - ta[2]}, Me[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) Me[r] = M[3 * r] * e[0] + M[3 * r + 1] * e[1] + M[3 * r + 2] * e[2];
+                acc[27] += w * (e[0] * Me[0] + e[1] * Me[1] + e[2] * Me[2]);
+                const double J[18] = {0, -ta[2], ta[1], -1, 0, 0,
+                                      ta[2], 0, -ta[0], 0, -1, 0,
+                                      -ta[1], ta[0], 0, 0, 0, -1};
+                double MJ[18];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 6; ++c)
+                        MJ[6 * r + c] = M[3 * r] * J[c] + M[3 * r + 1] * J[6 + c] + M[3 * r + 2] * J[12 + c];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                    for (int c = r; c < 6; ++c)
+                        acc[r * 6 - (r * (r - 1)) / 2 + (c - r)] += w * (J[r] * MJ[c] + J[6 + r] * MJ[6 + c] + J[12 + r] * MJ[12 + c]);
+                }
+#pragma unroll
+                for (int r = 0; r < 6; ++r) acc[21 + r] += w * (J[r] * Me[0] + J[6 + r] * Me[1] + J[12 + r] * Me[2]);
+            }
+        }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < kTerms; ++i) {
+        const double v = wave_sum_d(acc[i]);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kTerms) {
+        double v = 0;
+        for (int w = 0; w < kNNThreads / 64; ++w) v += red[w][threadIdx.x];
+        pout[threadIdx.x] = v;
+    }
+}
+
 // ---- device-side LM bookkeeping (one lane per pair) ------------------------------------------
 __device__ void mul4d(const double* a, const double* b, double* c)
 {
@@ -1083,6 +1247,11 @@ struct mrs_gicp_batch {
     int* d_nblocks = nullptr;
     int* d_nactive = nullptr;
     int* d_corr = nullptr;          // [total source points] correspondences of the current evaluation
+    unsigned long long* d_vkeys = nullptr;  // G7 voxel map of the targets (sorted keys, all pairs)
+    float4* d_vmean = nullptr;
+    double* d_vcov = nullptr;
+    int n_voxels = 0;
+    double vox_res_built = 0.0;
     int max_blocks = 0;
     double last_nn_passes = 0;
 };
@@ -1119,6 +1288,8 @@ void mrs_gicp_default_params(mrs_gicp_params* p)
     p->lm_max_iterations = 10;
     p->lm_init_lambda_factor = 1e-9;
     p->force_iterations = 0;
+    p->voxel_resolution = 0.0;          // FastVGICP(Cuda) default is 1.0; Mapping sets 0.5 (global_manager.cpp:2450)
+    p->voxel_neighbors = 1;             // DIRECT1 (global_manager.cpp:2452)
 }
 
 int mrs_gicp_batch_create(mrs_ctx* ctx, int32_t n_pairs, mrs_gicp_batch** out)
@@ -1147,6 +1318,9 @@ int mrs_gicp_batch_destroy(mrs_gicp_batch* h)
     if (h->d_nblocks) (void)hipFree(h->d_nblocks);
     if (h->d_nactive) (void)hipFree(h->d_nactive);
     if (h->d_corr) (void)hipFree(h->d_corr);
+    if (h->d_vkeys) (void)hipFree(h->d_vkeys);
+    if (h->d_vmean) (void)hipFree(h->d_vmean);
+    if (h->d_vcov) (void)hipFree(h->d_vcov);
     delete h;
     return MRS_OK;
 }
@@ -1167,6 +1341,10 @@ int mrs_gicp_batch_set_params(mrs_gicp_batch* h, const mrs_gicp_params* p)
     h->prm.lm_max_iter = p->lm_max_iterations;
     h->prm.lm_init_factor = p->lm_init_lambda_factor;
     h->prm.force_iters = p->force_iterations;
+    MRS_REQUIRE(p->voxel_resolution >= 0.0, "voxel_resolution must be >= 0");
+    MRS_REQUIRE(p->voxel_neighbors == 1 || p->voxel_neighbors == 7 || p->voxel_neighbors == 27, "voxel_neighbors must be 1, 7 or 27");
+    h->prm.voxel_res = p->voxel_resolution;
+    h->prm.voxel_neighbors = p->voxel_neighbors;
     return MRS_OK;
 }
 
@@ -1272,6 +1450,7 @@ int mrs_gicp_batch_compute_covariances(mrs_gicp_batch* h, int32_t which, int32_t
                            h->d_tlo[which], h->d_thi[which], k, h->d_cov[which], d_knn_out);
     MRS_HIP_TRY(hipGetLastError());
     h->cov_valid[which] = true;
+    if (which == 1) h->vox_res_built = 0.0;
     return MRS_OK;
 }
 
@@ -1319,6 +1498,54 @@ static int ensure_state(mrs_gicp_batch* h)
     return MRS_OK;
 }
 
+
+static int build_voxel_map(mrs_gicp_batch* h, hipStream_t s)
+{
+    if (h->vox_res_built == h->prm.voxel_res && h->d_vkeys) return MRS_OK;
+    MRS_REQUIRE(h->n_pairs < 65536, "VGICP supports at most 65535 pairs per batch");
+    const size_t total = (size_t)h->offs[1][h->n_pairs];
+    mrs::Scratch keys_in, keys_out, vals_in, vals_out, head, slot, tmp;
+    int st;
+    if ((st = keys_in.alloc(total * 8, s)) != MRS_OK) return st;
+    if ((st = keys_out.alloc(total * 8, s)) != MRS_OK) return st;
+    if ((st = vals_in.alloc(total * 4, s)) != MRS_OK) return st;
+    if ((st = vals_out.alloc(total * 4, s)) != MRS_OK) return st;
+    if ((st = head.alloc(total * 4, s)) != MRS_OK) return st;
+    if ((st = slot.alloc(total * 4, s)) != MRS_OK) return st;
+    int64_t longest = 0;
+    for (int i = 0; i < h->n_pairs; ++i) longest = std::max(longest, h->offs[1][i + 1] - h->offs[1][i]);
+    hipLaunchKernelGGL(k_vox_keys, dim3((unsigned)std::min<int64_t>((longest + 255) / 256, 1024), h->n_pairs), dim3(256), 0, s,
+                       h->d_pts[1], h->d_offs[1], h->prm.voxel_res, keys_in.as<unsigned long long>(), vals_in.as<int>());
+    size_t b1 = 0, b2 = 0;
+    MRS_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, b1, keys_in.as<unsigned long long>(), keys_out.as<unsigned long long>(),
+                                                   vals_in.as<int>(), vals_out.as<int>(), (int)total, 0, 64, s));
+    MRS_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, b2, head.as<int>(), slot.as<int>(), (int)total, s));
+    if ((st = tmp.alloc(std::max(b1, b2), s)) != MRS_OK) return st;
+    MRS_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, b1, keys_in.as<unsigned long long>(), keys_out.as<unsigned long long>(),
+                                                   vals_in.as<int>(), vals_out.as<int>(), (int)total, 0, 64, s));
+    const int fb = (int)std::min<size_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_vox_heads, dim3(fb), dim3(256), 0, s, keys_out.as<unsigned long long>(), total, head.as<int>());
+    MRS_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, b2, head.as<int>(), slot.as<int>(), (int)total, s));
+    int last_head = 0, last_slot = 0;
+    MRS_HIP_TRY(hipMemcpyAsync(&last_head, head.as<int>() + (total - 1), 4, hipMemcpyDeviceToHost, s));
+    MRS_HIP_TRY(hipMemcpyAsync(&last_slot, slot.as<int>() + (total - 1), 4, hipMemcpyDeviceToHost, s));
+    MRS_HIP_TRY(hipStreamSynchronize(s));
+    h->n_voxels = last_head + last_slot;
+    if (h->d_vkeys) (void)hipFree(h->d_vkeys);
+    if (h->d_vmean) (void)hipFree(h->d_vmean);
+    if (h->d_vcov) (void)hipFree(h->d_vcov);
+    h->d_vkeys = nullptr; h->d_vmean = nullptr; h->d_vcov = nullptr;
+    MRS_HIP_TRY(hipMalloc(&h->d_vkeys, (size_t)h->n_voxels * 8));
+    MRS_HIP_TRY(hipMalloc(&h->d_vmean, (size_t)h->n_voxels * sizeof(float4)));
+    MRS_HIP_TRY(hipMalloc(&h->d_vcov, (size_t)h->n_voxels * 6 * sizeof(double)));
+    hipLaunchKernelGGL(k_vox_build, dim3(fb), dim3(256), 0, s, h->d_pts[1], h->d_cov[1], keys_out.as<unsigned long long>(),
+                       vals_out.as<int>(), head.as<int>(), slot.as<int>(), total, h->d_vkeys, h->d_vmean, h->d_vcov);
+    MRS_HIP_TRY(hipGetLastError());
+    MRS_HIP_TRY(hipStreamSynchronize(s));
+    h->vox_res_built = h->prm.voxel_res;
+    return MRS_OK;
+}
+
 int mrs_gicp_batch_align(mrs_gicp_batch* h, const double* h_guess, double* h_final, int32_t* h_converged,
                          int32_t* h_iterations, double* h_hessian, mrs_stream stream)
 {
@@ -1331,6 +1558,10 @@ int mrs_gicp_batch_align(mrs_gicp_batch* h, const double* h_guess, double* h_fin
         if (!h->cov_valid[w]) { st = mrs_gicp_batch_compute_covariances(h, w, nullptr, stream); if (st != MRS_OK) return st; }
     st = ensure_state(h);
     if (st != MRS_OK) return st;
+    if (h->prm.voxel_res > 0.0) {
+        st = build_voxel_map(h, s);
+        if (st != MRS_OK) return st;
+    }
     std::vector<LmState> init(h->n_pairs);
     for (int p = 0; p < h->n_pairs; ++p) {
         LmState& S = init[p];
@@ -1349,10 +1580,15 @@ int mrs_gicp_batch_align(mrs_gicp_batch* h, const double* h_guess, double* h_fin
     int active = h->n_pairs;
     while (active > 0 && ticks < max_ticks) {
         MRS_HIP_TRY(hipMemsetAsync(h->d_nactive, 0, sizeof(int), s));
-        hipLaunchKernelGGL(k_nn_scan, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_pts[1], h->d_offs[1],
-                           h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_state, h->prm, h->d_corr);
-        hipLaunchKernelGGL(k_linearize, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_cov[0],
-                           h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->d_corr, h->d_partial, h->max_blocks);
+        if (h->prm.voxel_res > 0.0) {
+            hipLaunchKernelGGL(k_linearize_voxel, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_cov[0], h->d_vkeys,
+                               h->d_vmean, h->d_vcov, h->n_voxels, h->d_state, h->prm, h->d_partial, h->max_blocks);
+        } else {
+            hipLaunchKernelGGL(k_nn_scan, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_pts[1], h->d_offs[1],
+                               h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_state, h->prm, h->d_corr);
+            hipLaunchKernelGGL(k_linearize, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_cov[0],
+                               h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->d_corr, h->d_partial, h->max_blocks);
+        }
         hipLaunchKernelGGL(k_lm_update, dim3(h->n_pairs), dim3(64), 0, s, h->d_state, h->d_partial, h->d_nblocks,
                            h->max_blocks, h->prm, h->d_nactive);
         MRS_HIP_TRY(hipGetLastError());
@@ -1391,11 +1627,20 @@ int mrs_gicp_batch_linearize(mrs_gicp_batch* h, const double* h_poses, double* h
         init[p].active = 1;
     }
     MRS_HIP_TRY(hipMemcpyAsync(h->d_state, init.data(), init.size() * sizeof(LmState), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_nn_scan, dim3(h->max_blocks, h->n_pairs), dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0],
-                       h->d_pts[1], h->d_offs[1], h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_state, h->prm, h->d_corr);
-    hipLaunchKernelGGL(k_linearize, dim3(h->max_blocks, h->n_pairs), dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0],
-                       h->d_cov[0], h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->d_corr, h->d_partial,
-                       h->max_blocks);
+    if (h->prm.voxel_res > 0.0) {
+        st = build_voxel_map(h, s);
+        if (st != MRS_OK) return st;
+        MRS_REQUIRE(d_corr == nullptr, "per-point correspondences are not defined for the voxelised variant");
+        hipLaunchKernelGGL(k_linearize_voxel, dim3(h->max_blocks, h->n_pairs), dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0],
+                           h->d_cov[0], h->d_vkeys, h->d_vmean, h->d_vcov, h->n_voxels, h->d_state, h->prm, h->d_partial,
+                           h->max_blocks);
+    } else {
+        hipLaunchKernelGGL(k_nn_scan, dim3(h->max_blocks, h->n_pairs), dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0],
+                           h->d_pts[1], h->d_offs[1], h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_state, h->prm, h->d_corr);
+        hipLaunchKernelGGL(k_linearize, dim3(h->max_blocks, h->n_pairs), dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0],
+                           h->d_cov[0], h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->d_corr, h->d_partial,
+                           h->max_blocks);
+    }
     if (d_corr)
         hipLaunchKernelGGL(k_corr_to_original, dim3(64, h->n_pairs), dim3(256), 0, s, h->d_pts[0], h->d_offs[0], h->d_pts[1],
                            h->d_offs[1], h->d_corr, d_corr);

@@ -25,7 +25,9 @@
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <numeric>
+#include <tuple>
 #include <vector>
 
 #ifdef _OPENMP
@@ -259,7 +261,80 @@ struct Gicp {
     double final_H[36];
     int converged = 0, iterations = 0;
     int lm_trials = 0;
+    // row G7: voxelised target (FastVGICP); 0 = plain GICP
+    double voxel_res = 0.0;
+    int voxel_neighbors = 1;
+    struct Voxel { double mean[3] = {0, 0, 0}; double cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; int n = 0; };
+    std::map<std::tuple<int, int, int>, Voxel> voxels;
+    double voxels_built_for = 0.0;
 };
+
+// Gaussian voxel map of the target (ADDITIVE accumulation): mean of the points, mean of their covariances
+void build_voxels(Gicp& g)
+{
+    if (g.voxels_built_for == g.voxel_res && !g.voxels.empty()) return;
+    g.voxels.clear();
+    for (int i = 0; i < g.tgt.n; ++i) {
+        const float* p = &g.tgt.pts[3 * (size_t)i];
+        auto key = std::make_tuple((int)std::floor((double)p[0] / g.voxel_res), (int)std::floor((double)p[1] / g.voxel_res),
+                                   (int)std::floor((double)p[2] / g.voxel_res));
+        Gicp::Voxel& v = g.voxels[key];
+        for (int a = 0; a < 3; ++a) v.mean[a] += (double)p[a];
+        for (int a = 0; a < 9; ++a) v.cov[a] += g.tgt.cov[9 * (size_t)i + a];
+        ++v.n;
+    }
+    for (auto& kv : g.voxels) {
+        for (int a = 0; a < 3; ++a) kv.second.mean[a] = (double)(float)(kv.second.mean[a] / kv.second.n);
+        for (int a = 0; a < 9; ++a) kv.second.cov[a] /= kv.second.n;
+    }
+    g.voxels_built_for = g.voxel_res;
+}
+
+// row G7 linearisation: every source point against the voxel containing its transformed position
+// (+ 6 / 26 neighbours), weight sqrt(points in the voxel)
+double linearize_voxel(Gicp& g, const double* T, double* H, double* b)
+{
+    build_voxels(g);
+    const double R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
+    double Hs[36] = {0}, bs[6] = {0}, err = 0;
+    for (int i = 0; i < g.src.n; ++i) {
+        const float* pa = &g.src.pts[3 * (size_t)i];
+        double ta[3];
+        for (int a = 0; a < 3; ++a) ta[a] = T[4 * a] * (double)pa[0] + T[4 * a + 1] * (double)pa[1] + T[4 * a + 2] * (double)pa[2] + T[4 * a + 3];
+        const int c[3] = {(int)std::floor(ta[0] / g.voxel_res), (int)std::floor(ta[1] / g.voxel_res), (int)std::floor(ta[2] / g.voxel_res)};
+        double RC[9], RCRa[9], Rt[9];
+        for (int a = 0; a < 3; ++a) for (int bb = 0; bb < 3; ++bb) Rt[3 * a + bb] = R[3 * bb + a];
+        mul3(R, &g.src.cov[9 * (size_t)i], RC);
+        mul3(RC, Rt, RCRa);
+        for (int o = 0; o < 27; ++o) {
+            const int dx = o % 3 - 1, dy = (o / 3) % 3 - 1, dz = o / 9 - 1;
+            const int man = std::abs(dx) + std::abs(dy) + std::abs(dz);
+            if ((g.voxel_neighbors == 1 && man != 0) || (g.voxel_neighbors == 7 && man > 1)) continue;
+            auto it = g.voxels.find(std::make_tuple(c[0] + dx, c[1] + dy, c[2] + dz));
+            if (it == g.voxels.end()) continue;
+            const Gicp::Voxel& v = it->second;
+            double RCR[9], M[9];
+            for (int a = 0; a < 9; ++a) RCR[a] = RCRa[a] + v.cov[a];
+            if (!inv3(RCR, M)) continue;
+            const double w = std::sqrt((double)v.n);
+            double e[3], Me[3];
+            for (int a = 0; a < 3; ++a) e[a] = v.mean[a] - ta[a];
+            for (int a = 0; a < 3; ++a) Me[a] = M[3 * a] * e[0] + M[3 * a + 1] * e[1] + M[3 * a + 2] * e[2];
+            err += w * (e[0] * Me[0] + e[1] * Me[1] + e[2] * Me[2]);
+            if (!H) continue;
+            double J[18] = {0, -ta[2], ta[1], -1, 0, 0, ta[2], 0, -ta[0], 0, -1, 0, -ta[1], ta[0], 0, 0, 0, -1};
+            double MJ[18];
+            for (int a = 0; a < 3; ++a)
+                for (int cc = 0; cc < 6; ++cc) MJ[6 * a + cc] = M[3 * a] * J[cc] + M[3 * a + 1] * J[6 + cc] + M[3 * a + 2] * J[12 + cc];
+            for (int r = 0; r < 6; ++r) {
+                for (int cc = 0; cc < 6; ++cc) Hs[6 * r + cc] += w * (J[r] * MJ[cc] + J[6 + r] * MJ[6 + cc] + J[12 + r] * MJ[12 + cc]);
+                bs[r] += w * (J[r] * Me[0] + J[6 + r] * Me[1] + J[12 + r] * Me[2]);
+            }
+        }
+    }
+    if (H) { std::memcpy(H, Hs, sizeof(Hs)); std::memcpy(b, bs, sizeof(bs)); }
+    return err;
+}
 
 void compute_covariances(Cloud& c, int k, int threads)
 {
@@ -317,8 +392,11 @@ void update_correspondences(Gicp& g, const double* T)
 }
 
 // linearize (H, b optional) -> sum of e^T M e
+double linearize_voxel(Gicp& g, const double* T, double* H, double* b);
+
 double linearize(Gicp& g, const double* T, double* H, double* b)
 {
+    if (g.voxel_res > 0.0) return linearize_voxel(g, T, H, b);
     update_correspondences(g, T);
     const int n = g.src.n;
     const int nt = g.threads;
@@ -428,7 +506,7 @@ static void set_cloud(Cloud& c, const float* xyz, int n)
     c.tree.build(c.pts.data(), n);
 }
 void orc_gicp_set_source(void* h, const float* xyz, int n) { set_cloud(static_cast<Gicp*>(h)->src, xyz, n); }
-void orc_gicp_set_target(void* h, const float* xyz, int n) { set_cloud(static_cast<Gicp*>(h)->tgt, xyz, n); }
+void orc_gicp_set_target(void* h, const float* xyz, int n) { set_cloud(static_cast<Gicp*>(h)->tgt, xyz, n); static_cast<Gicp*>(h)->voxels.clear(); }
 
 void orc_gicp_set_params(void* h, int k, double max_corr, int max_iter, double rot_eps, double trans_eps, int threads)
 {
@@ -436,6 +514,12 @@ void orc_gicp_set_params(void* h, int k, double max_corr, int max_iter, double r
     g->k = k; g->max_corr = max_corr; g->max_iter = max_iter; g->rot_eps = rot_eps; g->trans_eps = trans_eps;
     g->threads = threads > 0 ? threads : 1;
     g->src.cov.clear(); g->tgt.cov.clear();
+}
+
+void orc_gicp_set_voxel(void* h, double resolution, int neighbors)
+{
+    Gicp* g = static_cast<Gicp*>(h);
+    g->voxel_res = resolution; g->voxel_neighbors = neighbors; g->voxels.clear();
 }
 
 void orc_gicp_covariances(void* h, int which, double* out /* [n][9] or null */)

@@ -212,6 +212,10 @@ class Gicp:
         self._l.orc_gicp_set_params(self._h, int(k), C.c_double(max_corr), int(max_iter), C.c_double(rot_eps),
                                     C.c_double(trans_eps), int(threads))
 
+    def set_voxel(self, resolution, neighbors=1):
+        """row G7: voxelised target (FastVGICP); resolution 0 switches back to GICP."""
+        self._l.orc_gicp_set_voxel(self._h, C.c_double(resolution), int(neighbors))
+
     def set_source(self, pts):
         p = _f32(np.asarray(pts)[:, :3]); self._ns = p.shape[0]
         self._l.orc_gicp_set_source(self._h, _p(p), p.shape[0])

@@ -48,5 +48,22 @@ int main()
                 std::atan2(T(1, 0), T(0, 0)), fit);
     const bool ok = icp->hasConverged() && std::fabs(T(0, 3) - tx) < 5e-3 && std::fabs(T(1, 3) - ty) < 5e-3 &&
                     std::fabs(std::atan2(T(1, 0), T(0, 0)) - yaw) < 1e-3;
-    return ok ? 0 : 1;
+    // launch-file default: FAST_VGICP_CUDA (global_manager.cpp:2445-2455), started near the solution like ICPCheck does
+    auto vg = std::make_shared<fast_gicp::FastVGICPCuda<pcl::PointXYZI, pcl::PointXYZI>>();
+    vg->setResolution(0.5);
+    vg->setTransformationEpsilon(1e-3);
+    vg->setMaximumIterations(50);
+    vg->setCorrespondenceRandomness(15);
+    vg->setNeighborSearchMethod(fast_gicp::NeighborSearchMethod::DIRECT1, 1.5);
+    vg->setInputSource(src);
+    vg->setInputTarget(tgt);
+    Eigen::Matrix4f guess = Eigen::Matrix4f::Identity();
+    guess(0, 0) = std::cos(0.045f); guess(0, 1) = -std::sin(0.045f); guess(1, 0) = std::sin(0.045f); guess(1, 1) = std::cos(0.045f);
+    guess(0, 3) = 0.35f; guess(1, 3) = -0.15f;
+    vg->align(unused, guess);
+    const Eigen::Matrix4f V = vg->getFinalTransformation();
+    std::printf("vgicp converged=%d tx=%.4f ty=%.4f yaw=%.5f\n", (int)vg->hasConverged(), V(0, 3), V(1, 3), std::atan2(V(1, 0), V(0, 0)));
+    const bool okv = vg->hasConverged() && std::fabs(V(0, 3) - tx) < 2e-2 && std::fabs(V(1, 3) - ty) < 2e-2 &&
+                     std::fabs(std::atan2(V(1, 0), V(0, 0)) - yaw) < 3e-3;
+    return (ok && okv) ? 0 : 1;
 }

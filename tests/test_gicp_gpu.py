@@ -169,3 +169,30 @@ def test_full_size_pair(dev):
     f1 = b.fitness(T, 1.0)[0]
     dt, dr = _pose_err(T[0], Ttrue)
     assert conv[0] and dt < 5e-3 and dr < 5e-4 and f1 < f0
+
+
+@pytest.mark.parametrize("res,nb", [(0.5, 1), (0.5, 7), (1.0, 27)])
+def test_vgicp_matches_restatement(dev, oracle, res, nb):
+    """Row G7 (FastVGICP / FastVGICPCuda as configured at global_manager.cpp:2445-2455): voxelised target,
+    DIRECT1/7/27 correspondences; started near the solution like ICPCheck does."""
+    from mr_slam_amd import gicp
+    src, tgt, Ttrue = _pair(11, 15000)
+    guess = Ttrue.copy()
+    guess[:3, 3] += [0.08, -0.05, 0.02]
+    guess[:3, :3] = Rot.from_rotvec([0, 0, 0.01]).as_matrix() @ guess[:3, :3]
+    b = gicp.GicpBatch(1)
+    b.set_params(k_correspondences=15, max_iterations=50, transformation_epsilon=1e-3, voxel_resolution=res, voxel_neighbors=nb)
+    b.set_sources([src]); b.set_targets([tgt])
+    e, H, bb, _ = b.linearize(guess[None])
+    g = oracle.Gicp(k=15, max_corr=1e300, max_iter=50, trans_eps=1e-3)
+    g.set_voxel(res, nb)
+    g.set_source(src); g.set_target(tgt)
+    we, wH, wb, _ = g.linearize(guess)
+    assert abs(e[0] - we) < 1e-6 * abs(we)
+    np.testing.assert_allclose(H[0], wH, rtol=1e-6, atol=1e-6 * np.abs(wH).max())
+    np.testing.assert_allclose(bb[0], wb, rtol=1e-6, atol=1e-6 * np.abs(wb).max())
+    T, conv, its = b.align(guess[None])
+    wT, wconv, wits, _ = g.align(guess)
+    dt, dr = _pose_err(T[0], wT)
+    assert dt < TOL_T and dr < TOL_R and conv[0] == wconv
+    assert _pose_err(T[0], Ttrue)[0] < 1e-2
