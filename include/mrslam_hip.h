@@ -386,6 +386,46 @@ int mrs_disco_rel_ori_literal(mrs_ctx* ctx, const float* d_a, const float* d_b, 
 int mrs_signature_search(mrs_ctx* ctx, const float* d_query, int32_t n_query, const float* d_db, int32_t n_db, int32_t dim,
                          int32_t* d_index, float* d_dist2, mrs_stream stream);
 
+/* ------------------------------------------------------------------------------------
+ * Elevation mapping: the nine functions of the reference's libgpu.so
+ * (Mapping/src/elevation_mapping_periodical/elevation_mapping/cuda/gpu_process.cu:938-1312; declared by hand
+ * in elevation_mapping/src/ElevationMapping.cpp:44-50 and src/sensor_processors/SensorProcessorBase.cpp:34).
+ * Same argument meaning, host arrays in/out like the reference; Eigen arguments become plain floats
+ * (row-major 4x4 / 3x3, 3-vectors); the map state lives in a handle instead of __device__ globals.
+ * ---------------------------------------------------------------------------------- */
+typedef struct mrs_elev_map mrs_elev_map;
+
+/* Init_GPU_elevationmap(length, resolution, mahalanobisDistanceThreshold, obstacle_threshold) */
+int mrs_elev_create(mrs_ctx* ctx, int32_t length, float resolution, float mahalanobis_threshold, float obstacle_threshold,
+                    mrs_elev_map** out);
+int mrs_elev_destroy(mrs_elev_map* m);
+/* Move(current_Position[3], resolution, length, Central_coordinate[2], Start_indice[2], alignedPositionShift[2]) */
+int mrs_elev_move(mrs_elev_map* m, const float* h_position3, float* h_central2, int32_t* h_start2, float* h_aligned_shift2);
+/* Process_points(map_index, point_x/y/z (rejected -> -1), point_var, point_x/y/z_ts, transform, point_num, thresholds,
+ * sensor model, sensorJacobian, rotationVariance, C_SB_transpose, P_mul_C_BM_transpose, B_r_BS_skew) */
+int mrs_elev_process_points(mrs_elev_map* m, int32_t n, float* h_x, float* h_y, float* h_z, const float* h_transform16,
+                            double relative_lower_threshold, double relative_upper_threshold, float min_r, float beam_a,
+                            float beam_c, const float* h_sensorJacobian3, const float* h_rotationVariance9,
+                            const float* h_C_SB_transpose9, const float* h_P_mul_C_BM_transpose3, const float* h_B_r_BS_skew9,
+                            int32_t* h_map_index, float* h_var, float* h_x_ts, float* h_y_ts, float* h_z_ts);
+/* Fuse(length, point_num, point_index, colorR/G/B, intensity, height, var) */
+int mrs_elev_fuse(mrs_elev_map* m, int32_t n, const int32_t* h_index, const int32_t* h_colorR, const int32_t* h_colorG,
+                  const int32_t* h_colorB, const float* h_intensity, const float* h_height, const float* h_var);
+/* Mapvar_update(length, var_update) */
+int mrs_elev_mapvar_update(mrs_elev_map* m, float var_update);
+/* Map_feature(length, elevation, var, colorR/G/B, rough, slope, traver, intensity): float/int32 [length*length] each */
+int mrs_elev_map_feature(mrs_elev_map* m, float* h_elevation, float* h_var, int32_t* h_colorR, int32_t* h_colorG,
+                         int32_t* h_colorB, float* h_rough, float* h_slope, float* h_traver, float* h_intensity);
+/* Raytracing(length) */
+int mrs_elev_raytracing(mrs_elev_map* m);
+/* Map_optmove(opt_p[2], height_update, resolution, length, opt_alignedPosition[2]) */
+int mrs_elev_map_optmove(mrs_elev_map* m, const float* h_opt_p2, float height_update, float* h_aligned2);
+/* Map_closeloop(update_position[2], height_update, length, resolution) */
+int mrs_elev_map_closeloop(mrs_elev_map* m, const float* h_update_position2, float height_update);
+/* state readback for tests / debugging: which = 0 lowest, 1 elevation, 2 variance, 3 intensity, 4 traversability */
+int mrs_elev_get_layer(mrs_elev_map* m, int32_t which, float* h_out);
+int mrs_elev_get_frame(mrs_elev_map* m, float* h_central2, int32_t* h_start2);
+
 #ifdef __cplusplus
 }
 #endif

@@ -260,3 +260,73 @@ def se3_exp(a):
     T = np.empty((4, 4), np.float64)
     lib().orc_se3_exp(_p(a), _p(T))
     return T
+
+
+# ------------------------------------------------------------------------------ elevation map
+class ElevMap:
+    """ctypes handle on oracle/elev_oracle.cpp (sequential restatement of gpu_process.cu; unpinned)."""
+
+    def __init__(self, length, resolution, mahal=2.0, obstacle=0.6):
+        L = lib()
+        L.orc_elev_create.restype = C.c_void_p
+        self._l, self.L = L, int(length)
+        self._h = C.c_void_p(L.orc_elev_create(self.L, C.c_float(resolution), C.c_float(mahal), C.c_float(obstacle)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._l.orc_elev_destroy(self._h)
+
+    def move(self, pos3):
+        p = _f32(pos3); c = np.zeros(2, np.float32); s = np.zeros(2, np.int32); a = np.zeros(2, np.float32)
+        self._l.orc_elev_move(self._h, _p(p), _p(c), _p(s), _p(a))
+        return c, s, a
+
+    def process_points(self, x, y, z, T, lower, upper, min_r, beam_a, beam_c, sj, rv, csb, pmul, bskew):
+        x, y, z = _f32(x).copy(), _f32(y).copy(), _f32(z).copy()
+        n = x.size
+        mi = np.empty(n, np.int32)
+        var, xt, yt, zt = (np.empty(n, np.float32) for _ in range(4))
+        a = [_f32(T).reshape(16), _f32(sj).reshape(3), _f32(rv).reshape(9), _f32(csb).reshape(9), _f32(pmul).reshape(3), _f32(bskew).reshape(9)]
+        self._l.orc_elev_process_points(self._h, n, _p(x), _p(y), _p(z), _p(a[0]), C.c_double(lower), C.c_double(upper),
+                                        C.c_float(min_r), C.c_float(beam_a), C.c_float(beam_c), _p(a[1]), _p(a[2]), _p(a[3]),
+                                        _p(a[4]), _p(a[5]), _p(mi), _p(var), _p(xt), _p(yt), _p(zt))
+        return dict(map_index=mi, x=x, y=y, z=z, var=var, x_ts=xt, y_ts=yt, z_ts=zt)
+
+    def fuse(self, index, cr, cg, cb, inten, h, v):
+        arrs = [np.ascontiguousarray(index, np.int32), np.ascontiguousarray(cr, np.int32), np.ascontiguousarray(cg, np.int32),
+                np.ascontiguousarray(cb, np.int32), _f32(inten), _f32(h), _f32(v)]
+        self._l.orc_elev_fuse(self._h, arrs[0].size, *[_p(a) for a in arrs])
+
+    def mapvar_update(self, v):
+        self._l.orc_elev_mapvar_update(self._h, C.c_float(v))
+
+    def map_feature(self):
+        n = self.L * self.L
+        f = {k: np.zeros(n, np.float32) for k in ("elevation", "var", "rough", "slope", "traver", "intensity")}
+        f["traver"][:] = -10
+        c = {k: np.zeros(n, np.int32) for k in ("colorR", "colorG", "colorB")}
+        self._l.orc_elev_map_feature(self._h, _p(f["elevation"]), _p(f["var"]), _p(c["colorR"]), _p(c["colorG"]), _p(c["colorB"]),
+                                     _p(f["rough"]), _p(f["slope"]), _p(f["traver"]), _p(f["intensity"]))
+        f.update(c)
+        return f
+
+    def raytracing(self):
+        self._l.orc_elev_raytracing(self._h)
+
+    def map_optmove(self, p, dh):
+        a = np.zeros(2, np.float32)
+        self._l.orc_elev_map_optmove(self._h, _p(_f32(p)), C.c_float(dh), _p(a))
+        return a
+
+    def map_closeloop(self, p, dh):
+        self._l.orc_elev_map_closeloop(self._h, _p(_f32(p)), C.c_float(dh))
+
+    def layer(self, which):
+        out = np.empty(self.L * self.L, np.float32)
+        self._l.orc_elev_get(self._h, int(which), _p(out))
+        return out
+
+    def frame(self):
+        c = np.zeros(2, np.float32); s = np.zeros(2, np.int32)
+        self._l.orc_elev_get_frame(self._h, _p(c), _p(s))
+        return c, s
