@@ -257,10 +257,25 @@ __global__ __launch_bounds__(kWG) void k_cart_lds(const float* __restrict__ xyz,
     for (int i = threadIdx.x; i < cells; i += kWG) grid[i] = 0;
     __syncthreads();
 
+    // Only z > 0 can change this map (max_h starts at 0: manager.cu:57,69).  Common case in one test:
+    // 0 < z < 1 and 0 < |x|,|y| <= 1 (no zero substitution, no clamp, height layer 0) and both quotients
+    // at least eps away from a bin edge -> the fp32 quotient's floor IS the reference's double floor.
+    // Everything else (rare) takes the exact per-axis path of cart_lin().
+    const float eps = fmaxf(p.eps_x, p.eps_y);
+    const float inv_x = p.inv_x, inv_y = p.inv_y;
+    const int NY = p.NY;
     auto put = [&](float x, float y, float z) {
-        int col;
-        const int lin = cart_lin(p, x, y, z, col);
-        if (lin >= 0 && z > 0.0f) atomicMax(&grid[lin], __float_as_int(z));
+        const float gx = __builtin_fmaf(x, inv_x, inv_x), gy = __builtin_fmaf(y, inv_y, inv_y);
+        const float fx = floorf(gx), fy = floorf(gy);
+        const float ex = 0.5f - fabsf((gx - fx) - 0.5f), ey = 0.5f - fabsf((gy - fy) - 0.5f);  // distance to a bin edge
+        const bool fast = (bool)((int)(z > 0.0f) & (int)(z < 1.0f) & (int)(fmaxf(fabsf(x), fabsf(y)) <= 1.0f) & (int)(x * y != 0.0f) & (int)(fminf(ex, ey) >= eps));
+        if (fast) {
+            atomicMax(&grid[(int)fy + (int)fx * NY], __float_as_int(z));
+        } else if (z > 0.0f) {
+            int col;
+            const int lin = cart_lin(p, x, y, z, col);
+            if (lin >= 0) atomicMax(&grid[lin], __float_as_int(z));
+        }
     };
     int done = 0;
     if (aligned16(px) && aligned16(py) && aligned16(pz)) {
@@ -281,6 +296,17 @@ __global__ __launch_bounds__(kWG) void k_cart_lds(const float* __restrict__ xyz,
     for (int i = done + threadIdx.x; i < n; i += kWG) put(px[i], py[i], pz[i]);
     __syncthreads();
     float* dst = out + (size_t)b * cells;
+    if ((cells & 3) == 0) {  // 16-byte LDS reads and stores (dst is 16-byte aligned when cells % 4 == 0 and out is)
+        const int4* g4 = reinterpret_cast<const int4*>(grid);
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        if (aligned16(dst)) {
+            for (int i = threadIdx.x; i < (cells >> 2); i += kWG) {
+                const int4 v = g4[i];
+                d4[i] = make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+            }
+            return;
+        }
+    }
     for (int i = threadIdx.x; i < cells; i += kWG) dst[i] = __int_as_float(grid[i]);
 }
 
@@ -297,13 +323,57 @@ __global__ __launch_bounds__(kWG) void k_polar_lds(const float* __restrict__ xyz
     const float* py = px + n;
     const float* pz = py + n;
     const int cells = p.R * p.S * p.H;
-    const int words = (cells + 31) >> 5;
+    int wshift = 0;  // words = smallest power of two >= cells / 32: cell c -> word c & (words-1), bit c >> wshift
+    while ((32 << wshift) < cells) ++wshift;
+    const int words = 1 << wshift, wmask = words - 1;
     for (int i = threadIdx.x; i < words; i += kWG) bits[i] = 0u;
     __syncthreads();
 
+    // Common case in ONE test: no zero coordinate, and the ring / sector / height quotients all at least
+    // eps away from a bin edge (fp32 fast path == the reference's double path there); everything else
+    // (rare) re-evaluates exactly through polar_lin().
+    const float fR = (float)p.R, hmax = (float)(2 * p.H + 16);
     auto put = [&](float x, float y, float z) {
-        const int lin = polar_lin(p, x, y, z);
-        if (lin >= 0) atomicOr(&bits[lin >> 5], 1u << (lin & 31));
+        const float gr = __builtin_amdgcn_sqrtf(__builtin_fmaf(x, x, y * y)) * p.inv_ring;
+        const float fr = floorf(gr);
+        const float ax = fabsf(x), ay = fabsf(y);
+        const bool steep = ay > ax;
+        const float t = (steep ? ax : ay) * __builtin_amdgcn_rcpf(steep ? ay : ax);
+        float a = atan01(t) * 57.295779513f;
+        a = steep ? 90.0f - a : a;
+        const bool xn = x < 0.0f, yn = y < 0.0f;
+        const float base = xn ? 180.0f : (yn ? 360.0f : 0.0f);
+        const float theta = (xn != yn) ? base - a : base + a;
+        const float gs = theta * p.inv_sector;
+        const float fs = floorf(gs);
+        const float sh = z + p.mh;
+        float gh = sh * p.inv_height;
+        float fh = floorf(gh);
+        // height edge (ground returns sit right on the z = 0 bin edge after the reference's z > 0 crop): the
+        // reference quotient is a plain fp32 division -> redo just that, IEEE-rounded, instead of leaving the fast path
+        if (0.5f - fabsf((gh - fh) - 0.5f) < p.eps_height) {
+            gh = sh / p.gap_height;
+            fh = floorf(gh);
+        }
+        const float er = gr >= fR + 1.0f ? 1.0f : 0.5f - fabsf((gr - fr) - 0.5f);
+        const float es = 0.5f - fabsf((gs - fs) - 0.5f);
+        const bool fast = (bool)((int)(x * y * z != 0.0f) & (int)(fminf(er - p.eps_ring, es - p.eps_sector) >= 0.0f) &
+                                 (int)(gr < 5.0e8f) & (int)(fabsf(gh) < hmax));
+        int lin;
+        if (fast) {
+            const int kr = gr >= fR ? p.R - 1 : (int)fr;
+            lin = (int)fs + kr * p.S + (int)fh * (p.S * p.R);
+            if ((unsigned)lin >= (unsigned)cells) lin = -1;
+        } else {
+            lin = polar_lin(p, x, y, z);
+        }
+        if (lin >= 0) {
+            // bit of cell c lives in word c % words, position c / words: neighbouring cells (consecutive lidar
+            // returns) land in different words and banks instead of fighting over one dword
+            const int w = lin & wmask;
+            const unsigned m = 1u << (lin >> wshift);
+            if (!(bits[w] & m)) atomicOr(&bits[w], m);
+        }
     };
     int done = 0;
     if (aligned16(px) && aligned16(py) && aligned16(pz)) {
@@ -324,8 +394,21 @@ __global__ __launch_bounds__(kWG) void k_polar_lds(const float* __restrict__ xyz
     for (int i = done + threadIdx.x; i < n; i += kWG) put(px[i], py[i], pz[i]);
     __syncthreads();
     float* dst = out + (size_t)b * cells;
+    if ((cells & 3) == 0 && wshift >= 2 && aligned16(dst)) {
+        // cells 4j..4j+3 sit in four consecutive words at the same bit position: one 16-byte LDS read, one 16-byte store
+        const uint4* b4 = reinterpret_cast<const uint4*>(bits);
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        const int w4mask = wmask >> 2;
+        for (int j = threadIdx.x; j < (cells >> 2); j += kWG) {
+            const uint4 v = b4[j & w4mask];
+            const int sh = (4 * j) >> wshift;
+            d4[j] = make_float4((float)((v.x >> sh) & 1u), (float)((v.y >> sh) & 1u), (float)((v.z >> sh) & 1u),
+                                (float)((v.w >> sh) & 1u));
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < cells; i += kWG)
-        dst[i] = (bits[i >> 5] >> (i & 31)) & 1u ? 1.0f : 0.0f;
+        dst[i] = (bits[i & wmask] >> (i >> wshift)) & 1u ? 1.0f : 0.0f;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -575,7 +658,8 @@ int make_polar(mrs_ctx* ctx, const mrs_bev_cfg* c, PolarP& p)
     p.mh = (float)c->max_height;
     p.eps_ring = eps_for(p.R);
     p.eps_sector = eps_for(p.S);
-    p.eps_height = eps_for(2 * p.H + 16);
+    // |(z+mh)*inv - reference quotient| <= ~2.5e-7 * |quotient| (three fp32 roundings each side): 8x margin
+    p.eps_height = fmaxf(2e-5f, (float)(2 * p.H + 16) * 2e-6f);
     {
         std::lock_guard<std::mutex> g(ctx->mu);
         auto it = ctx->sector_luts.find(p.S);
@@ -686,7 +770,8 @@ int mrs_bev_polar_batch(mrs_ctx* ctx, const float* d_xyz, const int64_t* d_offse
     if (st != MRS_OK) return st;
     hipStream_t s = (hipStream_t)stream;
     const size_t cells = (size_t)p.R * p.S * p.H;
-    const size_t lds = ((cells + 31) / 32) * 4;
+    size_t lds = 4;
+    while (lds * 8 < cells) lds <<= 1;  // power-of-two bitset, see k_polar_lds
     if (layout == MRS_BEV_OUT_COMPACT && p.K == 1 && lds <= ctx->lds_bytes) {
         st = allow_lds(k_polar_lds, lds);
         if (st != MRS_OK) return st;
