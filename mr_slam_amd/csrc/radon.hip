@@ -14,6 +14,7 @@
 // Numerics are shared with oracle/radon_oracle.c op for op (cos/sin evaluated on the host in
 // double when the plan is built), so HIP == oracle bit for bit.
 #include <cmath>
+#include <vector>
 
 #include "common.hpp"
 
@@ -21,8 +22,7 @@ struct mrs_radon_plan {
     mrs_ctx* ctx = nullptr;
     int n_angles = 0, det = 0, H = 0, W = 0;
     float spacing = 1.0f;
-    float L = 0.0f;
-    float* d_cs = nullptr;  // [n_angles][2] = (cos, sin)
+    int* d_meta = nullptr;   // ray table, one allocation: meta | base | q | vm | n, each [n_angles*det]
 };
 
 namespace {
@@ -30,70 +30,43 @@ namespace {
 constexpr int kRadonWG = 960;  // 15 waves; 120x120 rays = 15 rays per lane exactly
 constexpr int kPad = 2;
 
+// The geometry of a ray does not depend on the image: it is evaluated once, on the host, when the
+// plan is built (fp32 op for op like forward.cu:32-112, cos/sin in double), and every workgroup
+// streams the table from L2 instead of redoing ~10 IEEE divisions per ray per image.
 struct RadonP {
     int A, D, H, W, stride;
-    float spacing, L;
-    const float* cs;
+    const int* meta;    // n_steps | ydom << 16  (n_steps == 0: the ray misses the image)
+    const int* base;    // LDS byte offset of the first sample's dominant-axis texel line
+    const float* q;     // minor-axis coordinate of the first sample, shifted by +1.5 (border + centre)
+    const float* vm;    // its increment per sample
+    const float* nrm;   // length of one step
 };
 
-// Sample loop of one ray.  line: LDS address of (dominant texel line, minor index 0); lstep: its
-// increment per sample; mc/vm: minor-axis coordinate and increment.  STRIDE > 0: compile-time row
-// stride.  Accumulation order is strictly sequential (matches the oracle bit for bit).
-template <bool YDOM, int STRIDE>
-__device__ __forceinline__ float march(const float* line, int lstep, float mc, float vm, int n_steps, int rstride)
-{
-    const int unit = YDOM ? 1 : (STRIDE > 0 ? STRIDE : rstride);  // distance between the two taps
-    float acc = 0.0f;
-    int j = 0;
-    for (; j + 4 <= n_steps; j += 4) {   // 4 samples in flight: addresses first, then the taps
-        float fr[4], t0[4], t1[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float mb = mc - 0.5f;
-            const float fl = floorf(mb);
-            fr[u] = mb - fl;
-            const float* q = line + (int)fl * unit;
-            t0[u] = q[0];
-            t1[u] = q[unit];
-            mc += vm;
-            line += lstep;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc += __builtin_fmaf(fr[u], t1[u] - t0[u], t0[u]);
-    }
-    for (; j < n_steps; ++j) {
-        const float mb = mc - 0.5f;
-        const float fl = floorf(mb);
-        const float* q = line + (int)fl * unit;
-        const float t0 = q[0], t1 = q[unit];
-        acc += __builtin_fmaf(mb - fl, t1 - t0, t0);
-        mc += vm;
-        line += lstep;
-    }
-    return acc;
-}
+struct HostRay {
+    int n_steps, ydom, major;
+    float q, vm, n;
+};
 
-// forward.cu:18-123 for one ray (a, r)
-template <int STRIDE>
-__device__ __forceinline__ float trace_ray(const float* img, const RadonP& p, int a, int r)
+// forward.cu:32-112 for one ray (a, r); samples are taken along INCREASING dominant-axis index
+// (a ray running the other way is entered at its last sample).
+HostRay ray_setup(int H, int W, float cs, float sn, int r, int det, float spacing, float L)
 {
-    const int stride = STRIDE > 0 ? STRIDE : p.stride;
-    const float cs = p.cs[2 * a], sn = p.cs[2 * a + 1];
-    const float sx = ((float)r - (float)p.D * 0.5f + 0.5f) * p.spacing;
-    const float sy = p.L, ex = sx, ey = -p.L;
+    HostRay o = {0, 0, 0, 0.0f, 0.0f, 0.0f};
+    const float sx = ((float)r - (float)det * 0.5f + 0.5f) * spacing;
+    const float sy = L, ex = sx, ey = -L;
     float rsx = sx * cs + sy * sn;
     float rsy = -sx * sn + sy * cs;
     float rdx = ex * cs + ey * sn - rsx;
     float rdy = -ex * sn + ey * cs - rsy;
-    rsx = rsx - (-0.5f * (float)p.W);
-    rsy = rsy - (-0.5f * (float)p.H);
+    rsx = rsx - (-0.5f * (float)W);
+    rsy = rsy - (-0.5f * (float)H);
     const float dx = rdx >= 0 ? fmaxf(rdx, 1e-6f) : fminf(rdx, -1e-6f);
     const float dy = rdy >= 0 ? fmaxf(rdy, 1e-6f) : fminf(rdy, -1e-6f);
-    const float axm = (-rsx) / dx, axp = ((float)p.W - rsx) / dx;
-    const float aym = (-rsy) / dy, ayp = ((float)p.H - rsy) / dy;
+    const float axm = (-rsx) / dx, axp = ((float)W - rsx) / dx;
+    const float aym = (-rsy) / dy, ayp = ((float)H - rsy) / dy;
     const float as = fmaxf(fminf(axp, axm), fminf(ayp, aym));
     const float ae = fminf(fmaxf(axp, axm), fmaxf(ayp, aym));
-    if ((double)as > (double)ae - 1e-6) return 0.0f;
+    if ((double)as > (double)ae - 1e-6) return o;
     rsx += rdx * as;
     rsy += rdy * as;
     rdx *= (ae - as);
@@ -101,9 +74,10 @@ __device__ __forceinline__ float trace_ray(const float* img, const RadonP& p, in
     const float m = fmaxf(fabsf(rdx), fabsf(rdy));
     const int n_steps = (int)rintf(m);
     const float vx = rdx / m, vy = rdy / m;
-    const float n = sqrtf(vx * vx + vy * vy);
+    o.n = sqrtf(vx * vx + vy * vy);
+    const bool ydom = fabsf(rdy) >= fabsf(rdx);
     float step;
-    if (fabsf(rdy) >= fabsf(rdx)) {
+    if (ydom) {
         const float inc = 0.5f - rsy + rintf(rsy);
         step = inc / vy;
         step += (vy < 0) ? 1.0f : 0.0f;
@@ -114,20 +88,97 @@ __device__ __forceinline__ float trace_ray(const float* img, const RadonP& p, in
     }
     rsx += step * vx;
     rsy += step * vy;
-    // dominant axis: integer texel line stepping by +-1; minor axis: cumulative float coordinate,
-    // 2-tap interpolation.  The two orientations get their own loop (wave-uniform branch except
-    // for the one wave in 15 that straddles the 45-degree switch) so that both taps come from one
-    // ds_read2_b32 and no per-sample integer multiply is needed.  Indices stay inside the 2-texel
-    // zero border: the alignment step is in [0,1] and n_steps = rint(length), so a ray overshoots
-    // its exit point by at most half a texel.
-    const bool ydom = fabsf(rdy) >= fabsf(rdx);
-    const int major = (int)floorf(ydom ? rsy : rsx);
-    const bool neg = (ydom ? vy : vx) < 0;
-    float acc = 0.0f;
-    if (ydom)
-        acc = march<true, STRIDE>(img + (major + kPad) * stride + kPad, neg ? -stride : stride, rsx, vx, n_steps, stride);
-    else
-        acc = march<false, STRIDE>(img + kPad * stride + (major + kPad), neg ? -1 : 1, rsy, vy, n_steps, stride);
+    o.ydom = ydom ? 1 : 0;
+    o.major = (int)floorf(ydom ? rsy : rsx);
+    o.q = (ydom ? rsx : rsy) + 1.5f;
+    o.vm = ydom ? vx : vy;
+    o.n_steps = n_steps;
+    if (n_steps > 0 && (ydom ? vy : vx) < 0) {
+        o.major -= n_steps - 1;
+        o.q = fmaf((float)(n_steps - 1), o.vm, o.q);
+        o.vm = -o.vm;
+    }
+    return o;
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// byte offset of minor index i: a shift when the minor axis is x, a full-rate 24-bit multiply (not the
+// quarter-rate v_mul_lo_u32) when it is y
+template <bool YDOM>
+__device__ __forceinline__ int minor_bytes(int i, int unit)
+{
+    return YDOM ? i * 4 : __mul24(i, unit);
+}
+
+typedef const __attribute__((address_space(3))) float* lds_fptr;
+typedef const __attribute__((address_space(3))) char* lds_cptr;
+
+__device__ __forceinline__ float lds_at(unsigned addr) { return *(lds_fptr)(uintptr_t)addr; }
+
+// Sample loop of one ray.  off: absolute LDS byte address of the first sample's texel line; the line
+// advances by one row (YDOM) / one column (!YDOM) per sample, the two taps sit one column / one row apart.
+// Per sample: q += vm, fract, cvt, address shift-add (or 24-bit mad), 1 - fr, one packed FMA
+// (t0,t1)*(1-fr,fr) -> two running sums; both taps in one ds_read2_b32 whose immediate offsets absorb
+// the line advance of the unrolled samples.  The chain of each running sum is strictly sequential
+// (matches the oracle bit for bit).
+template <bool YDOM, int STRIDE>
+__device__ __forceinline__ float march(unsigned off, float q, float vm, int n_steps, int rstride)
+{
+    const int stride = STRIDE > 0 ? STRIDE : rstride;
+    const int unit = (YDOM ? 1 : stride) * 4;   // bytes between the two taps == bytes per minor index
+    const int lstep = (YDOM ? stride : 1) * 4;  // bytes per sample along the dominant axis
+    constexpr int U = 6;  // samples in flight; ds_read2_b32 offsets are 8-bit dword counts (2*125+1 fits), so
+                          // the unrolled samples hang off two line addresses, three immediates each
+    v2f acc = {0.0f, 0.0f};
+    int j = 0;
+    unsigned off2 = off + 3 * lstep;
+#pragma nounroll
+    for (; j + U <= n_steps; j += U) {
+        v2f w[U], t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float fr = __builtin_amdgcn_fractf(q);
+            const unsigned a = (u < 3 ? off : off2) + (unsigned)minor_bytes<YDOM>((int)q, unit);
+            t[u].x = lds_at(a + (u % 3) * lstep);
+            t[u].y = lds_at(a + (u % 3) * lstep + unit);
+            w[u].x = 1.0f - fr;
+            w[u].y = fr;
+            q += vm;
+        }
+        off += U * lstep;
+        off2 += U * lstep;
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = __builtin_elementwise_fma(t[u], w[u], acc);
+    }
+    for (; j < n_steps; ++j) {
+        const float fr = __builtin_amdgcn_fractf(q);
+        const unsigned a = off + (unsigned)minor_bytes<YDOM>((int)q, unit);
+        v2f t, w;
+        t.x = lds_at(a);
+        t.y = lds_at(a + unit);
+        w.x = 1.0f - fr;
+        w.y = fr;
+        acc = __builtin_elementwise_fma(t, w, acc);
+        q += vm;
+        off += lstep;
+    }
+    return acc.x + acc.y;
+}
+
+template <int STRIDE>
+__device__ __forceinline__ float trace_ray(const float* img, const RadonP& p, int ray)
+{
+    const int meta = p.meta[ray];
+    const int n_steps = meta & 0xffff;
+    if (n_steps == 0) return 0.0f;
+    const int off = p.base[ray];
+    const float q = p.q[ray], vm = p.vm[ray], n = p.nrm[ray];
+    const unsigned tile = (unsigned)(uintptr_t)(lds_cptr)reinterpret_cast<const char*>(img) + (unsigned)off;
+    // the two orientations get their own loop (wave-uniform branch except for the one wave in 15 that
+    // straddles the 45-degree switch)
+    const float acc = (meta >> 16) ? march<true, STRIDE>(tile, q, vm, n_steps, p.stride)
+                                   : march<false, STRIDE>(tile, q, vm, n_steps, p.stride);
     return acc * n;
 }
 
@@ -166,8 +217,7 @@ __global__ __launch_bounds__(kRadonWG) void k_radon(const float* __restrict__ im
         const int ray = threadIdx.x + k * kRadonWG;
         float v = 0.0f;
         if (ray < rays) {
-            const int a = ray / p.D, r = ray - a * p.D;
-            v = trace_ray<STRIDE>(tile, p, a, r);
+            v = trace_ray<STRIDE>(tile, p, ray);
             if (sino_raw) sino_raw[(size_t)b * rays + ray] = v;
             s1 += (double)v;
         }
@@ -222,10 +272,8 @@ __global__ __launch_bounds__(kRadonWG) void k_radon_big(const float* __restrict_
     }
     __syncthreads();
     const int rays = p.A * p.D;
-    for (int ray = threadIdx.x; ray < rays; ray += kRadonWG) {
-        const int a = ray / p.D, r = ray - a * p.D;
-        sino_raw[(size_t)b * rays + ray] = trace_ray<0>(tile, p, a, r);
-    }
+    for (int ray = threadIdx.x; ray < rays; ray += kRadonWG)
+        sino_raw[(size_t)b * rays + ray] = trace_ray<0>(tile, p, ray);
 }
 
 // (x - mean) / std over `group` consecutive floats per block (unbiased std), in place or not.
@@ -277,20 +325,43 @@ int mrs_radon_plan_create(mrs_ctx* ctx, const float* h_angles, int32_t n_angles,
         return MRS_ERR_UNSUPPORTED;
     }
     MRS_HIP_TRY(hipSetDevice(ctx->device));
-    std::vector<float> cs(2 * (size_t)n_angles);
+    MRS_REQUIRE(height + width < 60000, "image too large for the 16-bit step count");
+    const size_t rays = (size_t)n_angles * det_count;
+    const float L = sqrtf((width * 0.5f) * (width * 0.5f) + (height * 0.5f) * (height * 0.5f));  // forward.cu:33
+    std::vector<int> tab(5 * rays);
+    int* meta = tab.data();
+    int* base = meta + rays;
+    float* q = reinterpret_cast<float*>(base + rays);
+    float* vm = q + rays;
+    float* nrm = vm + rays;
     for (int a = 0; a < n_angles; ++a) {
-        cs[2 * a] = (float)cos((double)h_angles[a]);
-        cs[2 * a + 1] = (float)sin((double)h_angles[a]);
+        const float cs = (float)cos((double)h_angles[a]);
+        const float sn = (float)sin((double)h_angles[a]);
+        for (int r = 0; r < det_count; ++r) {
+            const HostRay g = ray_setup(height, width, cs, sn, r, det_count, det_spacing, L);
+            const size_t k = (size_t)a * det_count + r;
+            meta[k] = g.n_steps | (g.ydom << 16);
+            base[k] = 4 * (g.ydom ? (g.major + kPad) * stride : g.major + kPad);
+            q[k] = g.q; vm[k] = g.vm; nrm[k] = g.n;
+            if (g.n_steps > 0) {  // every tap must stay inside the zero border
+                const int last = g.major + g.n_steps - 1, lim = g.ydom ? height : width, mlim = g.ydom ? width : height;
+                const float q_end = g.q + (float)(g.n_steps - 1) * g.vm;
+                if (g.major < -kPad || last >= lim + kPad || fminf(g.q, q_end) < 0.0f ||
+                    fmaxf(g.q, q_end) >= (float)(mlim + 2 * kPad - 1)) {
+                    mrs::set_error("Radon ray (%d,%d) leaves the %d-texel border", a, r, kPad);
+                    return MRS_ERR_UNSUPPORTED;
+                }
+            }
+        }
     }
     mrs_radon_plan* pl = new mrs_radon_plan();
     pl->ctx = ctx;
     pl->n_angles = n_angles; pl->det = det_count; pl->H = height; pl->W = width;
     pl->spacing = det_spacing;
-    pl->L = sqrtf((width * 0.5f) * (width * 0.5f) + (height * 0.5f) * (height * 0.5f));
-    if (hipMalloc(&pl->d_cs, cs.size() * sizeof(float)) != hipSuccess ||
-        hipMemcpy(pl->d_cs, cs.data(), cs.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
-        mrs::set_error("could not upload the angle table");
-        if (pl->d_cs) (void)hipFree(pl->d_cs);
+    if (hipMalloc(&pl->d_meta, tab.size() * sizeof(int)) != hipSuccess ||
+        hipMemcpy(pl->d_meta, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+        mrs::set_error("could not upload the ray table");
+        if (pl->d_meta) (void)hipFree(pl->d_meta);
         delete pl;
         return MRS_ERR_HIP;
     }
@@ -302,7 +373,7 @@ int mrs_radon_plan_destroy(mrs_radon_plan* plan)
 {
     if (!plan) return MRS_OK;
     (void)hipSetDevice(plan->ctx->device);
-    if (plan->d_cs) (void)hipFree(plan->d_cs);
+    if (plan->d_meta) (void)hipFree(plan->d_meta);
     delete plan;
     return MRS_OK;
 }
@@ -328,7 +399,12 @@ int mrs_radon_forward(mrs_radon_plan* plan, const float* d_img, int32_t batch, f
     RadonP p;
     p.A = plan->n_angles; p.D = plan->det; p.H = plan->H; p.W = plan->W;
     p.stride = (plan->W + 2 * kPad) | 1;
-    p.spacing = plan->spacing; p.L = plan->L; p.cs = plan->d_cs;
+    const size_t nr = (size_t)p.A * p.D;
+    p.meta = plan->d_meta;
+    p.base = plan->d_meta + nr;
+    p.q = reinterpret_cast<const float*>(plan->d_meta + 2 * nr);
+    p.vm = p.q + nr;
+    p.nrm = p.vm + nr;
     const size_t lds = (size_t)(p.H + 2 * kPad) * p.stride * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     const int rays = p.A * p.D;

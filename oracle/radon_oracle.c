@@ -18,6 +18,8 @@
  *     (1e-6, far below the texture unit's 1/256 weight resolution).  The alignment is made
  *     exact here: the dominant-axis texel index is an integer that steps by +-1, and each sample
  *     is a 2-tap linear interpolation along the minor axis.                [ref: 4-tap HW fetch]
+ *   - a ray is summed along increasing dominant-axis index, one fp32 running sum per tap
+ *     (t0*(1-fr) and t1*fr), added at the end                              [ref: one running sum]
  *   - hypot(a,b) -> sqrtf(a*a + b*b)                                        [ref: CUDA hypot]
  */
 #include <math.h>
@@ -29,17 +31,71 @@ static inline float orc_texel(const float *img, int W, int H, int i, int j)
     return (i < 0 || j < 0 || i >= W || j >= H) ? 0.0f : img[(size_t)j * W + i];
 }
 
-/* linear interpolation along the minor axis at minor coordinate m (texel centres at +0.5),
- * on the texel line `major` of the dominant axis; ydom selects which image axis is which */
-static inline float orc_tex1d(const float *img, int W, int H, int ydom, int major, float m)
+/* Geometry of one ray (forward.cu:32-112), independent of the image.  The samples of a ray are
+ * summed along INCREASING dominant-axis texel index (a ray that runs the other way is entered at
+ * its last sample: same sample set, the order of an fp32 sum is not part of the reference's
+ * contract -- the CUDA kernel itself tree-reduces nothing but accumulates in a hardware-dependent
+ * FMA order).  q is the minor-axis coordinate shifted by +1.5 (= -0.5 texel-centre offset + 2 border
+ * texels), which keeps it positive so that floor == truncation. */
+typedef struct {
+    int n_steps; /* 0: the ray misses the image */
+    int ydom;    /* dominant axis is y */
+    int major;   /* dominant-axis texel index of the first sample */
+    float q;     /* shifted minor-axis coordinate of the first sample */
+    float vm;    /* its increment per sample */
+    float n;     /* length of one step */
+} orc_ray;
+
+static orc_ray orc_ray_setup(int H, int W, float cs, float sn, int r, int det, float spacing, float L)
 {
-    const float mb = m - 0.5f;
-    const float fl = floorf(mb);
-    const float fr = mb - fl;
-    const int i = (int)fl;
-    const float t0 = ydom ? orc_texel(img, W, H, i, major) : orc_texel(img, W, H, major, i);
-    const float t1 = ydom ? orc_texel(img, W, H, i + 1, major) : orc_texel(img, W, H, major, i + 1);
-    return fmaf(fr, t1 - t0, t0);
+    orc_ray o = {0, 0, 0, 0.0f, 0.0f, 0.0f};
+    const float ox = -0.5f * (float)W, oy = -0.5f * (float)H;             /* forward.cu:56-57 */
+    const float sx = ((float)r - (float)det * 0.5f + 0.5f) * spacing;     /* forward.cu:32 */
+    const float sy = L, ex = sx, ey = -L;
+    float rsx = sx * cs + sy * sn;                                        /* forward.cu:50-53 */
+    float rsy = -sx * sn + sy * cs;
+    float rdx = ex * cs + ey * sn - rsx;
+    float rdy = -ex * sn + ey * cs - rsy;
+    rsx = rsx - ox;                                                       /* forward.cu:58-61, scale 1 */
+    rsy = rsy - oy;
+    const float dx = rdx >= 0 ? fmaxf(rdx, 1e-6f) : fminf(rdx, -1e-6f);
+    const float dy = rdy >= 0 ? fmaxf(rdy, 1e-6f) : fminf(rdy, -1e-6f);
+    const float axm = (-rsx) / dx, axp = ((float)W - rsx) / dx;
+    const float aym = (-rsy) / dy, ayp = ((float)H - rsy) / dy;
+    const float as = fmaxf(fminf(axp, axm), fminf(ayp, aym));
+    const float ae = fminf(fmaxf(axp, axm), fmaxf(ayp, aym));
+    if ((double)as > (double)ae - 1e-6) return o;                          /* forward.cu:75 */
+    rsx += rdx * as;
+    rsy += rdy * as;
+    rdx *= (ae - as);
+    rdy *= (ae - as);
+    const float m = fmaxf(fabsf(rdx), fabsf(rdy));
+    const int n_steps = (int)rintf(m);                                    /* __float2int_rn */
+    const float vx = rdx / m, vy = rdy / m;
+    o.n = sqrtf(vx * vx + vy * vy);
+    float step;
+    if (fabsf(rdy) >= fabsf(rdx)) {                                       /* forward.cu:100-112 */
+        const float inc = 0.5f - rsy + rintf(rsy);
+        step = inc / vy;
+        step += (vy < 0) ? 1.0f : 0.0f;
+    } else {
+        const float inc = 0.5f - rsx + rintf(rsx);
+        step = inc / vx;
+        step += (vx < 0) ? 1.0f : 0.0f;
+    }
+    rsx += step * vx;
+    rsy += step * vy;
+    o.ydom = fabsf(rdy) >= fabsf(rdx);
+    o.major = (int)floorf(o.ydom ? rsy : rsx);
+    o.q = (o.ydom ? rsx : rsy) + 1.5f;
+    o.vm = o.ydom ? vx : vy;
+    o.n_steps = n_steps;
+    if (n_steps > 0 && (o.ydom ? vy : vx) < 0) { /* enter at the last sample, walk back */
+        o.major -= n_steps - 1;
+        o.q = fmaf((float)(n_steps - 1), o.vm, o.q);
+        o.vm = -o.vm;
+    }
+    return o;
 }
 
 /* One sinogram: img [H][W] -> sino [n_angles][det].  Volume centre 0, voxel size 1
@@ -48,60 +104,27 @@ void orc_radon_parallel(const float *img, int H, int W, const float *angles, int
                         int det, float spacing, float *sino)
 {
     const float L = sqrtf((W * 0.5f) * (W * 0.5f) + (H * 0.5f) * (H * 0.5f)); /* forward.cu:33 */
-    const float ox = -0.5f * (float)W, oy = -0.5f * (float)H;                 /* forward.cu:56-57 */
     for (int a = 0; a < n_angles; ++a) {
         const float cs = (float)cos((double)angles[a]);
         const float sn = (float)sin((double)angles[a]);
         for (int r = 0; r < det; ++r) {
-            const float sx = ((float)r - (float)det * 0.5f + 0.5f) * spacing; /* forward.cu:32 */
-            const float sy = L, ex = sx, ey = -L;
-            float rsx = sx * cs + sy * sn;                                    /* forward.cu:50-53 */
-            float rsy = -sx * sn + sy * cs;
-            float rdx = ex * cs + ey * sn - rsx;
-            float rdy = -ex * sn + ey * cs - rsy;
-            rsx = rsx - ox;                                                   /* forward.cu:58-61, scale 1 */
-            rsy = rsy - oy;
-            const float dx = rdx >= 0 ? fmaxf(rdx, 1e-6f) : fminf(rdx, -1e-6f);
-            const float dy = rdy >= 0 ? fmaxf(rdy, 1e-6f) : fminf(rdy, -1e-6f);
-            const float axm = (-rsx) / dx, axp = ((float)W - rsx) / dx;
-            const float aym = (-rsy) / dy, ayp = ((float)H - rsy) / dy;
-            const float as = fmaxf(fminf(axp, axm), fminf(ayp, aym));
-            const float ae = fminf(fmaxf(axp, axm), fmaxf(ayp, aym));
-            float *dst = sino + (size_t)a * det + r;
-            if ((double)as > (double)ae - 1e-6) { *dst = 0.0f; continue; }     /* forward.cu:75 */
-            rsx += rdx * as;
-            rsy += rdy * as;
-            rdx *= (ae - as);
-            rdy *= (ae - as);
-            const float m = fmaxf(fabsf(rdx), fabsf(rdy));
-            const int n_steps = (int)rintf(m);                                /* __float2int_rn */
-            const float vx = rdx / m, vy = rdy / m;
-            const float n = sqrtf(vx * vx + vy * vy);
-            float step;
-            if (fabsf(rdy) >= fabsf(rdx)) {
-                const float inc = 0.5f - rsy + rintf(rsy);
-                step = inc / vy;
-                step += (vy < 0) ? 1.0f : 0.0f;
-            } else {
-                const float inc = 0.5f - rsx + rintf(rsx);
-                step = inc / vx;
-                step += (vx < 0) ? 1.0f : 0.0f;
+            const orc_ray g = orc_ray_setup(H, W, cs, sn, r, det, spacing, L);
+            /* dominant axis: integer texel line stepping by +1; minor axis: cumulative float, 2-tap
+             * interpolation  t0*(1-fr) + t1*fr  with one running sum per tap */
+            float q = g.q, a0 = 0.0f, a1 = 0.0f;
+            int major = g.major;
+            for (int j = 0; j < g.n_steps; ++j) {
+                const float fl = floorf(q);
+                const float fr = q - fl;
+                const int i = (int)fl - 2;
+                const float t0 = g.ydom ? orc_texel(img, W, H, i, major) : orc_texel(img, W, H, major, i);
+                const float t1 = g.ydom ? orc_texel(img, W, H, i + 1, major) : orc_texel(img, W, H, major, i + 1);
+                a0 = fmaf(t0, 1.0f - fr, a0);
+                a1 = fmaf(t1, fr, a1);
+                q += g.vm;
+                major += 1;
             }
-            rsx += step * vx;
-            rsy += step * vy;
-            /* dominant axis: integer texel line stepping by +-1; minor axis: cumulative float */
-            const int ydom = fabsf(rdy) >= fabsf(rdx);
-            int major = (int)floorf(ydom ? rsy : rsx);
-            const int mstep = (ydom ? vy : vx) < 0 ? -1 : 1;
-            float mc = ydom ? rsx : rsy;      /* minor-axis coordinate */
-            const float vm = ydom ? vx : vy;
-            float acc = 0.0f;
-            for (int j = 0; j < n_steps; ++j) {
-                acc += orc_tex1d(img, W, H, ydom, major, mc);
-                mc += vm;
-                major += mstep;
-            }
-            *dst = acc * n;
+            sino[(size_t)a * det + r] = (a0 + a1) * g.n;
         }
     }
 }

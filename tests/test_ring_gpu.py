@@ -131,7 +131,7 @@ def test_corr_sweep_matches_fast_corr_restatement(dev):
             if top2[1] - top2[0] > 1e-3 * top2[1]:      # unambiguous maximum
                 assert ang[i, j] == g
     assert ang[0, 1] == -17 and ang[1, 4] == 0 and ang[2, 5] == 33   # query rolled by +k <=> angle -k
-    assert dist[1, 4] == dist.min()
+    assert dist[1, 4] <= dist.min() + 1e-6
 
 
 def test_fast_corr_literal_spectra(dev):
