@@ -55,3 +55,27 @@ def loopinfo_line(robot_cur, idx_cur, robot_cand, idx_cand, position, quaternion
     """One line of ./loopinfo.txt (main_RING.py:229-233)."""
     vals = [robot_cur, idx_cur, robot_cand, idx_cand, *position, *quaternion_xyzw]
     return " ".join(str(v) for v in vals)
+
+
+# ---- NCLT velodyne_sync record format (disco_ros/loading_pointclouds.py:27-68) ----
+def decode_nclt(buf):
+    """Raw NCLT hits: 8-byte records <HHHBB (x, y, z in 5 mm steps offset -100 m, intensity, laser).
+    Returns (xyz float64 [n,3] metres, intensity uint8 [n], laser uint8 [n])."""
+    rec = np.frombuffer(buf, dtype=np.dtype([("x", "<u2"), ("y", "<u2"), ("z", "<u2"), ("i", "u1"), ("l", "u1")]))
+    xyz = np.stack([rec["x"], rec["y"], rec["z"]], axis=1).astype(np.float64) * 0.005 + (-100.0)
+    return xyz, rec["i"].copy(), rec["l"].copy()
+
+
+def load_lidar_file_nclt(path_or_bytes):
+    """loading_pointclouds.py:38-68: crop |x|,|y| < 70, -20 < z < -2, drop the 5 m box around the sensor,
+    scale by 70/70/20 and flip z.  Returns float64 [n,3] in acquisition order."""
+    if isinstance(path_or_bytes, (bytes, bytearray, memoryview)):
+        xyz, _, _ = decode_nclt(path_or_bytes)
+    else:
+        with open(path_or_bytes, "rb") as f:
+            xyz, _, _ = decode_nclt(f.read())
+    x, y, z = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    keep = (np.abs(x) < 70.0) & (z > -20.0) & (z < -2.0) & (np.abs(y) < 70.0) & ~((np.abs(x) < 5.0) & (np.abs(y) < 5.0))
+    hits = np.stack([x[keep] / 70.0, y[keep] / 70.0, z[keep] / 20.0], axis=1)
+    hits[:, 2] = -hits[:, 2]
+    return hits

@@ -104,3 +104,34 @@ def test_feat_oracle_is_true_max(oracle):
     for j in range(F):
         np.maximum.at(ref[:, j], cell, np.maximum(pts[j], 0))
     np.testing.assert_array_equal(out, ref)
+
+
+NCLT_LAYOUTS = ((40, 120, 1), (40, 120, 20), (120, 120, 1))
+
+
+def nclt_bytes(g):
+    """Re-assemble the NCLT record stream (<HHHBB) from the golden's columns."""
+    rec = np.zeros(g["raw_u16"].shape[0], dtype=np.dtype([("x", "<u2"), ("y", "<u2"), ("z", "<u2"), ("i", "u1"), ("l", "u1")]))
+    rec["x"], rec["y"], rec["z"] = g["raw_u16"].T
+    rec["i"], rec["l"] = g["intensity"], g["laser"]
+    return rec.tobytes()
+
+
+def test_nclt_scan_reference_golden(oracle, golden_dir):
+    """BASELINE configs[0] input: the one real scan in the reference tree (disco_ros/test.bin), decoded by the
+    host helper, rasterised by the C restatement, against the reference CPU rasteriser's output."""
+    from mr_slam_amd import preprocess
+    g = np.load(os.path.join(golden_dir, "nclt_scan.npz"))
+    hits = preprocess.load_lidar_file_nclt(nclt_bytes(g))
+    np.testing.assert_array_equal(hits, g["hits"])           # loading_pointclouds.py:38-68, record by record
+    soa = hits.transpose().flatten().astype(np.float32)      # load_pc_file_infer: loading_pointclouds.py:76
+    for (R, S, H) in NCLT_LAYOUTS:
+        tag = f"{R}x{S}x{H}"
+        ring, sector, height, valid = oracle.bev_polar_indices(soa, 1, 1, R, S, H)
+        assert valid.all()
+        np.testing.assert_array_equal(ring, g[f"ring_{tag}"])
+        np.testing.assert_array_equal(sector, g[f"sector_{tag}"])
+        np.testing.assert_array_equal(height, g[f"height_{tag}"])
+        out = oracle.bev_polar(soa, 1, 1, R, S, H, 1)
+        np.testing.assert_array_equal(np.flatnonzero(out.reshape(-1, 3)[:, 2]).astype(np.int32), g[f"occupied_{tag}"])
+        assert oracle.occupied_fingerprint(out)[0] == int(g[f"fingerprint_{tag}"][0])
