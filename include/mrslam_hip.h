@@ -349,6 +349,18 @@ int mrs_ring_corr_fft_sweep(mrs_ctx* ctx, const float* d_query_spec, int32_t n_q
 int mrs_ring_corr_fft_pairs(mrs_ctx* ctx, const float* d_a_spec, const float* d_b_spec, int32_t n_pairs,
                             float* d_dist, int32_t* d_angle, float* d_corr, mrs_stream stream);
 
+/* fp16 replica format (multi-GPU exchange): every descriptor has to reach every GPU, and at
+ * >1 M descriptors/s/GPU the fp32 half spectrum (58 560 B) exceeds what the xGMI links carry.  A rank keeps its
+ * own descriptors in fp32 (exact scoring) and ships round-to-nearest fp16 copies (29 280 B) to the others, which
+ * sweep them with the same kernel (fp32 arithmetic; |dist - fp32 dist| < 2e-3).  The reference has no multi-GPU
+ * path; this is the RCCL all-gather format, not a change of the single-GPU results.
+ * mrs_ring_half_spectrum_f16: like mrs_ring_half_spectrum, with either output optional (not both null);
+ * d_half_spec_f16 = IEEE binary16 pairs [n_img][61][120][2]. */
+int mrs_ring_half_spectrum_f16(mrs_ctx* ctx, const float* d_norm_sino, int32_t n_img, int32_t n_angles, int32_t det,
+                               float* d_half_spec, void* d_half_spec_f16, mrs_stream stream);
+int mrs_ring_corr_fft_sweep_f16(mrs_ctx* ctx, const float* d_query_spec, int32_t n_query, const void* d_db_spec_f16,
+                                int32_t n_db, float* d_dist, int32_t* d_angle, float* d_corr, mrs_stream stream);
+
 /* ------------------------------------------------------------------------------------
  * Scan pre-processing
  * ---------------------------------------------------------------------------------- */

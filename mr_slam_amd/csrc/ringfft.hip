@@ -13,6 +13,8 @@
 // ~0.3 MFLOP and 58.56 KB per pair -> HBM-bound by design (5 flop/byte vs 26 flop/byte machine balance).
 #include <cmath>
 
+#include <hip/hip_fp16.h>
+
 #include "common.hpp"
 #include "fft_codelets.hpp"
 
@@ -98,7 +100,9 @@ __device__ __forceinline__ void rfft120(float (&re)[60], float (&im)[60], Store 
 }
 
 // R2: half spectrum (ortho) of normalised sinograms.  grid = images, 128 lanes (120 columns).
-__global__ __launch_bounds__(kSlotThreads) void k_ring_half_spectrum(const float* __restrict__ x, float2* __restrict__ out)
+// out16 (optional): the same values rounded to nearest-even fp16 = the exchange / replica format (29 280 B)
+__global__ __launch_bounds__(kSlotThreads) void k_ring_half_spectrum(const float* __restrict__ x, float2* __restrict__ out,
+                                                                     __half2* __restrict__ out16)
 {
     const int d = min((int)threadIdx.x, kD - 1);
     const float* src = x + (size_t)blockIdx.x * kA * kD + d;
@@ -110,9 +114,12 @@ __global__ __launch_bounds__(kSlotThreads) void k_ring_half_spectrum(const float
     }
     const bool live = threadIdx.x < kD;
     const float sc = 0.09128709291752769f;  // 1/sqrt(120)
-    float2* dst = out + (size_t)blockIdx.x * kHalf * kD + d;
+    const size_t o = (size_t)blockIdx.x * kHalf * kD + d;
     rfft120(re, im, [&](int k, float xr, float xi) {
-        if (live) dst[k * kD] = make_float2(xr * sc, xi * sc);
+        if (!live) return;
+        const float2 v = make_float2(xr * sc, xi * sc);
+        if (out) out[o + k * kD] = v;
+        if (out16) out16[o + k * kD] = __floats2half2_rn(v.x, v.y);
     });
 }
 
@@ -157,8 +164,12 @@ struct FftCorrP {
 };
 
 // grid = (blocks, nq); NSLOT pair streams of 128 lanes share the LDS-resident query spectrum.
-template <int NSLOT, bool PAIRWISE>
-__global__ __launch_bounds__(NSLOT* kSlotThreads) void k_ring_corr_fft(const float2* __restrict__ Q, const float2* __restrict__ DB,
+__device__ __forceinline__ float2 load_spec(const float2* p) { return *p; }
+__device__ __forceinline__ float2 load_spec(const __half2* p) { return __half22float2(*p); }
+
+// DBT = float2 (the database format) or __half2 (fp16 replicas received from other ranks)
+template <int NSLOT, bool PAIRWISE, typename DBT>
+__global__ __launch_bounds__(NSLOT* kSlotThreads) void k_ring_corr_fft(const float2* __restrict__ Q, const DBT* __restrict__ DB,
                                                                        FftCorrP p, float* __restrict__ dist,
                                                                        int* __restrict__ angle, float* __restrict__ corr_out)
 {
@@ -183,9 +194,9 @@ __global__ __launch_bounds__(NSLOT* kSlotThreads) void k_ring_corr_fft(const flo
         const bool live = cand < ncand;
         float re[60], im[60];
         if (live) {
-            const float2* b = DB + ((size_t)(PAIRWISE ? q : cand) * kHalf) * kD + d;
+            const DBT* b = DB + ((size_t)(PAIRWISE ? q : cand) * kHalf) * kD + d;
             corr_irfft120([&](int k, float& ar, float& ai, float& br, float& bi) {
-                const float2 bv = b[k * kD];
+                const float2 bv = load_spec(b + k * kD);
                 const float2 av = PAIRWISE ? qsrc[k * kD + d] : qs[k * kD + d];
                 ar = av.x; ai = av.y; br = bv.x; bi = bv.y;
             }, re, im);
@@ -229,10 +240,10 @@ __global__ __launch_bounds__(NSLOT* kSlotThreads) void k_ring_corr_fft(const flo
 
 extern "C" {
 
-int mrs_ring_half_spectrum(mrs_ctx* ctx, const float* d_norm_sino, int32_t n_img, int32_t n_angles, int32_t det,
-                           float* d_half_spec, mrs_stream stream)
+static int half_spectrum_launch(mrs_ctx* ctx, const float* d_norm_sino, int32_t n_img, int32_t n_angles, int32_t det,
+                                float* d_half_spec, void* d_half_spec_f16, mrs_stream stream)
 {
-    MRS_REQUIRE(ctx && d_norm_sino && d_half_spec, "null pointer");
+    MRS_REQUIRE(ctx && d_norm_sino && (d_half_spec || d_half_spec_f16), "null pointer");
     MRS_REQUIRE(n_img > 0, "n_img must be positive");
     if (n_angles != kA || det != kD) {
         mrs::set_error("ring_half_spectrum is specialised for 120 x 120 (got %d x %d)", n_angles, det);
@@ -240,12 +251,27 @@ int mrs_ring_half_spectrum(mrs_ctx* ctx, const float* d_norm_sino, int32_t n_img
     }
     MRS_HIP_TRY(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_ring_half_spectrum, dim3(n_img), dim3(kSlotThreads), 0, (hipStream_t)stream, d_norm_sino,
-                       reinterpret_cast<float2*>(d_half_spec));
+                       reinterpret_cast<float2*>(d_half_spec), reinterpret_cast<__half2*>(d_half_spec_f16));
     MRS_HIP_TRY(hipGetLastError());
     return MRS_OK;
 }
 
-static int corr_fft_launch(mrs_ctx* ctx, const float* d_q, int32_t n_q, const float* d_db, int32_t n_db, float* d_dist,
+int mrs_ring_half_spectrum(mrs_ctx* ctx, const float* d_norm_sino, int32_t n_img, int32_t n_angles, int32_t det,
+                           float* d_half_spec, mrs_stream stream)
+{
+    MRS_REQUIRE(d_half_spec, "null pointer");
+    return half_spectrum_launch(ctx, d_norm_sino, n_img, n_angles, det, d_half_spec, nullptr, stream);
+}
+
+int mrs_ring_half_spectrum_f16(mrs_ctx* ctx, const float* d_norm_sino, int32_t n_img, int32_t n_angles, int32_t det,
+                               float* d_half_spec, void* d_half_spec_f16, mrs_stream stream)
+{
+    return half_spectrum_launch(ctx, d_norm_sino, n_img, n_angles, det, d_half_spec, d_half_spec_f16, stream);
+}
+
+extern "C++" {
+template <typename DBT>
+static int corr_fft_launch(mrs_ctx* ctx, const float* d_q, int32_t n_q, const void* d_db, int32_t n_db, float* d_dist,
                            int32_t* d_angle, float* d_corr, mrs_stream stream, bool pairwise)
 {
     MRS_REQUIRE(ctx && d_q && d_db && d_dist && d_angle, "null pointer");
@@ -257,12 +283,12 @@ static int corr_fft_launch(mrs_ctx* ctx, const float* d_q, int32_t n_q, const fl
     constexpr int NSLOT = 2;
     hipStream_t s = (hipStream_t)stream;
     const float2* q2 = reinterpret_cast<const float2*>(d_q);
-    const float2* db2 = reinterpret_cast<const float2*>(d_db);
+    const DBT* db2 = reinterpret_cast<const DBT*>(d_db);
     if (pairwise) {
-        hipLaunchKernelGGL((k_ring_corr_fft<1, true>), dim3(1, n_q), dim3(kSlotThreads), 0, s, q2, db2, p, d_dist, d_angle, d_corr);
+        hipLaunchKernelGGL((k_ring_corr_fft<1, true, DBT>), dim3(1, n_q), dim3(kSlotThreads), 0, s, q2, db2, p, d_dist, d_angle, d_corr);
     } else {
         const size_t lds = (size_t)kHalf * kD * sizeof(float2);
-        auto kern = k_ring_corr_fft<NSLOT, false>;
+        auto kern = k_ring_corr_fft<NSLOT, false, DBT>;
         MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int blocks = 2 * (ctx->num_cu > 0 ? ctx->num_cu : 256);
         if (n_q > 1) blocks = (blocks + n_q - 1) / n_q;
@@ -275,16 +301,24 @@ static int corr_fft_launch(mrs_ctx* ctx, const float* d_q, int32_t n_q, const fl
     return MRS_OK;
 }
 
+}  // extern "C++"
+
 int mrs_ring_corr_fft_sweep(mrs_ctx* ctx, const float* d_query_spec, int32_t n_query, const float* d_db_spec,
                             int32_t n_db, float* d_dist, int32_t* d_angle, float* d_corr, mrs_stream stream)
 {
-    return corr_fft_launch(ctx, d_query_spec, n_query, d_db_spec, n_db, d_dist, d_angle, d_corr, stream, false);
+    return corr_fft_launch<float2>(ctx, d_query_spec, n_query, d_db_spec, n_db, d_dist, d_angle, d_corr, stream, false);
+}
+
+int mrs_ring_corr_fft_sweep_f16(mrs_ctx* ctx, const float* d_query_spec, int32_t n_query, const void* d_db_spec_f16,
+                                int32_t n_db, float* d_dist, int32_t* d_angle, float* d_corr, mrs_stream stream)
+{
+    return corr_fft_launch<__half2>(ctx, d_query_spec, n_query, d_db_spec_f16, n_db, d_dist, d_angle, d_corr, stream, false);
 }
 
 int mrs_ring_corr_fft_pairs(mrs_ctx* ctx, const float* d_a_spec, const float* d_b_spec, int32_t n_pairs, float* d_dist,
                             int32_t* d_angle, float* d_corr, mrs_stream stream)
 {
-    return corr_fft_launch(ctx, d_a_spec, n_pairs, d_b_spec, n_pairs, d_dist, d_angle, d_corr, stream, true);
+    return corr_fft_launch<float2>(ctx, d_a_spec, n_pairs, d_b_spec, n_pairs, d_dist, d_angle, d_corr, stream, true);
 }
 
 }  // extern "C"

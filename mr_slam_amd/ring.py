@@ -274,17 +274,38 @@ def half_spectrum(norm):
     return torch.view_as_complex(out)
 
 
+def half_spectrum_f16(norm, want_f32=True):
+    """half_spectrum plus its fp16 replica [..., 61, 120, 2] float16 (the multi-GPU exchange format).
+    Returns (spec complex64 | None, spec16 float16)."""
+    d = _dev(norm)
+    x = norm.contiguous()
+    A, D = x.shape[-2:]
+    n = x.numel() // (A * D)
+    shape = x.shape[:-2] + (A // 2 + 1, D, 2)
+    out = torch.empty(shape, dtype=torch.float32, device=x.device) if want_f32 else None
+    out16 = torch.empty(shape, dtype=torch.float16, device=x.device)
+    _lib.check(_lib.load().mrs_ring_half_spectrum_f16(_lib.ctx(d), _lib.ptr(x), n, A, D, _lib.ptr(out) if want_f32 else None,
+                                                      _lib.ptr(out16), _lib.current_stream(d)))
+    return (torch.view_as_complex(out) if want_f32 else None), out16
+
+
 def corr_sweep_fft(query_spec, db_spec, want_corr=False):
-    """C1 sweep on half spectra: query_spec [Q,61,120], db_spec [N,61,120] complex64 (device)."""
+    """C1 sweep on half spectra: query_spec [Q,61,120] complex64, db_spec [N,61,120] complex64 or its fp16
+    replica [N,61,120,2] float16 (device)."""
     d = _dev(query_spec)
     q, db = query_spec.contiguous(), db_spec.contiguous()
     Q, N = q.shape[0], db.shape[0]
     dist = torch.empty((Q, N), dtype=torch.float32, device=q.device)
     ang = torch.empty((Q, N), dtype=torch.int32, device=q.device)
     corr = torch.empty((Q, N, 120), dtype=torch.float32, device=q.device) if want_corr else None
-    _lib.check(_lib.load().mrs_ring_corr_fft_sweep(_lib.ctx(d), _lib.ptr(torch.view_as_real(q)), Q,
-                                                   _lib.ptr(torch.view_as_real(db)), N, _lib.ptr(dist), _lib.ptr(ang),
-                                                   _lib.ptr(corr) if want_corr else None, _lib.current_stream(d)))
+    if db.dtype == torch.float16:
+        assert db.shape[1:] == (61, 120, 2)
+        fn, dbp = _lib.load().mrs_ring_corr_fft_sweep_f16, _lib.ptr(db)
+    else:
+        assert db.dtype == torch.complex64
+        fn, dbp = _lib.load().mrs_ring_corr_fft_sweep, _lib.ptr(torch.view_as_real(db))
+    _lib.check(fn(_lib.ctx(d), _lib.ptr(torch.view_as_real(q)), Q, dbp, N, _lib.ptr(dist), _lib.ptr(ang),
+                  _lib.ptr(corr) if want_corr else None, _lib.current_stream(d)))
     return (dist, ang, corr) if want_corr else (dist, ang)
 
 

@@ -236,3 +236,30 @@ def test_fft_domain_sweep_matches_reference_and_direct_kernel(dev):
     dp, ap = ring.corr_pairs_fft(sq, sdb[[2, 5, 6]])
     assert np.array_equal(ap.cpu().numpy(), [-21, 0, 7])
     assert np.abs(dp.cpu().numpy() - dist[[0, 1, 2], [2, 5, 6]]).max() < 1e-6
+
+
+def test_fp16_replica_format(dev):
+    """Multi-GPU exchange format: fp16 copies of the half spectra are exactly the rounded fp32 ones, and a
+    sweep over replicas agrees with the fp32 sweep (dist within 2e-3, same angle where the peak is clear)."""
+    import torch
+    from mr_slam_amd import ring
+    db = _ring_db(9, 21)
+    q = np.stack([np.roll(db[2], 21, axis=1), db[5], np.roll(db[8], -40, axis=1)])
+    tq, tdb = torch.from_numpy(q).to(dev), torch.from_numpy(db).to(dev)
+    sq = ring.half_spectrum(tq[:, 0])
+    sdb, sdb16 = ring.half_spectrum_f16(tdb[:, 0])
+    assert sdb16.dtype == torch.float16 and sdb16.shape == (9, 61, 120, 2)
+    assert torch.equal(sdb, ring.half_spectrum(tdb[:, 0]))
+    assert torch.equal(sdb16, torch.view_as_real(sdb).to(torch.float16))       # round-to-nearest-even
+    only16 = ring.half_spectrum_f16(tdb[:, 0], want_f32=False)
+    assert only16[0] is None and torch.equal(only16[1], sdb16)
+    d32, a32, c32 = ring.corr_sweep_fft(sq, sdb, want_corr=True)
+    d16, a16, c16 = ring.corr_sweep_fft(sq, sdb16, want_corr=True)
+    assert float((d16 - d32).abs().max()) < 2e-3
+    np.testing.assert_allclose(c16.cpu().numpy(), c32.cpu().numpy(), rtol=2e-3, atol=0.2)
+    c = c32.cpu().numpy()
+    top2 = np.sort(c, axis=-1)[..., -2:]
+    clear = (top2[..., 1] - top2[..., 0]) > 1e-2 * top2[..., 1]
+    assert clear.sum() >= 3
+    assert np.array_equal(a16.cpu().numpy()[clear], a32.cpu().numpy()[clear])
+    assert a16[0, 2] == -21 and a16[1, 5] == 0 and a16[2, 8] == 40

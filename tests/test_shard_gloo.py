@@ -34,6 +34,9 @@ def _worker(rank, world, port, out_dir):
     local = torch.from_numpy(db[lo:hi])
     full = shard.allgather_ragged(local)
     assert torch.equal(full, torch.from_numpy(db))
+    # the exchange format of the GPU path: fp16 replicas travel, the owner keeps fp32
+    rep = shard.allgather_ragged(local.to(torch.float16))
+    assert rep.dtype == torch.float16 and torch.equal(rep, torch.from_numpy(db).to(torch.float16))
 
     def sweep(qq, dd):                                  # CPU stand-in for ring.corr_sweep (the checker)
         D = torch.zeros((qq.shape[0], dd.shape[0])); A = torch.zeros((qq.shape[0], dd.shape[0]), dtype=torch.int32)
