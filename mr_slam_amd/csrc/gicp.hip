@@ -94,11 +94,15 @@ struct TileBoxes {
     int ntiles;
 };
 
+constexpr int kSub = 128;                 // candidates per sub-tile (wave-level culling granularity inside a staged tile)
+constexpr int kSubs = kTile / kSub;
+
 struct ScanShared {
     float4 tile[kTile];
     float lb[kMaxOrder];
     short order[kMaxOrder];
     float qlo[4][3], qhi[4][3];
+    float sub[kSubs][2][6];               // per sub-tile and per half (one wave each): min xyz, max xyz
 };
 
 __device__ __forceinline__ float box_point_d2(const float4& lo, const float4& hi, float x, float y, float z)
@@ -158,8 +162,10 @@ __device__ __forceinline__ void order_tiles(ScanShared& sh, const TileBoxes& tb,
 template <int P>
 __device__ __forceinline__ void nn_scan(const float4* __restrict__ tgt, int m, const TileBoxes& tb, float maxc2,
                                         const float (&qx)[P], const float (&qy)[P], const float (&qz)[P],
-                                        const bool (&live)[P], ScanShared& sh, float (&best)[P], int (&bidx)[P])
+                                        const bool (&live)[P], ScanShared& sh, float (&best)[P], int (&bidx)[P],
+                                        const int (&seed)[P])
 {
+    static_assert(kNNThreads == 256 && kTile == 1024 && kSub == 128, "staging layout below assumes 4 waves x 4 loads");
     int grp[P];
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
@@ -169,9 +175,12 @@ __device__ __forceinline__ void nn_scan(const float4* __restrict__ tgt, int m, c
             lo[0] = fminf(lo[0], qx[p]); hi[0] = fmaxf(hi[0], qx[p]);
             lo[1] = fminf(lo[1], qy[p]); hi[1] = fmaxf(hi[1], qy[p]);
             lo[2] = fminf(lo[2], qz[p]); hi[2] = fmaxf(hi[2], qz[p]);
+            // warm start: any target point is an upper bound; last pass's neighbour is nearly always the winner
+            if (seed[p] >= 0 && seed[p] < m) { best[p] = dist2(qx[p], qy[p], qz[p], tgt[seed[p]]); grp[p] = seed[p] & ~7; }
         }
     }
     order_tiles(sh, tb, maxc2, lo, hi);
+    const int wave = threadIdx.x >> 6;
     for (int k = 0; k < tb.ntiles; ++k) {
         const int t = k < kMaxOrder ? (int)sh.order[k] : k;
         if (k < kMaxOrder && sh.lb[t] == INFINITY) break;  // this and every later tile: beyond maxc2
@@ -183,24 +192,56 @@ __device__ __forceinline__ void nn_scan(const float4* __restrict__ tgt, int m, c
         if (!__syncthreads_or(need)) continue;
         const int t0 = t * kTile;
         const int cnt = min(kTile, m - t0);
-        for (int i = threadIdx.x; i < kTile; i += kNNThreads)
-            sh.tile[i] = i < cnt ? tgt[t0 + i] : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
-        __syncthreads();
-        const int groups = (cnt + 7) >> 3;
-        for (int g = 0; g < groups; ++g) {
-            float4 c[8];
+        // stage the tile and, on the way, the bounding boxes of its 8 sub-tiles of 128 candidates
+        // (load j of wave w covers candidates [256 j + 64 w, +64): half (w & 1) of sub-tile 2 j + (w >> 1))
 #pragma unroll
-            for (int u = 0; u < 8; ++u) c[u] = sh.tile[8 * g + u];
+        for (int j = 0; j < kTile / kNNThreads; ++j) {
+            const int i = j * kNNThreads + threadIdx.x;
+            const bool in = i < cnt;
+            const float4 c = in ? tgt[t0 + i] : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
+            sh.tile[i] = c;
+            float b[6] = {c.x, c.y, c.z, in ? c.x : -INFINITY, in ? c.y : -INFINITY, in ? c.z : -INFINITY};
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                float d[8];
+            for (int a = 0; a < 3; ++a)
+                for (int o = 32; o > 0; o >>= 1) {
+                    b[a] = fminf(b[a], __shfl_xor(b[a], o, 64));
+                    b[3 + a] = fmaxf(b[3 + a], __shfl_xor(b[3 + a], o, 64));
+                }
+            if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) d[u] = dist2(qx[p], qy[p], qz[p], c[u]);
-                const float mn = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])), fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
-                if (mn < best[p]) { best[p] = mn; grp[p] = t0 + 8 * g; }
+                for (int a = 0; a < 6; ++a) sh.sub[2 * j + (wave >> 1)][wave & 1][a] = b[a];
             }
         }
-        // the next __syncthreads_or also protects sh.tile against early overwriting
+        __syncthreads();
+        for (int sb = 0; sb < kSubs; ++sb) {
+            if (sb * kSub >= cnt) break;
+            // wave-level culling: this wave's queries (4 x 64 consecutive Morton-ordered points) vs the sub-tile's box
+            float4 slo, shi;
+            slo.x = fminf(sh.sub[sb][0][0], sh.sub[sb][1][0]); slo.y = fminf(sh.sub[sb][0][1], sh.sub[sb][1][1]);
+            slo.z = fminf(sh.sub[sb][0][2], sh.sub[sb][1][2]);
+            shi.x = fmaxf(sh.sub[sb][0][3], sh.sub[sb][1][3]); shi.y = fmaxf(sh.sub[sb][0][4], sh.sub[sb][1][4]);
+            shi.z = fmaxf(sh.sub[sb][0][5], sh.sub[sb][1][5]);
+            bool wneed = false;
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                wneed |= live[p] && box_point_d2(slo, shi, qx[p], qy[p], qz[p]) * 0.9999f <= fminf(best[p], maxc2);
+            if (!__any(wneed)) continue;
+            const int g_end = min((sb + 1) * (kSub / 8), (cnt + 7) >> 3);
+            for (int g = sb * (kSub / 8); g < g_end; ++g) {
+                float4 c[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) c[u] = sh.tile[8 * g + u];
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    float d[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) d[u] = dist2(qx[p], qy[p], qz[p], c[u]);
+                    const float mn = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])), fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
+                    if (mn < best[p]) { best[p] = mn; grp[p] = t0 + 8 * g; }
+                }
+            }
+        }
+        // the next __syncthreads_or also protects sh.tile / sh.sub against early overwriting
     }
     // resolve the index inside the winning group of 8
 #pragma unroll
@@ -692,7 +733,7 @@ __global__ __launch_bounds__(kNNThreads) void k_nn_scan(
     const float4* __restrict__ src_all, const int64_t* __restrict__ src_offs,
     const float4* __restrict__ tgt_all, const int64_t* __restrict__ tgt_offs,
     const int* __restrict__ tgt_tile_base, const float4* __restrict__ tlo, const float4* __restrict__ thi,
-    const LmState* __restrict__ st, GicpParams prm, int* __restrict__ corr)
+    const LmState* __restrict__ st, GicpParams prm, int* __restrict__ corr, int* __restrict__ nn_seed)
 {
     __shared__ ScanShared sh;
     const int pair = blockIdx.y;
@@ -713,24 +754,29 @@ __global__ __launch_bounds__(kNNThreads) void k_nn_scan(
     const int per_block = kNNThreads * kPts;
     for (int base = blockIdx.x * per_block; base < n; base += gridDim.x * per_block) {
         float qx[kPts], qy[kPts], qz[kPts];
-        int si[kPts];
+        int si[kPts], seed[kPts];
         bool live[kPts];
 #pragma unroll
         for (int p = 0; p < kPts; ++p) {
-            si[p] = base + p * kNNThreads + threadIdx.x;
+            // a wave owns 4 x 64 CONSECUTIVE (Morton-ordered, i.e. spatially compact) source points
+            si[p] = base + (threadIdx.x >> 6) * (64 * kPts) + p * 64 + (threadIdx.x & 63);
             live[p] = si[p] < n;
             const float4 a = src[live[p] ? si[p] : 0];
             qx[p] = Tf[0] * a.x + Tf[1] * a.y + Tf[2] * a.z + Tf[3];
             qy[p] = Tf[4] * a.x + Tf[5] * a.y + Tf[6] * a.z + Tf[7];
             qz[p] = Tf[8] * a.x + Tf[9] * a.y + Tf[10] * a.z + Tf[11];
+            seed[p] = live[p] ? nn_seed[so + si[p]] : -1;   // last pass's nearest neighbour (the rejected ones too)
         }
         float best[kPts];
         int bidx[kPts];
         __syncthreads();
-        nn_scan<kPts>(tgt, m, tb, maxc2, qx, qy, qz, live, sh, best, bidx);
+        nn_scan<kPts>(tgt, m, tb, maxc2, qx, qy, qz, live, sh, best, bidx, seed);
 #pragma unroll
         for (int p = 0; p < kPts; ++p)
-            if (live[p]) corr[so + si[p]] = (bidx[p] >= 0 && (double)best[p] < prm.max_corr2) ? bidx[p] : -1;
+            if (live[p]) {
+                corr[so + si[p]] = (bidx[p] >= 0 && (double)best[p] < prm.max_corr2) ? bidx[p] : -1;
+                nn_seed[so + si[p]] = bidx[p];
+            }
     }
 }
 
@@ -1186,7 +1232,7 @@ __global__ __launch_bounds__(kNNThreads) void k_fitness(const float4* __restrict
         bool live[kPts];
 #pragma unroll
         for (int p = 0; p < kPts; ++p) {
-            si[p] = base + p * kNNThreads + threadIdx.x;
+            si[p] = base + (threadIdx.x >> 6) * (64 * kPts) + p * 64 + (threadIdx.x & 63);
             live[p] = si[p] < n;
             const float4 a = src[live[p] ? si[p] : 0];
             qx[p] = Tf[0] * a.x + Tf[1] * a.y + Tf[2] * a.z + Tf[3];
@@ -1195,8 +1241,9 @@ __global__ __launch_bounds__(kNNThreads) void k_fitness(const float4* __restrict
         }
         float best[kPts];
         int bidx[kPts];
+        const int no_seed[kPts] = {-1, -1, -1, -1};
         __syncthreads();
-        nn_scan<kPts>(tgt, m, tb, maxc2, qx, qy, qz, live, sh, best, bidx);
+        nn_scan<kPts>(tgt, m, tb, maxc2, qx, qy, qz, live, sh, best, bidx, no_seed);
 #pragma unroll
         for (int p = 0; p < kPts; ++p)
             if (live[p] && bidx[p] >= 0 && (double)best[p] <= max_range) { s += (double)best[p]; c += 1.0; }
@@ -1247,6 +1294,8 @@ struct mrs_gicp_batch {
     int* d_nblocks = nullptr;
     int* d_nactive = nullptr;
     int* d_corr = nullptr;          // [total source points] correspondences of the current evaluation
+    int* d_seed = nullptr;          // [total source points] last nearest neighbour (warm start of the next NN pass)
+    size_t n_seed = 0;
     unsigned long long* d_vkeys = nullptr;  // G7 voxel map of the targets (sorted keys, all pairs)
     float4* d_vmean = nullptr;
     double* d_vcov = nullptr;
@@ -1318,6 +1367,7 @@ int mrs_gicp_batch_destroy(mrs_gicp_batch* h)
     if (h->d_nblocks) (void)hipFree(h->d_nblocks);
     if (h->d_nactive) (void)hipFree(h->d_nactive);
     if (h->d_corr) (void)hipFree(h->d_corr);
+    if (h->d_seed) (void)hipFree(h->d_seed);
     if (h->d_vkeys) (void)hipFree(h->d_vkeys);
     if (h->d_vmean) (void)hipFree(h->d_vmean);
     if (h->d_vcov) (void)hipFree(h->d_vcov);
@@ -1388,7 +1438,12 @@ int mrs_gicp_batch_set_clouds(mrs_gicp_batch* h, int32_t which, const float* d_p
         if (h->d_corr) (void)hipFree(h->d_corr);
         h->d_corr = nullptr;
         MRS_HIP_TRY(hipMalloc(&h->d_corr, (size_t)total * sizeof(int)));
+        if (h->d_seed) (void)hipFree(h->d_seed);
+        h->d_seed = nullptr;
+        MRS_HIP_TRY(hipMalloc(&h->d_seed, (size_t)total * sizeof(int)));
+        h->n_seed = (size_t)total;
     }
+    if (h->d_seed) MRS_HIP_TRY(hipMemsetAsync(h->d_seed, 0xff, h->n_seed * sizeof(int), s));  // -1: no warm start across clouds
     MRS_HIP_TRY(hipMemcpyAsync(h->d_offs[which], h_offsets, (h->n_pairs + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
     MRS_HIP_TRY(hipMemcpyAsync(h->d_tile_base[which], tile_base.data(), h->n_pairs * sizeof(int), hipMemcpyHostToDevice, s));
 
@@ -1585,7 +1640,7 @@ int mrs_gicp_batch_align(mrs_gicp_batch* h, const double* h_guess, double* h_fin
                                h->d_vmean, h->d_vcov, h->n_voxels, h->d_state, h->prm, h->d_partial, h->max_blocks);
         } else {
             hipLaunchKernelGGL(k_nn_scan, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_pts[1], h->d_offs[1],
-                               h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_state, h->prm, h->d_corr);
+                               h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_state, h->prm, h->d_corr, h->d_seed);
             hipLaunchKernelGGL(k_linearize, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_cov[0],
                                h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->d_corr, h->d_partial, h->max_blocks);
         }
@@ -1636,7 +1691,7 @@ int mrs_gicp_batch_linearize(mrs_gicp_batch* h, const double* h_poses, double* h
                            h->max_blocks);
     } else {
         hipLaunchKernelGGL(k_nn_scan, dim3(h->max_blocks, h->n_pairs), dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0],
-                           h->d_pts[1], h->d_offs[1], h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_state, h->prm, h->d_corr);
+                           h->d_pts[1], h->d_offs[1], h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_state, h->prm, h->d_corr, h->d_seed);
         hipLaunchKernelGGL(k_linearize, dim3(h->max_blocks, h->n_pairs), dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0],
                            h->d_cov[0], h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->d_corr, h->d_partial,
                            h->max_blocks);
