@@ -156,6 +156,42 @@ __device__ __forceinline__ void order_tiles(ScanShared& sh, const TileBoxes& tb,
     __syncthreads();
 }
 
+// Stage target tile [t0, t0 + cnt) into LDS together with the bounding boxes of its 8 sub-tiles of 128 candidates
+// (load j of wave w covers candidates [256 j + 64 w, +64): half (w & 1) of sub-tile 2 j + (w >> 1)).
+// Ends with a barrier; the caller's next barrier protects sh.tile / sh.sub against early overwriting.
+__device__ __forceinline__ void stage_tile(ScanShared& sh, const float4* __restrict__ tgt, int t0, int cnt)
+{
+    static_assert(kNNThreads == 256 && kTile == 1024 && kSub == 128, "staging layout assumes 4 waves x 4 loads");
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < kTile / kNNThreads; ++j) {
+        const int i = j * kNNThreads + threadIdx.x;
+        const bool in = i < cnt;
+        const float4 c = in ? tgt[t0 + i] : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
+        sh.tile[i] = c;
+        float b[6] = {c.x, c.y, c.z, in ? c.x : -INFINITY, in ? c.y : -INFINITY, in ? c.z : -INFINITY};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            for (int o = 32; o > 0; o >>= 1) {
+                b[a] = fminf(b[a], __shfl_xor(b[a], o, 64));
+                b[3 + a] = fmaxf(b[3 + a], __shfl_xor(b[3 + a], o, 64));
+            }
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) sh.sub[2 * j + (wave >> 1)][wave & 1][a] = b[a];
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void sub_box(const ScanShared& sh, int sb, float4& slo, float4& shi)
+{
+    slo.x = fminf(sh.sub[sb][0][0], sh.sub[sb][1][0]); slo.y = fminf(sh.sub[sb][0][1], sh.sub[sb][1][1]);
+    slo.z = fminf(sh.sub[sb][0][2], sh.sub[sb][1][2]);
+    shi.x = fmaxf(sh.sub[sb][0][3], sh.sub[sb][1][3]); shi.y = fmaxf(sh.sub[sb][0][4], sh.sub[sb][1][4]);
+    shi.z = fmaxf(sh.sub[sb][0][5], sh.sub[sb][1][5]);
+}
+
 // Exact 1-NN of P query points per lane over the Morton-ordered cloud tgt[0..m): squared distance
 // and (sorted-space) index.  Tiles are culled conservatively with their bounding boxes; `maxc2` is
 // the rejection radius (inf = none).  The whole workgroup must call it together.
@@ -165,7 +201,6 @@ __device__ __forceinline__ void nn_scan(const float4* __restrict__ tgt, int m, c
                                         const bool (&live)[P], ScanShared& sh, float (&best)[P], int (&bidx)[P],
                                         const int (&seed)[P])
 {
-    static_assert(kNNThreads == 256 && kTile == 1024 && kSub == 128, "staging layout below assumes 4 waves x 4 loads");
     int grp[P];
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
@@ -180,7 +215,6 @@ __device__ __forceinline__ void nn_scan(const float4* __restrict__ tgt, int m, c
         }
     }
     order_tiles(sh, tb, maxc2, lo, hi);
-    const int wave = threadIdx.x >> 6;
     for (int k = 0; k < tb.ntiles; ++k) {
         const int t = k < kMaxOrder ? (int)sh.order[k] : k;
         if (k < kMaxOrder && sh.lb[t] == INFINITY) break;  // this and every later tile: beyond maxc2
@@ -192,35 +226,12 @@ __device__ __forceinline__ void nn_scan(const float4* __restrict__ tgt, int m, c
         if (!__syncthreads_or(need)) continue;
         const int t0 = t * kTile;
         const int cnt = min(kTile, m - t0);
-        // stage the tile and, on the way, the bounding boxes of its 8 sub-tiles of 128 candidates
-        // (load j of wave w covers candidates [256 j + 64 w, +64): half (w & 1) of sub-tile 2 j + (w >> 1))
-#pragma unroll
-        for (int j = 0; j < kTile / kNNThreads; ++j) {
-            const int i = j * kNNThreads + threadIdx.x;
-            const bool in = i < cnt;
-            const float4 c = in ? tgt[t0 + i] : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
-            sh.tile[i] = c;
-            float b[6] = {c.x, c.y, c.z, in ? c.x : -INFINITY, in ? c.y : -INFINITY, in ? c.z : -INFINITY};
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-                for (int o = 32; o > 0; o >>= 1) {
-                    b[a] = fminf(b[a], __shfl_xor(b[a], o, 64));
-                    b[3 + a] = fmaxf(b[3 + a], __shfl_xor(b[3 + a], o, 64));
-                }
-            if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-                for (int a = 0; a < 6; ++a) sh.sub[2 * j + (wave >> 1)][wave & 1][a] = b[a];
-            }
-        }
-        __syncthreads();
+        stage_tile(sh, tgt, t0, cnt);
         for (int sb = 0; sb < kSubs; ++sb) {
             if (sb * kSub >= cnt) break;
             // wave-level culling: this wave's queries (4 x 64 consecutive Morton-ordered points) vs the sub-tile's box
             float4 slo, shi;
-            slo.x = fminf(sh.sub[sb][0][0], sh.sub[sb][1][0]); slo.y = fminf(sh.sub[sb][0][1], sh.sub[sb][1][1]);
-            slo.z = fminf(sh.sub[sb][0][2], sh.sub[sb][1][2]);
-            shi.x = fmaxf(sh.sub[sb][0][3], sh.sub[sb][1][3]); shi.y = fmaxf(sh.sub[sb][0][4], sh.sub[sb][1][4]);
-            shi.z = fmaxf(sh.sub[sb][0][5], sh.sub[sb][1][5]);
+            sub_box(sh, sb, slo, shi);
             bool wneed = false;
 #pragma unroll
             for (int p = 0; p < P; ++p)
@@ -460,9 +471,13 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_cov(const float4* __restrict
             if (!__syncthreads_or(need)) continue;
             const int t0 = t * kTile;
             const int cnt = min(kTile, n - t0);
-            for (int u = threadIdx.x; u < cnt; u += kNNThreads) sh.tile[u] = pts[t0 + u];
-            __syncthreads();
-            for (int u = 0; u < cnt; ++u) {
+            stage_tile(sh, pts, t0, cnt);
+            for (int sb = 0; sb < kSubs && sb * kSub < cnt; ++sb) {
+              float4 slo, shi;   // wave-level culling against the sub-tile's box (this wave: 64 consecutive Morton points)
+              sub_box(sh, sb, slo, shi);
+              if (!__any(live && box_point_d2(slo, shi, q.x, q.y, q.z) * 0.9999f <= dk[KMAX - 1])) continue;
+              const int u_end = min((sb + 1) * kSub, cnt);
+              for (int u = sb * kSub; u < u_end; ++u) {
                 const float d = dist2(q.x, q.y, q.z, sh.tile[u]);
                 if (d < dk[KMAX - 1]) {  // sorted insertion, static register indices
                     const int j = t0 + u;
@@ -475,6 +490,7 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_cov(const float4* __restrict
                     }
                     if (dk[0] > d) { dk[0] = d; ik[0] = j; }
                 }
+              }
             }
         }
         if (!live) continue;
@@ -645,9 +661,13 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_features(const float4* __res
             if (!__syncthreads_or(need)) continue;
             const int t0 = t * kTile;
             const int cnt = min(kTile, n - t0);
-            for (int u = threadIdx.x; u < cnt; u += kNNThreads) sh.tile[u] = pts[t0 + u];
-            __syncthreads();
-            for (int u = 0; u < cnt; ++u) {
+            stage_tile(sh, pts, t0, cnt);
+            for (int sb = 0; sb < kSubs && sb * kSub < cnt; ++sb) {
+              float4 slo, shi;   // wave-level culling against the sub-tile's box
+              sub_box(sh, sb, slo, shi);
+              if (!__any(live && box_point_d2(slo, shi, q.x, q.y, q.z) * 0.9999f <= dk[KMAX - 1])) continue;
+              const int u_end = min((sb + 1) * kSub, cnt);
+              for (int u = sb * kSub; u < u_end; ++u) {
                 const float d = dist2(q.x, q.y, q.z, sh.tile[u]);
                 if (d < dk[KMAX - 1]) {
                     const int j = t0 + u;
@@ -660,6 +680,7 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_features(const float4* __res
                     }
                     if (dk[0] > d) { dk[0] = d; ik[0] = j; }
                 }
+              }
             }
         }
         if (!live) continue;
