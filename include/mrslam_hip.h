@@ -349,6 +349,15 @@ int mrs_ring_corr_fft_sweep(mrs_ctx* ctx, const float* d_query_spec, int32_t n_q
 int mrs_ring_corr_fft_pairs(mrs_ctx* ctx, const float* d_a_spec, const float* d_b_spec, int32_t n_pairs,
                             float* d_dist, int32_t* d_angle, float* d_corr, mrs_stream stream);
 
+/* Multi-channel forms (RING++, fast_corr_RINGplusplus, RING_ros/util.py:337-358): descriptors are
+ * [channels][61][120] complex64 half spectra of the jointly normalised channels (mrs_normalize_groups over
+ * channels*120*120, then mrs_ring_half_spectrum with n_img = n * channels); |corr| is summed over channels and
+ * detectors, dist = 1 - max / (0.15 * channels * 120 * 120). */
+int mrs_ring_corr_fft_sweep_mc(mrs_ctx* ctx, const float* d_query_spec, int32_t n_query, const float* d_db_spec, int32_t n_db,
+                               int32_t channels, float* d_dist, int32_t* d_angle, float* d_corr, mrs_stream stream);
+int mrs_ring_corr_fft_pairs_mc(mrs_ctx* ctx, const float* d_a_spec, const float* d_b_spec, int32_t n_pairs, int32_t channels,
+                               float* d_dist, int32_t* d_angle, float* d_corr, mrs_stream stream);
+
 /* fp16 replica format (multi-GPU exchange): every descriptor has to reach every GPU, and at
  * >1 M descriptors/s/GPU the fp32 half spectrum (58 560 B) exceeds what the xGMI links carry.  A rank keeps its
  * own descriptors in fp32 (exact scoring) and ships round-to-nearest fp16 copies (29 280 B) to the others, which

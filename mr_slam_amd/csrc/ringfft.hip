@@ -159,21 +159,24 @@ __device__ __forceinline__ void wave_abs_reduce_scatter(const float (&re)[60], c
 }
 
 struct FftCorrP {
-    int nq, ndb, pairwise;
+    int nq, ndb, pairwise, channels;
     float denom;  // 0.15 * C * A * D
 };
 
-// grid = (blocks, nq); NSLOT pair streams of 128 lanes share the LDS-resident query spectrum.
 __device__ __forceinline__ float2 load_spec(const float2* p) { return *p; }
 __device__ __forceinline__ float2 load_spec(const __half2* p) { return __half22float2(*p); }
 
-// DBT = float2 (the database format) or __half2 (fp16 replicas received from other ranks)
-template <int NSLOT, bool PAIRWISE, typename DBT>
+// grid = (blocks, nq); NSLOT pair streams of 128 lanes.  QLDS: the (single-channel) query spectrum is staged in
+// LDS and shared by the slots; otherwise (pairwise mode, C > 1) it is read through L2 like the candidate.
+// DBT = float2 (the database format) or __half2 (fp16 replicas received from other ranks).
+// Descriptors with C channels are [C][61][120]: |corr| is summed over channels and detectors
+// (fast_corr_RINGplusplus, RING_ros/util.py:337-358; C = 1: fast_corr, util.py:362-374).
+template <int NSLOT, bool QLDS, typename DBT>
 __global__ __launch_bounds__(NSLOT* kSlotThreads) void k_ring_corr_fft(const float2* __restrict__ Q, const DBT* __restrict__ DB,
                                                                        FftCorrP p, float* __restrict__ dist,
                                                                        int* __restrict__ angle, float* __restrict__ corr_out)
 {
-    extern __shared__ __attribute__((aligned(16))) float2 qs[];  // [61][120] query half spectrum (sweep mode)
+    extern __shared__ __attribute__((aligned(16))) float2 qs[];  // [61][120] query half spectrum (QLDS)
     __shared__ float xbuf[NSLOT][128];
     const int q = blockIdx.y;
     const int slot = threadIdx.x / kSlotThreads;
@@ -181,31 +184,39 @@ __global__ __launch_bounds__(NSLOT* kSlotThreads) void k_ring_corr_fft(const flo
     const int wave_in_slot = t >> 6, lane = t & 63;
     const int d = min(t, kD - 1);
     const bool live_col = t < kD;
-    const float2* qsrc = Q + (size_t)q * kHalf * kD;
-    if (!PAIRWISE) {
+    const int C = p.channels;
+    const size_t entry = (size_t)C * kHalf * kD;
+    const float2* qsrc = Q + (size_t)q * entry;
+    if (QLDS) {
         for (int i = threadIdx.x; i < kHalf * kD; i += NSLOT * kSlotThreads) qs[i] = qsrc[i];
         __syncthreads();
     }
-    const int ncand = PAIRWISE ? 1 : p.ndb;
+    const int ncand = p.pairwise ? 1 : p.ndb;
     const int stride = gridDim.x * NSLOT;
     const int rounds = (ncand + stride - 1) / stride;
     for (int r = 0; r < rounds; ++r) {
         const int cand = (r * gridDim.x + blockIdx.x) * NSLOT + slot;
         const bool live = cand < ncand;
-        float re[60], im[60];
-        if (live) {
-            const DBT* b = DB + ((size_t)(PAIRWISE ? q : cand) * kHalf) * kD + d;
-            corr_irfft120([&](int k, float& ar, float& ai, float& br, float& bi) {
-                const float2 bv = load_spec(b + k * kD);
-                const float2 av = PAIRWISE ? qsrc[k * kD + d] : qs[k * kD + d];
-                ar = av.x; ai = av.y; br = bv.x; bi = bv.y;
-            }, re, im);
-        } else {
+        float v[2] = {0.0f, 0.0f};
+        for (int c = 0; c < C; ++c) {
+            float re[60], im[60];
+            if (live) {
+                const DBT* b = DB + (size_t)(p.pairwise ? q : cand) * entry + (size_t)c * kHalf * kD + d;
+                const float2* a = qsrc + (size_t)c * kHalf * kD + d;
+                corr_irfft120([&](int k, float& ar, float& ai, float& br, float& bi) {
+                    const float2 bv = load_spec(b + k * kD);
+                    const float2 av = QLDS ? qs[k * kD + d] : a[k * kD];
+                    ar = av.x; ai = av.y; br = bv.x; bi = bv.y;
+                }, re, im);
+            } else {
 #pragma unroll
-            for (int m = 0; m < 60; ++m) { re[m] = 0.0f; im[m] = 0.0f; }
+                for (int m = 0; m < 60; ++m) { re[m] = 0.0f; im[m] = 0.0f; }
+            }
+            float w0, w1;
+            wave_abs_reduce_scatter(re, im, live && live_col, w0, w1);
+            v[0] += w0;
+            v[1] += w1;
         }
-        float v[2];
-        wave_abs_reduce_scatter(re, im, live && live_col, v[0], v[1]);
         if (wave_in_slot == 1) { xbuf[slot][2 * lane] = v[0]; xbuf[slot][2 * lane + 1] = v[1]; }
         __syncthreads();
         if (wave_in_slot == 0 && live) {
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(NSLOT* kSlotThreads) void k_ring_corr_fft(const flo
             // fftshift: shifted index m = (n + 60) % 120; first maximum in m order (util.py:367-371)
             const int n0 = 2 * lane, n1 = 2 * lane + 1;
             const int m0 = n0 < 60 ? n0 + 60 : n0 - 60, m1 = n1 < 60 ? n1 + 60 : n1 - 60;
-            const size_t o = (size_t)q * (PAIRWISE ? 1 : p.ndb) + (PAIRWISE ? 0 : cand);
+            const size_t o = (size_t)q * (p.pairwise ? 1 : p.ndb) + (p.pairwise ? 0 : cand);
             float best = -1.0f;
             int bm = 1 << 30;
             if (lane < 60) {
@@ -271,54 +282,71 @@ int mrs_ring_half_spectrum_f16(mrs_ctx* ctx, const float* d_norm_sino, int32_t n
 
 extern "C++" {
 template <typename DBT>
-static int corr_fft_launch(mrs_ctx* ctx, const float* d_q, int32_t n_q, const void* d_db, int32_t n_db, float* d_dist,
-                           int32_t* d_angle, float* d_corr, mrs_stream stream, bool pairwise)
+static int corr_fft_launch(mrs_ctx* ctx, const float* d_q, int32_t n_q, const void* d_db, int32_t n_db, int32_t channels,
+                           float* d_dist, int32_t* d_angle, float* d_corr, mrs_stream stream, bool pairwise)
 {
     MRS_REQUIRE(ctx && d_q && d_db && d_dist && d_angle, "null pointer");
-    MRS_REQUIRE(n_q > 0 && n_db > 0, "counts must be positive");
+    MRS_REQUIRE(n_q > 0 && n_db > 0 && channels > 0, "counts must be positive");
     MRS_HIP_TRY(hipSetDevice(ctx->device));
     FftCorrP p;
-    p.nq = n_q; p.ndb = n_db; p.pairwise = pairwise ? 1 : 0;
-    p.denom = (float)(0.15 * kA * kD);
+    p.nq = n_q; p.ndb = n_db; p.pairwise = pairwise ? 1 : 0; p.channels = channels;
+    p.denom = (float)(0.15 * channels * kA * kD);
     constexpr int NSLOT = 2;
     hipStream_t s = (hipStream_t)stream;
     const float2* q2 = reinterpret_cast<const float2*>(d_q);
     const DBT* db2 = reinterpret_cast<const DBT*>(d_db);
     if (pairwise) {
-        hipLaunchKernelGGL((k_ring_corr_fft<1, true, DBT>), dim3(1, n_q), dim3(kSlotThreads), 0, s, q2, db2, p, d_dist, d_angle, d_corr);
+        hipLaunchKernelGGL((k_ring_corr_fft<1, false, DBT>), dim3(1, n_q), dim3(kSlotThreads), 0, s, q2, db2, p, d_dist, d_angle, d_corr);
     } else {
-        const size_t lds = (size_t)kHalf * kD * sizeof(float2);
-        auto kern = k_ring_corr_fft<NSLOT, false, DBT>;
-        MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int blocks = 2 * (ctx->num_cu > 0 ? ctx->num_cu : 256);
         if (n_q > 1) blocks = (blocks + n_q - 1) / n_q;
         const int need = (n_db + NSLOT - 1) / NSLOT;
         if (blocks > need) blocks = need;
         if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(kern, dim3(blocks, n_q), dim3(NSLOT * kSlotThreads), lds, s, q2, db2, p, d_dist, d_angle, d_corr);
+        if (channels == 1) {
+            const size_t lds = (size_t)kHalf * kD * sizeof(float2);
+            auto kern = k_ring_corr_fft<NSLOT, true, DBT>;
+            MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(blocks, n_q), dim3(NSLOT * kSlotThreads), lds, s, q2, db2, p, d_dist, d_angle, d_corr);
+        } else {
+            hipLaunchKernelGGL((k_ring_corr_fft<NSLOT, false, DBT>), dim3(blocks, n_q), dim3(NSLOT * kSlotThreads), 0, s, q2, db2, p,
+                               d_dist, d_angle, d_corr);
+        }
     }
     MRS_HIP_TRY(hipGetLastError());
     return MRS_OK;
 }
-
 }  // extern "C++"
 
 int mrs_ring_corr_fft_sweep(mrs_ctx* ctx, const float* d_query_spec, int32_t n_query, const float* d_db_spec,
                             int32_t n_db, float* d_dist, int32_t* d_angle, float* d_corr, mrs_stream stream)
 {
-    return corr_fft_launch<float2>(ctx, d_query_spec, n_query, d_db_spec, n_db, d_dist, d_angle, d_corr, stream, false);
+    return corr_fft_launch<float2>(ctx, d_query_spec, n_query, d_db_spec, n_db, 1, d_dist, d_angle, d_corr, stream, false);
 }
 
 int mrs_ring_corr_fft_sweep_f16(mrs_ctx* ctx, const float* d_query_spec, int32_t n_query, const void* d_db_spec_f16,
                                 int32_t n_db, float* d_dist, int32_t* d_angle, float* d_corr, mrs_stream stream)
 {
-    return corr_fft_launch<__half2>(ctx, d_query_spec, n_query, d_db_spec_f16, n_db, d_dist, d_angle, d_corr, stream, false);
+    return corr_fft_launch<__half2>(ctx, d_query_spec, n_query, d_db_spec_f16, n_db, 1, d_dist, d_angle, d_corr, stream, false);
 }
 
 int mrs_ring_corr_fft_pairs(mrs_ctx* ctx, const float* d_a_spec, const float* d_b_spec, int32_t n_pairs, float* d_dist,
                             int32_t* d_angle, float* d_corr, mrs_stream stream)
 {
-    return corr_fft_launch<float2>(ctx, d_a_spec, n_pairs, d_b_spec, n_pairs, d_dist, d_angle, d_corr, stream, true);
+    return corr_fft_launch<float2>(ctx, d_a_spec, n_pairs, d_b_spec, n_pairs, 1, d_dist, d_angle, d_corr, stream, true);
+}
+
+/* multi-channel (RING++) forms: descriptors are [channels][61][120] complex64 */
+int mrs_ring_corr_fft_sweep_mc(mrs_ctx* ctx, const float* d_query_spec, int32_t n_query, const float* d_db_spec, int32_t n_db,
+                               int32_t channels, float* d_dist, int32_t* d_angle, float* d_corr, mrs_stream stream)
+{
+    return corr_fft_launch<float2>(ctx, d_query_spec, n_query, d_db_spec, n_db, channels, d_dist, d_angle, d_corr, stream, false);
+}
+
+int mrs_ring_corr_fft_pairs_mc(mrs_ctx* ctx, const float* d_a_spec, const float* d_b_spec, int32_t n_pairs, int32_t channels,
+                               float* d_dist, int32_t* d_angle, float* d_corr, mrs_stream stream)
+{
+    return corr_fft_launch<float2>(ctx, d_a_spec, n_pairs, d_b_spec, n_pairs, channels, d_dist, d_angle, d_corr, stream, true);
 }
 
 }  // extern "C"

@@ -175,6 +175,9 @@ def fast_corr_RINGplusplus(a, b, device="cuda:0"):
     b = torch.as_tensor(b, dtype=torch.float32).to(device).contiguous()
     an = normalize(a[None])
     bn = normalize(b[None])
+    if a.shape[-2:] == (120, 120):      # FFT-domain kernel (specialised for the reference geometry)
+        dist, ang = corr_pairs_fft(half_spectrum(an), half_spectrum(bn))
+        return dist.cpu().numpy()[0], ang.cpu().numpy()[0]
     dist, ang = corr_sweep(an, bn)
     return dist.cpu().numpy()[0, 0], ang.cpu().numpy()[0, 0]
 
@@ -301,6 +304,13 @@ def corr_sweep_fft(query_spec, db_spec, want_corr=False):
     if db.dtype == torch.float16:
         assert db.shape[1:] == (61, 120, 2)
         fn, dbp = _lib.load().mrs_ring_corr_fft_sweep_f16, _lib.ptr(db)
+    elif db.dim() == 4:        # RING++: [N, C, 61, 120]
+        assert db.dtype == torch.complex64 and q.dim() == 4 and q.shape[1] == db.shape[1]
+        _lib.check(_lib.load().mrs_ring_corr_fft_sweep_mc(_lib.ctx(d), _lib.ptr(torch.view_as_real(q)), Q,
+                                                          _lib.ptr(torch.view_as_real(db)), N, int(db.shape[1]), _lib.ptr(dist),
+                                                          _lib.ptr(ang), _lib.ptr(corr) if want_corr else None,
+                                                          _lib.current_stream(d)))
+        return (dist, ang, corr) if want_corr else (dist, ang)
     else:
         assert db.dtype == torch.complex64
         fn, dbp = _lib.load().mrs_ring_corr_fft_sweep, _lib.ptr(torch.view_as_real(db))
@@ -310,12 +320,18 @@ def corr_sweep_fft(query_spec, db_spec, want_corr=False):
 
 
 def corr_pairs_fft(a_spec, b_spec, out=None):
-    """Pairwise C1 on half spectra [P,61,120] complex64 -> (dist [P], angle [P])."""
+    """Pairwise C1/C2 on half spectra [P,61,120] (or RING++ [P,C,61,120]) complex64 -> (dist [P], angle [P])."""
     d = _dev(a_spec)
     a, b = a_spec.contiguous(), b_spec.contiguous()
     P = a.shape[0]
     dist, ang = out if out is not None else (torch.empty(P, dtype=torch.float32, device=a.device),
                                              torch.empty(P, dtype=torch.int32, device=a.device))
+    if a.dim() == 4:
+        assert a.shape == b.shape
+        _lib.check(_lib.load().mrs_ring_corr_fft_pairs_mc(_lib.ctx(d), _lib.ptr(torch.view_as_real(a)),
+                                                          _lib.ptr(torch.view_as_real(b)), P, int(a.shape[1]), _lib.ptr(dist),
+                                                          _lib.ptr(ang), None, _lib.current_stream(d)))
+        return dist, ang
     _lib.check(_lib.load().mrs_ring_corr_fft_pairs(_lib.ctx(d), _lib.ptr(torch.view_as_real(a)),
                                                    _lib.ptr(torch.view_as_real(b)), P, _lib.ptr(dist), _lib.ptr(ang),
                                                    None, _lib.current_stream(d)))

@@ -263,3 +263,40 @@ def test_fp16_replica_format(dev):
     assert clear.sum() >= 3
     assert np.array_equal(a16.cpu().numpy()[clear], a32.cpu().numpy()[clear])
     assert a16[0, 2] == -21 and a16[1, 5] == 0 and a16[2, 8] == 40
+
+
+def test_ringpp_fft_domain_matches_restatement(dev):
+    """RING++ (6 channels): FFT-domain sweep / pairs on [C][61][120] half spectra vs fast_corr_RINGplusplus
+    (util.py:337-358) and vs the direct sinogram-domain kernel."""
+    import torch
+    from mr_slam_amd import ring
+    from oracle import corr_oracle as K
+    rng = np.random.default_rng(31)
+    C = 6
+    raw = rng.uniform(0, 1, size=(5, C, 120, 120)).astype(np.float32)
+    raw *= (rng.uniform(size=(5, C, 120, 120)) < 0.3)
+    db = raw.copy()
+    q = np.stack([np.roll(db[1], 13, axis=1), db[3], np.roll(db[4], -50, axis=1)])
+    tq, tdb = torch.from_numpy(q).to(dev), torch.from_numpy(db).to(dev)
+    nq, ndb = ring.normalize(tq), ring.normalize(tdb)              # one mean/std over all channels (util.py:339-340)
+    sq, sdb = ring.half_spectrum(nq), ring.half_spectrum(ndb)
+    assert sq.shape == (3, C, 61, 120)
+    dist, ang, corr = ring.corr_sweep_fft(sq, sdb, want_corr=True)
+    d2, a2, c2 = ring.corr_sweep(nq, ndb, want_corr=True)
+    np.testing.assert_allclose(corr.cpu().numpy(), c2.cpu().numpy(), rtol=1e-4, atol=5e-3)
+    assert np.abs(dist.cpu().numpy() - d2.cpu().numpy()).max() < 1e-5
+    dist, ang = dist.cpu().numpy(), ang.cpu().numpy()
+    for i in range(3):
+        for j in range(5):
+            wd, wa, wc = K.fast_corr_ringplusplus(q[i], db[j])
+            assert abs(dist[i, j] - float(wd)) < 1e-5
+            top2 = np.sort(wc)[-2:]
+            if top2[1] - top2[0] > 1e-3 * top2[1]:
+                assert ang[i, j] == wa
+    assert ang[0, 1] == -13 and ang[1, 3] == 0 and ang[2, 4] == 50
+    dp, ap = ring.corr_pairs_fft(sq, sdb[[1, 3, 4]])
+    assert np.array_equal(ap.cpu().numpy(), [-13, 0, 50])
+    assert np.abs(dp.cpu().numpy() - dist[[0, 1, 2], [1, 3, 4]]).max() < 1e-6
+    d1, a1 = ring.fast_corr_RINGplusplus(q[0], db[1], device=dev)     # the drop-in, now on the FFT-domain kernel
+    assert abs(float(d1) - float(K.fast_corr_ringplusplus(q[0], db[1])[0])) < 1e-5 and int(a1) == -13
+    # throughput note (not asserted): see bench.py sweep leg

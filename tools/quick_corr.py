@@ -34,3 +34,14 @@ print(f"direct pairs P={P}: {ms:.3f} ms")
 ms1 = timeit(lambda: ring.half_spectrum(db[:P, 0]))
 ms2 = timeit(lambda: ring.corr_pairs_fft(sdb[:P], sdb[P:2 * P]))
 print(f"fft pairs P={P}: spectrum {ms1:.3f} ms + corr {ms2:.3f} ms")
+
+# RING++ (6 channels)
+C = 6
+Np = max(64, N // 8)
+dbp = ring.normalize(torch.randn((Np, C, 120, 120), device=dev, generator=g))
+sdbp = ring.half_spectrum(dbp)
+for nq in (1, 4):
+    ms = timeit(lambda: ring.corr_sweep(dbp[:nq].contiguous(), dbp), n=2)
+    print(f"RING++ direct sweep nq={nq} N={Np}: {ms:.3f} ms  {nq*Np/ms/1e3:.3f} Mpairs/s")
+    ms = timeit(lambda: ring.corr_sweep_fft(sdbp[:nq].contiguous(), sdbp))
+    print(f"RING++ fft sweep    nq={nq} N={Np}: {ms:.3f} ms  {nq*Np/ms/1e3:.3f} Mpairs/s  {nq*Np*C*58560/ms/1e6:.0f} GB/s")
