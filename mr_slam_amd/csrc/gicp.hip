@@ -748,8 +748,11 @@ __device__ __forceinline__ bool inv3_sym(const double* a, double* r)
 }
 
 // G3a: exact 1-NN of every (float-)transformed source point (tile-culled brute force).
-// grid = (blocks, pairs).  Kept free of the fp64 algebra so that it runs at full occupancy.
+// grid = (blocks, pairs).  Kept free of the fp64 algebra so that it runs at full occupancy.  P source points per
+// lane: 4 when the batch fills the chip (every LDS candidate read serves 4 distance evaluations), fewer for a
+// single pair so that its ~120 workgroups become ~470 (latency of one align() call).
 // corr[so + i] = target index (sorted space), or -1 when d^2 >= max_corr^2.
+template <int P>
 __global__ __launch_bounds__(kNNThreads) void k_nn_scan(
     const float4* __restrict__ src_all, const int64_t* __restrict__ src_offs,
     const float4* __restrict__ tgt_all, const int64_t* __restrict__ tgt_offs,
@@ -772,15 +775,15 @@ __global__ __launch_bounds__(kNNThreads) void k_nn_scan(
     float Tf[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) Tf[i] = (float)S.xi[i];
-    const int per_block = kNNThreads * kPts;
+    const int per_block = kNNThreads * P;
     for (int base = blockIdx.x * per_block; base < n; base += gridDim.x * per_block) {
-        float qx[kPts], qy[kPts], qz[kPts];
-        int si[kPts], seed[kPts];
-        bool live[kPts];
+        float qx[P], qy[P], qz[P];
+        int si[P], seed[P];
+        bool live[P];
 #pragma unroll
-        for (int p = 0; p < kPts; ++p) {
+        for (int p = 0; p < P; ++p) {
             // a wave owns 4 x 64 CONSECUTIVE (Morton-ordered, i.e. spatially compact) source points
-            si[p] = base + (threadIdx.x >> 6) * (64 * kPts) + p * 64 + (threadIdx.x & 63);
+            si[p] = base + (threadIdx.x >> 6) * (64 * P) + p * 64 + (threadIdx.x & 63);
             live[p] = si[p] < n;
             const float4 a = src[live[p] ? si[p] : 0];
             qx[p] = Tf[0] * a.x + Tf[1] * a.y + Tf[2] * a.z + Tf[3];
@@ -788,12 +791,12 @@ __global__ __launch_bounds__(kNNThreads) void k_nn_scan(
             qz[p] = Tf[8] * a.x + Tf[9] * a.y + Tf[10] * a.z + Tf[11];
             seed[p] = live[p] ? nn_seed[so + si[p]] : -1;   // last pass's nearest neighbour (the rejected ones too)
         }
-        float best[kPts];
-        int bidx[kPts];
+        float best[P];
+        int bidx[P];
         __syncthreads();
-        nn_scan<kPts>(tgt, m, tb, maxc2, qx, qy, qz, live, sh, best, bidx, seed);
+        nn_scan<P>(tgt, m, tb, maxc2, qx, qy, qz, live, sh, best, bidx, seed);
 #pragma unroll
-        for (int p = 0; p < kPts; ++p)
+        for (int p = 0; p < P; ++p)
             if (live[p]) {
                 corr[so + si[p]] = (bidx[p] >= 0 && (double)best[p] < prm.max_corr2) ? bidx[p] : -1;
                 nn_seed[so + si[p]] = bidx[p];
@@ -1323,6 +1326,7 @@ struct mrs_gicp_batch {
     int n_voxels = 0;
     double vox_res_built = 0.0;
     int max_blocks = 0;
+    int longest_src = 0;            // points in the largest source cloud (grid of the NN scan)
     double last_nn_passes = 0;
 };
 
@@ -1342,6 +1346,19 @@ void free_cloud(mrs_gicp_batch* h, int w)
 }
 
 int blocks_for_points(int n) { return (n + kNNThreads * kPts - 1) / (kNNThreads * kPts); }
+
+template <class... Args>
+void launch_nn_scan(int longest_src, int n_pairs, int num_cu, hipStream_t s, Args... args)
+{
+    const int cus = num_cu > 0 ? num_cu : 256;
+    auto wgs = [&](int P) { return (long)n_pairs * ((longest_src + kNNThreads * P - 1) / (kNNThreads * P)); };
+    if (wgs(4) >= 3L * cus)
+        hipLaunchKernelGGL(k_nn_scan<4>, dim3((unsigned)(wgs(4) / n_pairs), n_pairs), dim3(kNNThreads), 0, s, args...);
+    else if (wgs(2) >= 3L * cus)
+        hipLaunchKernelGGL(k_nn_scan<2>, dim3((unsigned)(wgs(2) / n_pairs), n_pairs), dim3(kNNThreads), 0, s, args...);
+    else
+        hipLaunchKernelGGL(k_nn_scan<1>, dim3((unsigned)(wgs(1) / n_pairs), n_pairs), dim3(kNNThreads), 0, s, args...);
+}
 
 }  // namespace
 
@@ -1558,6 +1575,7 @@ static int ensure_state(mrs_gicp_batch* h)
     int64_t longest = 0;
     for (int i = 0; i < h->n_pairs; ++i) longest = std::max(longest, h->offs[0][i + 1] - h->offs[0][i]);
     const int mb = blocks_for_points((int)longest);
+    h->longest_src = (int)longest;
     if (!h->d_state) {
         MRS_HIP_TRY(hipMalloc(&h->d_state, h->n_pairs * sizeof(LmState)));
         MRS_HIP_TRY(hipMalloc(&h->d_nblocks, h->n_pairs * sizeof(int)));
@@ -1660,8 +1678,8 @@ int mrs_gicp_batch_align(mrs_gicp_batch* h, const double* h_guess, double* h_fin
             hipLaunchKernelGGL(k_linearize_voxel, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_cov[0], h->d_vkeys,
                                h->d_vmean, h->d_vcov, h->n_voxels, h->d_state, h->prm, h->d_partial, h->max_blocks);
         } else {
-            hipLaunchKernelGGL(k_nn_scan, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_pts[1], h->d_offs[1],
-                               h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_state, h->prm, h->d_corr, h->d_seed);
+            launch_nn_scan(h->longest_src, h->n_pairs, h->ctx->num_cu, s, h->d_pts[0], h->d_offs[0], h->d_pts[1], h->d_offs[1],
+                           h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_state, h->prm, h->d_corr, h->d_seed);
             hipLaunchKernelGGL(k_linearize, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_cov[0],
                                h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->d_corr, h->d_partial, h->max_blocks);
         }
@@ -1711,8 +1729,8 @@ int mrs_gicp_batch_linearize(mrs_gicp_batch* h, const double* h_poses, double* h
                            h->d_cov[0], h->d_vkeys, h->d_vmean, h->d_vcov, h->n_voxels, h->d_state, h->prm, h->d_partial,
                            h->max_blocks);
     } else {
-        hipLaunchKernelGGL(k_nn_scan, dim3(h->max_blocks, h->n_pairs), dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0],
-                           h->d_pts[1], h->d_offs[1], h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_state, h->prm, h->d_corr, h->d_seed);
+        launch_nn_scan(h->longest_src, h->n_pairs, h->ctx->num_cu, s, h->d_pts[0], h->d_offs[0],
+                       h->d_pts[1], h->d_offs[1], h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_state, h->prm, h->d_corr, h->d_seed);
         hipLaunchKernelGGL(k_linearize, dim3(h->max_blocks, h->n_pairs), dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0],
                            h->d_cov[0], h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->d_corr, h->d_partial,
                            h->max_blocks);
