@@ -81,12 +81,36 @@ def cpu_baseline(scans, n_sample=8):
                      f"C Radon restatement (OpenMP over images), torch-CPU fast_corr ({cores} threads)",
            "ms_per_pair": {"bev": 1e3 * (t1 - t0) / len(sample), "radon": 1e3 * (t2 - t1) / len(sample),
                            "fft_corr": 1e3 * (t3 - t2) / len(sample)}}
+    out["gicp"] = cpu_gicp_baseline(cores)
     if O.ref_polar() is not None:   # the reference's own CPU polar rasteriser, unmodified
         t0 = time.perf_counter()
         for s in soas:
             O.ref_bev_polar(s, 1, 1, 40, 120, 20, 1)
         out["reference_polar_bev_scans_per_s"] = len(sample) / (time.perf_counter() - t0)
     return out
+
+
+def cpu_gicp_baseline(cores, iters=5):
+    """fast_gicp restatement (kd-tree + OpenMP, oracle/gicp_oracle.cpp) on ONE 120k x 120k pair of the GICP leg's
+    shape: `iters` forced outer iterations, k = 15, max_corr 5.0; covariances timed separately, like the GPU leg."""
+    from oracle import pyoracle as O
+    from scipy.spatial.transform import Rotation as Rot
+    rng = np.random.default_rng(2000)
+    p = synth.lidar_scan(500, N_POINTS, metric=True).astype(np.float64)
+    R = Rot.from_rotvec([0.01, -0.02, 0.04]).as_matrix()
+    src = (p + rng.normal(0, 0.02, p.shape)).astype(np.float32)
+    tgt = (p @ R.T + [0.4, -0.3, 0.05] + rng.normal(0, 0.02, p.shape)).astype(np.float32)
+    g = O.Gicp(k=15, max_corr=5.0, threads=cores)
+    t0 = time.perf_counter()
+    g.set_source(src); g.set_target(tgt)        # builds both kd-trees
+    t1 = time.perf_counter()
+    g.covariances(0); g.covariances(1)
+    t2 = time.perf_counter()
+    _, _, its, trials = g.align(np.eye(4), force_iters=iters)
+    t3 = time.perf_counter()
+    return {"iters_per_s": its / (t3 - t2), "iterations": its, "lm_trials": trials, "align_s": t3 - t2,
+            "covariance_clouds_per_s": 2 / (t2 - t1), "kdtree_build_s": t1 - t0, "cores": cores,
+            "sample": f"1 pair x 120k pts, {its} forced iterations, k=15, max_corr 5.0 (restated fast_gicp, kd-tree + OpenMP)"}
 
 
 def gicp_leg(device_index, rank, n_pairs, iters):
