@@ -476,11 +476,19 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_cov(const float4* __restrict
               float4 slo, shi;   // wave-level culling against the sub-tile's box (this wave: 64 consecutive Morton points)
               sub_box(sh, sb, slo, shi);
               if (!__any(live && box_point_d2(slo, shi, q.x, q.y, q.z) * 0.9999f <= dk[KMAX - 1])) continue;
-              const int u_end = min((sb + 1) * kSub, cnt);
-              for (int u = sb * kSub; u < u_end; ++u) {
-                const float d = dist2(q.x, q.y, q.z, sh.tile[u]);
-                if (d < dk[KMAX - 1]) {  // sorted insertion, static register indices
-                    const int j = t0 + u;
+              // 8 candidates at a time (padding candidates sit at +inf): one test per group once the list has warmed up
+              const int g_end = min((sb + 1) * (kSub / 8), (cnt + 7) >> 3);
+              for (int g = sb * (kSub / 8); g < g_end; ++g) {
+                float dd[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) dd[u] = dist2(q.x, q.y, q.z, sh.tile[8 * g + u]);
+                const float mn = fminf(fminf(fminf(dd[0], dd[1]), fminf(dd[2], dd[3])), fminf(fminf(dd[4], dd[5]), fminf(dd[6], dd[7])));
+                if (!(mn < dk[KMAX - 1])) continue;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                  const float d = dd[u];
+                  if (d < dk[KMAX - 1]) {  // sorted insertion, static register indices
+                    const int j = t0 + 8 * g + u;
 #pragma unroll
                     for (int s = KMAX - 1; s > 0; --s) {
                         const bool up = dk[s - 1] > d;
@@ -489,6 +497,7 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_cov(const float4* __restrict
                         ik[s] = up ? ik[s - 1] : (here ? j : ik[s]);
                     }
                     if (dk[0] > d) { dk[0] = d; ik[0] = j; }
+                  }
                 }
               }
             }
@@ -666,11 +675,19 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_features(const float4* __res
               float4 slo, shi;   // wave-level culling against the sub-tile's box
               sub_box(sh, sb, slo, shi);
               if (!__any(live && box_point_d2(slo, shi, q.x, q.y, q.z) * 0.9999f <= dk[KMAX - 1])) continue;
-              const int u_end = min((sb + 1) * kSub, cnt);
-              for (int u = sb * kSub; u < u_end; ++u) {
-                const float d = dist2(q.x, q.y, q.z, sh.tile[u]);
-                if (d < dk[KMAX - 1]) {
-                    const int j = t0 + u;
+              // 8 candidates at a time (padding candidates sit at +inf): one test per group once the list has warmed up
+              const int g_end = min((sb + 1) * (kSub / 8), (cnt + 7) >> 3);
+              for (int g = sb * (kSub / 8); g < g_end; ++g) {
+                float dd[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) dd[u] = dist2(q.x, q.y, q.z, sh.tile[8 * g + u]);
+                const float mn = fminf(fminf(fminf(dd[0], dd[1]), fminf(dd[2], dd[3])), fminf(fminf(dd[4], dd[5]), fminf(dd[6], dd[7])));
+                if (!(mn < dk[KMAX - 1])) continue;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                  const float d = dd[u];
+                  if (d < dk[KMAX - 1]) {
+                    const int j = t0 + 8 * g + u;
 #pragma unroll
                     for (int s = KMAX - 1; s > 0; --s) {
                         const bool up = dk[s - 1] > d;
@@ -679,6 +696,7 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_features(const float4* __res
                         ik[s] = up ? ik[s - 1] : (here ? j : ik[s]);
                     }
                     if (dk[0] > d) { dk[0] = d; ik[0] = j; }
+                  }
                 }
               }
             }
