@@ -287,16 +287,23 @@ __global__ void k_cloud_bbox(const float* __restrict__ src, int stride, const in
 #pragma unroll
         for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], p[a]); hi[a] = fmaxf(hi[a], p[a]); }
     }
+    // wave butterflies -> one partial per wave in LDS -> ONE set of atomics per workgroup (six hot addresses per cloud)
+    __shared__ float red[4][6];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         for (int s = 32; s > 0; s >>= 1) {
             lo[a] = fminf(lo[a], __shfl_xor(lo[a], s, 64));
             hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], s, 64));
         }
-        if ((threadIdx.x & 63) == 0) {
-            atomicMin(&bbox[6 * c + a], float_to_ordered(lo[a]));
-            atomicMax(&bbox[6 * c + 3 + a], float_to_ordered(hi[a]));
-        }
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][a] = lo[a]; red[threadIdx.x >> 6][3 + a] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int a = threadIdx.x;
+        if (a < 3)
+            atomicMin(&bbox[6 * c + a], float_to_ordered(fminf(fminf(red[0][a], red[1][a]), fminf(red[2][a], red[3][a]))));
+        else
+            atomicMax(&bbox[6 * c + a], float_to_ordered(fmaxf(fmaxf(red[0][a], red[1][a]), fmaxf(red[2][a], red[3][a]))));
     }
 }
 
@@ -1249,7 +1256,8 @@ __global__ __launch_bounds__(kNNThreads) void k_fitness(const float4* __restrict
                                                         const int* __restrict__ tgt_tile_base,
                                                         const float4* __restrict__ tlo, const float4* __restrict__ thi,
                                                         const double* __restrict__ poses /* [pairs][16] */,
-                                                        double max_range, double* __restrict__ partial, int max_blocks)
+                                                        double max_range, double* __restrict__ partial, int max_blocks,
+                                                        const int* __restrict__ nn_seed /* optional warm start */)
 {
     __shared__ ScanShared sh;
     __shared__ double red[kNNThreads / 64][2];
@@ -1283,9 +1291,11 @@ __global__ __launch_bounds__(kNNThreads) void k_fitness(const float4* __restrict
         }
         float best[kPts];
         int bidx[kPts];
-        const int no_seed[kPts] = {-1, -1, -1, -1};
+        int seed[kPts];   // the neighbours of the last alignment pass: valid upper bounds at any pose
+#pragma unroll
+        for (int p = 0; p < kPts; ++p) seed[p] = (nn_seed && live[p]) ? nn_seed[so + si[p]] : -1;
         __syncthreads();
-        nn_scan<kPts>(tgt, m, tb, maxc2, qx, qy, qz, live, sh, best, bidx, no_seed);
+        nn_scan<kPts>(tgt, m, tb, maxc2, qx, qy, qz, live, sh, best, bidx, seed);
 #pragma unroll
         for (int p = 0; p < kPts; ++p)
             if (live[p] && bidx[p] >= 0 && (double)best[p] <= max_range) { s += (double)best[p]; c += 1.0; }
@@ -1519,7 +1529,8 @@ int mrs_gicp_batch_set_clouds(mrs_gicp_batch* h, int32_t which, const float* d_p
         MRS_HIP_TRY(hipStreamSynchronize(s));  // `init`, `tile_base`, h_offsets are temporaries
     }
     const dim3 pg((unsigned)std::min<int64_t>((longest + 255) / 256, 1024), h->n_pairs);
-    hipLaunchKernelGGL(k_cloud_bbox, pg, dim3(256), 0, s, d_points, stride_floats, h->d_offs[which], bbox.as<int>());
+    hipLaunchKernelGGL(k_cloud_bbox, dim3(std::min(pg.x, 64u), pg.y), dim3(256), 0, s, d_points, stride_floats, h->d_offs[which],
+                       bbox.as<int>());
     hipLaunchKernelGGL(k_morton_keys, pg, dim3(256), 0, s, d_points, stride_floats, h->d_offs[which], bbox.as<int>(),
                        keys_in.as<unsigned long long>(), vals_in.as<int>());
     size_t tmp_bytes = 0;
@@ -1792,7 +1803,7 @@ int mrs_gicp_batch_fitness(mrs_gicp_batch* h, const double* h_poses, double max_
     MRS_HIP_TRY(hipMemsetAsync(part.p, 0, (size_t)h->n_pairs * h->max_blocks * 2 * sizeof(double), s));
     hipLaunchKernelGGL(k_fitness, dim3(h->max_blocks, h->n_pairs), dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0],
                        h->d_pts[1], h->d_offs[1], h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], poses.as<double>(), max_range,
-                       part.as<double>(), h->max_blocks);
+                       part.as<double>(), h->max_blocks, (const int*)h->d_seed);
     MRS_HIP_TRY(hipGetLastError());
     std::vector<double> hp((size_t)h->n_pairs * h->max_blocks * 2);
     MRS_HIP_TRY(hipMemcpyAsync(hp.data(), part.p, hp.size() * sizeof(double), hipMemcpyDeviceToHost, s));
