@@ -156,9 +156,9 @@ def test_force_iterations_and_failure_modes(dev):
         gicp.GicpBatch(1).align()               # no clouds set
 
 
-def test_full_size_pair(dev):
-    """BASELINE size (120k x 120k): recovers a known transform to the noise floor and the fitness
-    improves; brute-force NN needs no size-dependent structure."""
+def test_full_size_pair(dev, oracle):
+    """BASELINE size (120k x 120k): recovers a known transform to the noise floor, the fitness improves, and the
+    result is within the north_star tolerance of the restatement at full size too."""
     from mr_slam_amd import gicp
     src, tgt, Ttrue = _pair(9, 120000, (0.01, -0.02, 0.05), (0.5, -0.3, 0.05), noise=0.02)
     b = gicp.GicpBatch(1)
@@ -169,6 +169,12 @@ def test_full_size_pair(dev):
     f1 = b.fitness(T, 1.0)[0]
     dt, dr = _pose_err(T[0], Ttrue)
     assert conv[0] and dt < 5e-3 and dr < 5e-4 and f1 < f0
+    g = oracle.Gicp(k=20, max_corr=5.0)
+    g.set_source(src); g.set_target(tgt)
+    wT, wconv, wits, _ = g.align()
+    dt, dr = _pose_err(T[0], wT)
+    assert wconv and dt < TOL_T and dr < TOL_R, (dt, dr, its, wits)
+    assert abs(f1 - g.fitness(wT, 1.0)) < 1e-6
 
 
 @pytest.mark.parametrize("res,nb", [(0.5, 1), (0.5, 7), (1.0, 27)])
