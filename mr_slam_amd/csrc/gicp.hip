@@ -103,6 +103,7 @@ struct ScanShared {
     short order[kMaxOrder];
     float qlo[4][3], qhi[4][3];
     float sub[kSubs][2][6];               // per sub-tile and per half (one wave each): min xyz, max xyz
+    float mini[kTile / 16][6];            // per 16 consecutive candidates: min xyz, max xyz (third culling level)
 };
 
 __device__ __forceinline__ float box_point_d2(const float4& lo, const float4& hi, float x, float y, float z)
@@ -172,7 +173,17 @@ __device__ __forceinline__ void stage_tile(ScanShared& sh, const float4* __restr
         float b[6] = {c.x, c.y, c.z, in ? c.x : -INFINITY, in ? c.y : -INFINITY, in ? c.z : -INFINITY};
 #pragma unroll
         for (int a = 0; a < 3; ++a)
-            for (int o = 32; o > 0; o >>= 1) {
+            for (int o = 1; o < 16; o <<= 1) {
+                b[a] = fminf(b[a], __shfl_xor(b[a], o, 64));
+                b[3 + a] = fmaxf(b[3 + a], __shfl_xor(b[3 + a], o, 64));
+            }
+        if ((threadIdx.x & 15) == 0) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) sh.mini[i >> 4][a] = b[a];
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            for (int o = 16; o < 64; o <<= 1) {
                 b[a] = fminf(b[a], __shfl_xor(b[a], o, 64));
                 b[3 + a] = fmaxf(b[3 + a], __shfl_xor(b[3 + a], o, 64));
             }
@@ -237,18 +248,31 @@ __device__ __forceinline__ void nn_scan(const float4* __restrict__ tgt, int m, c
             for (int p = 0; p < P; ++p)
                 wneed |= live[p] && box_point_d2(slo, shi, qx[p], qy[p], qz[p]) * 0.9999f <= fminf(best[p], maxc2);
             if (!__any(wneed)) continue;
-            const int g_end = min((sb + 1) * (kSub / 8), (cnt + 7) >> 3);
-            for (int g = sb * (kSub / 8); g < g_end; ++g) {
-                float4 c[8];
+            const int mi_end = min((sb + 1) * (kSub / 16), (cnt + 15) >> 4);
+            for (int mi = sb * (kSub / 16); mi < mi_end; ++mi) {
+                // third level: 16 consecutive candidates against this wave's queries
+                float4 mlo, mhi;
+                mlo.x = sh.mini[mi][0]; mlo.y = sh.mini[mi][1]; mlo.z = sh.mini[mi][2];
+                mhi.x = sh.mini[mi][3]; mhi.y = sh.mini[mi][4]; mhi.z = sh.mini[mi][5];
+                bool mneed = false;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) c[u] = sh.tile[8 * g + u];
+                for (int p = 0; p < P; ++p)
+                    mneed |= live[p] && box_point_d2(mlo, mhi, qx[p], qy[p], qz[p]) * 0.9999f <= fminf(best[p], maxc2);
+                if (!__any(mneed)) continue;
 #pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    float d[8];
+                for (int h = 0; h < 2; ++h) {
+                    const int g = 2 * mi + h;
+                    float4 c[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) d[u] = dist2(qx[p], qy[p], qz[p], c[u]);
-                    const float mn = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])), fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
-                    if (mn < best[p]) { best[p] = mn; grp[p] = t0 + 8 * g; }
+                    for (int u = 0; u < 8; ++u) c[u] = sh.tile[8 * g + u];
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        float d[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) d[u] = dist2(qx[p], qy[p], qz[p], c[u]);
+                        const float mn = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])), fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
+                        if (mn < best[p]) { best[p] = mn; grp[p] = t0 + 8 * g; }
+                    }
                 }
             }
         }
