@@ -104,6 +104,7 @@ struct ScanShared {
     float qlo[4][3], qhi[4][3];
     float sub[kSubs][2][6];               // per sub-tile and per half (one wave each): min xyz, max xyz
     float mini[kTile / 16][6];            // per 16 consecutive candidates: min xyz, max xyz (third culling level)
+    float wbest[4];                       // per wave: largest current search radius^2 of its live queries
 };
 
 __device__ __forceinline__ float box_point_d2(const float4& lo, const float4& hi, float x, float y, float z)
@@ -225,10 +226,19 @@ __device__ __forceinline__ void nn_scan(const float4* __restrict__ tgt, int m, c
             if (seed[p] >= 0 && seed[p] < m) { best[p] = dist2(qx[p], qy[p], qz[p], tgt[seed[p]]); grp[p] = seed[p] & ~7; }
         }
     }
+    {   // the workgroup's largest search radius (warm-started queries: centimetres; otherwise maxc2): tiles are visited
+        // in ascending box distance, so the first tile beyond it ends the loop without any further barrier
+        float r = 0.0f;
+#pragma unroll
+        for (int p = 0; p < P; ++p) r = fmaxf(r, live[p] ? fminf(best[p], maxc2) : 0.0f);
+        for (int o = 32; o > 0; o >>= 1) r = fmaxf(r, __shfl_xor(r, o, 64));
+        if ((threadIdx.x & 63) == 0) sh.wbest[threadIdx.x >> 6] = r;
+    }
     order_tiles(sh, tb, maxc2, lo, hi);
+    const float reach = fmaxf(fmaxf(sh.wbest[0], sh.wbest[1]), fmaxf(sh.wbest[2], sh.wbest[3]));
     for (int k = 0; k < tb.ntiles; ++k) {
         const int t = k < kMaxOrder ? (int)sh.order[k] : k;
-        if (k < kMaxOrder && sh.lb[t] == INFINITY) break;  // this and every later tile: beyond maxc2
+        if (k < kMaxOrder && !(sh.lb[t] * 0.9999f <= reach)) break;  // this and every later tile: out of reach
         const float4 blo = tb.lo[t], bhi = tb.hi[t];
         bool need = false;
 #pragma unroll
