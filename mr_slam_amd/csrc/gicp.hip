@@ -474,6 +474,38 @@ __device__ void smallest_eigvec(const double* c, double* n_out)
     n_out[0] = v[s]; n_out[1] = v[3 + s]; n_out[2] = v[6 + s];
 }
 
+// sorted insertion into the KMAX nearest so far (static register indices)
+template <int KMAX>
+__device__ __forceinline__ void knn_insert(float (&dk)[KMAX], int (&ik)[KMAX], float d, int j)
+{
+#pragma unroll
+    for (int s = KMAX - 1; s > 0; --s) {
+        const bool up = dk[s - 1] > d;
+        const bool here = !up && dk[s] > d;
+        dk[s] = up ? dk[s - 1] : (here ? d : dk[s]);
+        ik[s] = up ? ik[s - 1] : (here ? j : ik[s]);
+    }
+    if (dk[0] > d) { dk[0] = d; ik[0] = j; }
+}
+
+// Seeds the list with the query's 64 neighbours along the Morton curve [home, home + 64): the k-th distance is
+// close to final before the first tile is scanned, which spares most of the insertions of a cold start.  The
+// tile scan then skips exactly that index range (no duplicates).
+constexpr int kHome = 64;
+template <int KMAX>
+__device__ __forceinline__ int knn_seed_home(const float4* __restrict__ pts, int n, int i, bool live, const float4& q,
+                                             float (&dk)[KMAX], int (&ik)[KMAX])
+{
+    const int home = max(0, min(i - kHome / 2, n - kHome));
+    for (int u = 0; u < kHome; ++u) {
+        const int j = home + u;
+        if (j >= n) break;             // n < kHome: wave-uniform
+        const float d = dist2(q.x, q.y, q.z, pts[live ? j : 0]);
+        if (live && d < dk[KMAX - 1]) knn_insert<KMAX>(dk, ik, d, j);
+    }
+    return home;
+}
+
 // G2: exact kNN (KMAX slots, the first k are used) + covariance + PLANE regularisation, on the
 // Morton-ordered cloud with tile culling (bound = the lane's current KMAX-th distance).
 // grid = (blocks, clouds); cloud c spans pts[offs[c] .. offs[c+1]).
@@ -502,6 +534,7 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_cov(const float4* __restrict
         int ik[KMAX];
 #pragma unroll
         for (int s = 0; s < KMAX; ++s) { dk[s] = INFINITY; ik[s] = -1; }
+        const int home = knn_seed_home<KMAX>(pts, n, i, live, q, dk, ik);
         float lo[3] = {live ? q.x : INFINITY, live ? q.y : INFINITY, live ? q.z : INFINITY};
         float hi[3] = {live ? q.x : -INFINITY, live ? q.y : -INFINITY, live ? q.z : -INFINITY};
         __syncthreads();  // previous round done with sh
@@ -520,6 +553,13 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_cov(const float4* __restrict
               // 8 candidates at a time (padding candidates sit at +inf): one test per group once the list has warmed up
               const int g_end = min((sb + 1) * (kSub / 8), (cnt + 7) >> 3);
               for (int g = sb * (kSub / 8); g < g_end; ++g) {
+                if ((g & 1) == 0) {   // third level: the 16 candidates of groups g, g + 1
+                    const int mi = g >> 1;
+                    float4 mlo, mhi;
+                    mlo.x = sh.mini[mi][0]; mlo.y = sh.mini[mi][1]; mlo.z = sh.mini[mi][2];
+                    mhi.x = sh.mini[mi][3]; mhi.y = sh.mini[mi][4]; mhi.z = sh.mini[mi][5];
+                    if (!__any(live && box_point_d2(mlo, mhi, q.x, q.y, q.z) * 0.9999f <= dk[KMAX - 1])) { ++g; continue; }
+                }
                 float dd[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) dd[u] = dist2(q.x, q.y, q.z, sh.tile[8 * g + u]);
@@ -528,17 +568,8 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_cov(const float4* __restrict
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                   const float d = dd[u];
-                  if (d < dk[KMAX - 1]) {  // sorted insertion, static register indices
-                    const int j = t0 + 8 * g + u;
-#pragma unroll
-                    for (int s = KMAX - 1; s > 0; --s) {
-                        const bool up = dk[s - 1] > d;
-                        const bool here = !up && dk[s] > d;
-                        dk[s] = up ? dk[s - 1] : (here ? d : dk[s]);
-                        ik[s] = up ? ik[s - 1] : (here ? j : ik[s]);
-                    }
-                    if (dk[0] > d) { dk[0] = d; ik[0] = j; }
-                  }
+                  const int j = t0 + 8 * g + u;
+                  if (d < dk[KMAX - 1] && (unsigned)(j - home) >= (unsigned)kHome) knn_insert<KMAX>(dk, ik, d, j);
                 }
               }
             }
@@ -701,6 +732,7 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_features(const float4* __res
         int ik[KMAX];
 #pragma unroll
         for (int s = 0; s < KMAX; ++s) { dk[s] = INFINITY; ik[s] = -1; }
+        const int home = knn_seed_home<KMAX>(pts, n, i, live, q, dk, ik);
         float lo[3] = {live ? q.x : INFINITY, live ? q.y : INFINITY, live ? q.z : INFINITY};
         float hi[3] = {live ? q.x : -INFINITY, live ? q.y : -INFINITY, live ? q.z : -INFINITY};
         __syncthreads();
@@ -719,6 +751,13 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_features(const float4* __res
               // 8 candidates at a time (padding candidates sit at +inf): one test per group once the list has warmed up
               const int g_end = min((sb + 1) * (kSub / 8), (cnt + 7) >> 3);
               for (int g = sb * (kSub / 8); g < g_end; ++g) {
+                if ((g & 1) == 0) {   // third level: the 16 candidates of groups g, g + 1
+                    const int mi = g >> 1;
+                    float4 mlo, mhi;
+                    mlo.x = sh.mini[mi][0]; mlo.y = sh.mini[mi][1]; mlo.z = sh.mini[mi][2];
+                    mhi.x = sh.mini[mi][3]; mhi.y = sh.mini[mi][4]; mhi.z = sh.mini[mi][5];
+                    if (!__any(live && box_point_d2(mlo, mhi, q.x, q.y, q.z) * 0.9999f <= dk[KMAX - 1])) { ++g; continue; }
+                }
                 float dd[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) dd[u] = dist2(q.x, q.y, q.z, sh.tile[8 * g + u]);
@@ -727,17 +766,8 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_features(const float4* __res
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                   const float d = dd[u];
-                  if (d < dk[KMAX - 1]) {
-                    const int j = t0 + 8 * g + u;
-#pragma unroll
-                    for (int s = KMAX - 1; s > 0; --s) {
-                        const bool up = dk[s - 1] > d;
-                        const bool here = !up && dk[s] > d;
-                        dk[s] = up ? dk[s - 1] : (here ? d : dk[s]);
-                        ik[s] = up ? ik[s - 1] : (here ? j : ik[s]);
-                    }
-                    if (dk[0] > d) { dk[0] = d; ik[0] = j; }
-                  }
+                  const int j = t0 + 8 * g + u;
+                  if (d < dk[KMAX - 1] && (unsigned)(j - home) >= (unsigned)kHome) knn_insert<KMAX>(dk, ik, d, j);
                 }
               }
             }
