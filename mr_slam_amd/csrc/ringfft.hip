@@ -171,7 +171,8 @@ __device__ __forceinline__ float2 load_spec(const __half2* p) { return __half22f
 // DBT = float2 (the database format) or __half2 (fp16 replicas received from other ranks).
 // Descriptors with C channels are [C][61][120]: |corr| is summed over channels and detectors
 // (fast_corr_RINGplusplus, RING_ros/util.py:337-358; C = 1: fast_corr, util.py:362-374).
-template <int NSLOT, bool QLDS, typename DBT>
+// PAIRWISE: candidate = query index (one per block row); MULTI: runtime channel count (else C = 1, no loop).
+template <int NSLOT, bool QLDS, bool PAIRWISE, bool MULTI, typename DBT>
 __global__ __launch_bounds__(NSLOT* kSlotThreads) void k_ring_corr_fft(const float2* __restrict__ Q, const DBT* __restrict__ DB,
                                                                        FftCorrP p, float* __restrict__ dist,
                                                                        int* __restrict__ angle, float* __restrict__ corr_out)
@@ -184,14 +185,14 @@ __global__ __launch_bounds__(NSLOT* kSlotThreads) void k_ring_corr_fft(const flo
     const int wave_in_slot = t >> 6, lane = t & 63;
     const int d = min(t, kD - 1);
     const bool live_col = t < kD;
-    const int C = p.channels;
+    const int C = MULTI ? p.channels : 1;
     const size_t entry = (size_t)C * kHalf * kD;
     const float2* qsrc = Q + (size_t)q * entry;
     if (QLDS) {
         for (int i = threadIdx.x; i < kHalf * kD; i += NSLOT * kSlotThreads) qs[i] = qsrc[i];
         __syncthreads();
     }
-    const int ncand = p.pairwise ? 1 : p.ndb;
+    const int ncand = PAIRWISE ? 1 : p.ndb;
     const int stride = gridDim.x * NSLOT;
     const int rounds = (ncand + stride - 1) / stride;
     for (int r = 0; r < rounds; ++r) {
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(NSLOT* kSlotThreads) void k_ring_corr_fft(const flo
         for (int c = 0; c < C; ++c) {
             float re[60], im[60];
             if (live) {
-                const DBT* b = DB + (size_t)(p.pairwise ? q : cand) * entry + (size_t)c * kHalf * kD + d;
+                const DBT* b = DB + (size_t)(PAIRWISE ? q : cand) * entry + (size_t)c * kHalf * kD + d;
                 const float2* a = qsrc + (size_t)c * kHalf * kD + d;
                 corr_irfft120([&](int k, float& ar, float& ai, float& br, float& bi) {
                     const float2 bv = load_spec(b + k * kD);
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(NSLOT* kSlotThreads) void k_ring_corr_fft(const flo
             // fftshift: shifted index m = (n + 60) % 120; first maximum in m order (util.py:367-371)
             const int n0 = 2 * lane, n1 = 2 * lane + 1;
             const int m0 = n0 < 60 ? n0 + 60 : n0 - 60, m1 = n1 < 60 ? n1 + 60 : n1 - 60;
-            const size_t o = (size_t)q * (p.pairwise ? 1 : p.ndb) + (p.pairwise ? 0 : cand);
+            const size_t o = (size_t)q * (PAIRWISE ? 1 : p.ndb) + (PAIRWISE ? 0 : cand);
             float best = -1.0f;
             int bm = 1 << 30;
             if (lane < 60) {
@@ -296,7 +297,12 @@ static int corr_fft_launch(mrs_ctx* ctx, const float* d_q, int32_t n_q, const vo
     const float2* q2 = reinterpret_cast<const float2*>(d_q);
     const DBT* db2 = reinterpret_cast<const DBT*>(d_db);
     if (pairwise) {
-        hipLaunchKernelGGL((k_ring_corr_fft<1, false, DBT>), dim3(1, n_q), dim3(kSlotThreads), 0, s, q2, db2, p, d_dist, d_angle, d_corr);
+        if (channels == 1)
+            hipLaunchKernelGGL((k_ring_corr_fft<1, false, true, false, DBT>), dim3(1, n_q), dim3(kSlotThreads), 0, s, q2, db2, p, d_dist,
+                               d_angle, d_corr);
+        else
+            hipLaunchKernelGGL((k_ring_corr_fft<1, false, true, true, DBT>), dim3(1, n_q), dim3(kSlotThreads), 0, s, q2, db2, p, d_dist,
+                               d_angle, d_corr);
     } else {
         int blocks = 2 * (ctx->num_cu > 0 ? ctx->num_cu : 256);
         if (n_q > 1) blocks = (blocks + n_q - 1) / n_q;
@@ -305,11 +311,11 @@ static int corr_fft_launch(mrs_ctx* ctx, const float* d_q, int32_t n_q, const vo
         if (blocks < 1) blocks = 1;
         if (channels == 1) {
             const size_t lds = (size_t)kHalf * kD * sizeof(float2);
-            auto kern = k_ring_corr_fft<NSLOT, true, DBT>;
+            auto kern = k_ring_corr_fft<NSLOT, true, false, false, DBT>;
             MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, dim3(blocks, n_q), dim3(NSLOT * kSlotThreads), lds, s, q2, db2, p, d_dist, d_angle, d_corr);
         } else {
-            hipLaunchKernelGGL((k_ring_corr_fft<NSLOT, false, DBT>), dim3(blocks, n_q), dim3(NSLOT * kSlotThreads), 0, s, q2, db2, p,
+            hipLaunchKernelGGL((k_ring_corr_fft<NSLOT, false, false, true, DBT>), dim3(blocks, n_q), dim3(NSLOT * kSlotThreads), 0, s, q2, db2, p,
                                d_dist, d_angle, d_corr);
         }
     }
