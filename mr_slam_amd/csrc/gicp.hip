@@ -1246,11 +1246,16 @@ __global__ void k_lm_update(LmState* __restrict__ st, const double* __restrict__
     LmState& S = st[pair];
     if (!S.active) return;
     __shared__ double sum[kTerms];
-    if (threadIdx.x < kTerms) {
-        double v = 0;
-        const double* p = partial + (size_t)pair * max_blocks * kTerms + threadIdx.x;
-        for (int b = 0; b < nblocks[pair]; ++b) v += p[(size_t)b * kTerms];  // fixed order
-        sum[threadIdx.x] = v;
+    {   // fixed-order (deterministic) final sum of the per-workgroup partials: lane l adds blocks l, l + 64, ...
+        // in ascending order, then one wave butterfly per term
+        const double* p = partial + (size_t)pair * max_blocks * kTerms;
+        const int nb = nblocks[pair];
+        for (int t = 0; t < kTerms; ++t) {
+            double v = 0;
+            for (int b = threadIdx.x; b < nb; b += 64) v += p[(size_t)b * kTerms + t];
+            v = wave_sum_d(v);
+            if (threadIdx.x == 0) sum[t] = v;
+        }
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
