@@ -17,10 +17,12 @@
 // (source, target) pair; at 120k x 120k the un-culled scan runs at ~95 % of the VALU issue peak.
 // Both clouds are stored in Morton order (rocPRIM radix sort at set_clouds time), so a tile of 1024
 // consecutive points is spatially compact and carries an axis-aligned bounding box: a workgroup
-// (1024 consecutive, i.e. equally compact, queries) visits the tiles in order of increasing
-// box-to-box distance and skips every tile whose box is farther than what all of its lanes already
-// have (or than max_correspondence_distance).  The culling is conservative, so the neighbours are
-// still the exact ones.  The scan is VALU-bound (7 lane-ops per surviving (source, target) pair);
+// (1024 consecutive, i.e. equally compact, queries; a wave owns 4 x 64 consecutive ones) visits the tiles
+// in order of increasing box-to-box distance, stops at the first tile beyond its largest search radius,
+// and inside a staged tile every wave skips the 128- and 16-candidate sub-tiles (boxes built while
+// staging) that none of its lanes can use.  Every query starts from the neighbour it had in the previous
+// pass (any target point is an upper bound).  The culling is conservative, so the neighbours are still
+// the exact ones.  The scan is VALU-bound (7 lane-ops per surviving (source, target) pair);
 // the per-point 3x3 algebra and the 28-term fp64 reductions (wave __shfl butterflies -> one
 // partial per workgroup -> fixed-order final sum) are noise next to it.  All pairs of a batch
 // advance together; the Levenberg-Marquardt bookkeeping runs on the device (one lane per
