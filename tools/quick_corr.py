@@ -45,3 +45,9 @@ for nq in (1, 4):
     print(f"RING++ direct sweep nq={nq} N={Np}: {ms:.3f} ms  {nq*Np/ms/1e3:.3f} Mpairs/s")
     ms = timeit(lambda: ring.corr_sweep_fft(sdbp[:nq].contiguous(), sdbp))
     print(f"RING++ fft sweep    nq={nq} N={Np}: {ms:.3f} ms  {nq*Np/ms/1e3:.3f} Mpairs/s  {nq*Np*C*58560/ms/1e6:.0f} GB/s")
+
+# fp16 replicas
+_, sdb16 = ring.half_spectrum_f16(db[:, 0])
+for nq in (1, 8):
+    ms = timeit(lambda: ring.corr_sweep_fft(sq[:nq], sdb16))
+    print(f"fft sweep f16 nq={nq} N={N}: {ms:.3f} ms  {nq*N/ms/1e3:.2f} Mpairs/s  {nq*N*29280/ms/1e6:.0f} GB/s")
