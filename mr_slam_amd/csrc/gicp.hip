@@ -840,8 +840,7 @@ __device__ __forceinline__ bool inv3_sym(const double* a, double* r)
 
 // G3a: exact 1-NN of every (float-)transformed source point (tile-culled brute force).
 // grid = (blocks, pairs).  Kept free of the fp64 algebra so that it runs at full occupancy.  P source points per
-// lane: 4 when the batch fills the chip (every LDS candidate read serves 4 distance evaluations), fewer for a
-// single pair so that its ~120 workgroups become ~470 (latency of one align() call).
+// lane: 2 in a batch, 1 for a single pair so that its ~235 workgroups become ~470 (see launch_nn_scan).
 // corr[so + i] = target index (sorted space), or -1 when d^2 >= max_corr^2.
 template <int P>
 __global__ __launch_bounds__(kNNThreads) void k_nn_scan(
@@ -1345,30 +1344,31 @@ __global__ __launch_bounds__(kNNThreads) void k_fitness(const float4* __restrict
     float Tf[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) Tf[i] = (float)poses[(size_t)pair * 16 + i];
-    const int per_block = kNNThreads * kPts;
+    constexpr int PF = 2;  // source points per lane (see launch_nn_scan); the grid-stride loop covers any grid
+    const int per_block = kNNThreads * PF;
     double s = 0, c = 0;
     for (int base = blockIdx.x * per_block; base < n; base += gridDim.x * per_block) {
-        float qx[kPts], qy[kPts], qz[kPts];
-        int si[kPts];
-        bool live[kPts];
+        float qx[PF], qy[PF], qz[PF];
+        int si[PF];
+        bool live[PF];
 #pragma unroll
-        for (int p = 0; p < kPts; ++p) {
-            si[p] = base + (threadIdx.x >> 6) * (64 * kPts) + p * 64 + (threadIdx.x & 63);
+        for (int p = 0; p < PF; ++p) {
+            si[p] = base + (threadIdx.x >> 6) * (64 * PF) + p * 64 + (threadIdx.x & 63);
             live[p] = si[p] < n;
             const float4 a = src[live[p] ? si[p] : 0];
             qx[p] = Tf[0] * a.x + Tf[1] * a.y + Tf[2] * a.z + Tf[3];
             qy[p] = Tf[4] * a.x + Tf[5] * a.y + Tf[6] * a.z + Tf[7];
             qz[p] = Tf[8] * a.x + Tf[9] * a.y + Tf[10] * a.z + Tf[11];
         }
-        float best[kPts];
-        int bidx[kPts];
-        int seed[kPts];   // the neighbours of the last alignment pass: valid upper bounds at any pose
+        float best[PF];
+        int bidx[PF];
+        int seed[PF];   // the neighbours of the last alignment pass: valid upper bounds at any pose
 #pragma unroll
-        for (int p = 0; p < kPts; ++p) seed[p] = (nn_seed && live[p]) ? nn_seed[so + si[p]] : -1;
+        for (int p = 0; p < PF; ++p) seed[p] = (nn_seed && live[p]) ? nn_seed[so + si[p]] : -1;
         __syncthreads();
-        nn_scan<kPts>(tgt, m, tb, maxc2, qx, qy, qz, live, sh, best, bidx, seed);
+        nn_scan<PF>(tgt, m, tb, maxc2, qx, qy, qz, live, sh, best, bidx, seed);
 #pragma unroll
-        for (int p = 0; p < kPts; ++p)
+        for (int p = 0; p < PF; ++p)
             if (live[p] && bidx[p] >= 0 && (double)best[p] <= max_range) { s += (double)best[p]; c += 1.0; }
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1446,14 +1446,16 @@ void free_cloud(mrs_gicp_batch* h, int w)
 
 int blocks_for_points(int n) { return (n + kNNThreads * kPts - 1) / (kNNThreads * kPts); }
 
+// Source points per lane in the NN scan.  Fewer points per wave = a more compact query set = sharper sub-tile
+// culling; more = every LDS candidate read serves more distance evaluations.  Measured (120k x 120k, MI355X):
+// 2 beats 4 at every batch size (23.5k vs 21.4k it/s at 256 pairs, 14.3k vs 11.1k at 16) and 1 only wins when a
+// single pair would otherwise leave most CUs idle.
 template <class... Args>
 void launch_nn_scan(int longest_src, int n_pairs, int num_cu, hipStream_t s, Args... args)
 {
     const int cus = num_cu > 0 ? num_cu : 256;
     auto wgs = [&](int P) { return (long)n_pairs * ((longest_src + kNNThreads * P - 1) / (kNNThreads * P)); };
-    if (wgs(4) >= 3L * cus)
-        hipLaunchKernelGGL(k_nn_scan<4>, dim3((unsigned)(wgs(4) / n_pairs), n_pairs), dim3(kNNThreads), 0, s, args...);
-    else if (wgs(2) >= 3L * cus)
+    if (wgs(2) >= 3L * cus)
         hipLaunchKernelGGL(k_nn_scan<2>, dim3((unsigned)(wgs(2) / n_pairs), n_pairs), dim3(kNNThreads), 0, s, args...);
     else
         hipLaunchKernelGGL(k_nn_scan<1>, dim3((unsigned)(wgs(1) / n_pairs), n_pairs), dim3(kNNThreads), 0, s, args...);
