@@ -354,6 +354,47 @@ __device__ __forceinline__ unsigned long long spread3(unsigned v)  // 14 bits ->
     return x;
 }
 
+// 42-bit Morton code of (x, y, z) on the cubic grid (origin lo, scale sc) of a cloud
+__device__ __forceinline__ unsigned long long morton42(float x, float y, float z, const float (&lo)[3], float sc)
+{
+    const float p[3] = {x, y, z};
+    unsigned q[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float v = (p[a] - lo[a]) * sc;
+        q[a] = v >= 0.0f ? (unsigned)fminf(v, 16383.0f) : 0u;  // NaN -> 0
+    }
+    return spread3(q[0]) | (spread3(q[1]) << 1) | (spread3(q[2]) << 2);
+}
+
+__device__ __forceinline__ float morton_grid(const int* __restrict__ bbox, int c, float (&lo)[3])
+{
+    float ext = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = ordered_to_float(bbox[6 * c + a]);
+        ext = fmaxf(ext, ordered_to_float(bbox[6 * c + 3 + a]) - lo[a]);
+    }
+    return ext > 0.0f ? 16383.0f / ext : 0.0f;
+}
+
+// Cold start of the NN scan: the target point whose Morton code is closest to the query's (binary search over the
+// Morton-ordered cloud, codes recomputed from the points) or its predecessor, whichever is nearer.  Any index is
+// a valid upper bound; this one is usually within a cell or two of the true neighbour.
+__device__ __forceinline__ int morton_seed(const float4* __restrict__ tgt, int m, float qx, float qy, float qz,
+                                           const float (&lo)[3], float sc)
+{
+    const unsigned long long key = morton42(qx, qy, qz, lo, sc);
+    int a = 0, b = m;  // first index with code >= key
+    while (a < b) {
+        const int mid = (a + b) >> 1;
+        const float4 t = tgt[mid];
+        if (morton42(t.x, t.y, t.z, lo, sc) < key) a = mid + 1; else b = mid;
+    }
+    const int j1 = min(a, m - 1), j0 = max(j1 - 1, 0);
+    return dist2(qx, qy, qz, tgt[j0]) < dist2(qx, qy, qz, tgt[j1]) ? j0 : j1;
+}
+
 // key = cloud id (high bits) | 42-bit Morton code on a cubic grid spanning the cloud's bounding box
 __global__ void k_morton_keys(const float* __restrict__ src, int stride, const int64_t* __restrict__ offs,
                               const int* __restrict__ bbox, unsigned long long* __restrict__ keys, int* __restrict__ vals)
@@ -361,22 +402,11 @@ __global__ void k_morton_keys(const float* __restrict__ src, int stride, const i
     const int c = blockIdx.y;
     const int64_t o = offs[c];
     const int n = (int)(offs[c + 1] - o);
-    float lo[3], ext = 0.0f;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        lo[a] = ordered_to_float(bbox[6 * c + a]);
-        ext = fmaxf(ext, ordered_to_float(bbox[6 * c + 3 + a]) - lo[a]);
-    }
-    const float sc = ext > 0.0f ? 16383.0f / ext : 0.0f;
+    float lo[3];
+    const float sc = morton_grid(bbox, c, lo);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float* p = src + (size_t)(o + i) * stride;
-        unsigned q[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float v = (p[a] - lo[a]) * sc;
-            q[a] = v >= 0.0f ? (unsigned)fminf(v, 16383.0f) : 0u;  // NaN -> 0
-        }
-        keys[o + i] = ((unsigned long long)c << 42) | spread3(q[0]) | (spread3(q[1]) << 1) | (spread3(q[2]) << 2);
+        keys[o + i] = ((unsigned long long)c << 42) | morton42(p[0], p[1], p[2], lo, sc);
         vals[o + i] = (int)(o + i);
     }
 }
@@ -847,7 +877,8 @@ __global__ __launch_bounds__(kNNThreads) void k_nn_scan(
     const float4* __restrict__ src_all, const int64_t* __restrict__ src_offs,
     const float4* __restrict__ tgt_all, const int64_t* __restrict__ tgt_offs,
     const int* __restrict__ tgt_tile_base, const float4* __restrict__ tlo, const float4* __restrict__ thi,
-    const LmState* __restrict__ st, GicpParams prm, int* __restrict__ corr, int* __restrict__ nn_seed)
+    const LmState* __restrict__ st, GicpParams prm, int* __restrict__ corr, int* __restrict__ nn_seed,
+    const int* __restrict__ tgt_bbox)
 {
     __shared__ ScanShared sh;
     const int pair = blockIdx.y;
@@ -865,6 +896,8 @@ __global__ __launch_bounds__(kNNThreads) void k_nn_scan(
     float Tf[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) Tf[i] = (float)S.xi[i];
+    float glo[3];
+    const float gsc = morton_grid(tgt_bbox, pair, glo);
     const int per_block = kNNThreads * P;
     for (int base = blockIdx.x * per_block; base < n; base += gridDim.x * per_block) {
         float qx[P], qy[P], qz[P];
@@ -880,6 +913,7 @@ __global__ __launch_bounds__(kNNThreads) void k_nn_scan(
             qy[p] = Tf[4] * a.x + Tf[5] * a.y + Tf[6] * a.z + Tf[7];
             qz[p] = Tf[8] * a.x + Tf[9] * a.y + Tf[10] * a.z + Tf[11];
             seed[p] = live[p] ? nn_seed[so + si[p]] : -1;   // last pass's nearest neighbour (the rejected ones too)
+            if (live[p] && seed[p] < 0 && m > 0) seed[p] = morton_seed(tgt, m, qx[p], qy[p], qz[p], glo, gsc);  // cold start
         }
         float best[P];
         int bidx[P];
@@ -1416,6 +1450,7 @@ struct mrs_gicp_batch {
     double* d_partial = nullptr;
     int* d_nblocks = nullptr;
     int* d_nactive = nullptr;
+    int* d_bbox[2] = {nullptr, nullptr};  // [n_pairs][6] bounding box of each cloud (ordered ints), the Morton grid
     int* d_corr = nullptr;          // [total source points] correspondences of the current evaluation
     int* d_seed = nullptr;          // [total source points] last nearest neighbour (warm start of the next NN pass)
     size_t n_seed = 0;
@@ -1437,10 +1472,11 @@ void free_cloud(mrs_gicp_batch* h, int w)
     if (h->d_pts[w]) (void)hipFree(h->d_pts[w]);
     if (h->d_cov[w]) (void)hipFree(h->d_cov[w]);
     if (h->d_tile_base[w]) (void)hipFree(h->d_tile_base[w]);
+    if (h->d_bbox[w]) (void)hipFree(h->d_bbox[w]);
     if (h->d_tlo[w]) (void)hipFree(h->d_tlo[w]);
     if (h->d_thi[w]) (void)hipFree(h->d_thi[w]);
     h->d_offs[w] = nullptr; h->d_pts[w] = nullptr; h->d_cov[w] = nullptr;
-    h->d_tile_base[w] = nullptr; h->d_tlo[w] = nullptr; h->d_thi[w] = nullptr;
+    h->d_tile_base[w] = nullptr; h->d_tlo[w] = nullptr; h->d_thi[w] = nullptr; h->d_bbox[w] = nullptr;
     h->cov_valid[w] = false;
 }
 
@@ -1587,9 +1623,10 @@ int mrs_gicp_batch_set_clouds(mrs_gicp_batch* h, int32_t which, const float* d_p
     MRS_HIP_TRY(hipMemcpyAsync(h->d_tile_base[which], tile_base.data(), h->n_pairs * sizeof(int), hipMemcpyHostToDevice, s));
 
     // Morton order: per-cloud bounding box -> 64-bit keys (cloud id | Morton code) -> stable radix sort
-    mrs::Scratch bbox, keys_in, keys_out, vals_in, vals_out, tmp;
-    int st = bbox.alloc((size_t)h->n_pairs * 6 * sizeof(int), s);
-    if (st != MRS_OK) return st;
+    mrs::Scratch keys_in, keys_out, vals_in, vals_out, tmp;
+    int st;
+    MRS_HIP_TRY(hipMalloc(&h->d_bbox[which], (size_t)h->n_pairs * 6 * sizeof(int)));
+    int* const bbox_p = h->d_bbox[which];
     if ((st = keys_in.alloc((size_t)total * 8, s)) != MRS_OK) return st;
     if ((st = keys_out.alloc((size_t)total * 8, s)) != MRS_OK) return st;
     if ((st = vals_in.alloc((size_t)total * 4, s)) != MRS_OK) return st;
@@ -1598,13 +1635,13 @@ int mrs_gicp_batch_set_clouds(mrs_gicp_batch* h, int32_t which, const float* d_p
         std::vector<int> init((size_t)h->n_pairs * 6);
         for (int i = 0; i < h->n_pairs; ++i)
             for (int a = 0; a < 3; ++a) { init[6 * i + a] = INT32_MAX; init[6 * i + 3 + a] = INT32_MIN; }
-        MRS_HIP_TRY(hipMemcpyAsync(bbox.p, init.data(), init.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        MRS_HIP_TRY(hipMemcpyAsync(bbox_p, init.data(), init.size() * sizeof(int), hipMemcpyHostToDevice, s));
         MRS_HIP_TRY(hipStreamSynchronize(s));  // `init`, `tile_base`, h_offsets are temporaries
     }
     const dim3 pg((unsigned)std::min<int64_t>((longest + 255) / 256, 1024), h->n_pairs);
     hipLaunchKernelGGL(k_cloud_bbox, dim3(std::min(pg.x, 64u), pg.y), dim3(256), 0, s, d_points, stride_floats, h->d_offs[which],
-                       bbox.as<int>());
-    hipLaunchKernelGGL(k_morton_keys, pg, dim3(256), 0, s, d_points, stride_floats, h->d_offs[which], bbox.as<int>(),
+                       bbox_p);
+    hipLaunchKernelGGL(k_morton_keys, pg, dim3(256), 0, s, d_points, stride_floats, h->d_offs[which], bbox_p,
                        keys_in.as<unsigned long long>(), vals_in.as<int>());
     size_t tmp_bytes = 0;
     MRS_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in.as<unsigned long long>(),
@@ -1781,7 +1818,7 @@ int mrs_gicp_batch_align(mrs_gicp_batch* h, const double* h_guess, double* h_fin
                                h->d_vmean, h->d_vcov, h->n_voxels, h->d_state, h->prm, h->d_partial, h->max_blocks);
         } else {
             launch_nn_scan(h->longest_src, h->n_pairs, h->ctx->num_cu, s, h->d_pts[0], h->d_offs[0], h->d_pts[1], h->d_offs[1],
-                           h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_state, h->prm, h->d_corr, h->d_seed);
+                           h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_state, h->prm, h->d_corr, h->d_seed, (const int*)h->d_bbox[1]);
             hipLaunchKernelGGL(k_linearize, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_cov[0],
                                h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->d_corr, h->d_partial, h->max_blocks);
         }
@@ -1832,7 +1869,7 @@ int mrs_gicp_batch_linearize(mrs_gicp_batch* h, const double* h_poses, double* h
                            h->max_blocks);
     } else {
         launch_nn_scan(h->longest_src, h->n_pairs, h->ctx->num_cu, s, h->d_pts[0], h->d_offs[0],
-                       h->d_pts[1], h->d_offs[1], h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_state, h->prm, h->d_corr, h->d_seed);
+                       h->d_pts[1], h->d_offs[1], h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_state, h->prm, h->d_corr, h->d_seed, (const int*)h->d_bbox[1]);
         hipLaunchKernelGGL(k_linearize, dim3(h->max_blocks, h->n_pairs), dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0],
                            h->d_cov[0], h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->d_corr, h->d_partial,
                            h->max_blocks);
