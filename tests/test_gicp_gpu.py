@@ -202,3 +202,33 @@ def test_vgicp_matches_restatement(dev, oracle, res, nb):
     dt, dr = _pose_err(T[0], wT)
     assert dt < TOL_T and dr < TOL_R and conv[0] == wconv
     assert _pose_err(T[0], Ttrue)[0] < 1e-2
+
+
+def test_degenerate_clouds_terminate_with_finite_results(dev):
+    """Inputs the reference never guards against (fewer points than k, one target point, identical / collinear /
+    duplicated points, NaNs, no correspondence in range): every call returns, transforms stay finite, and an
+    empty correspondence set scores like PCL's getFitnessScore (max double)."""
+    from mr_slam_amd import gicp
+    rng = np.random.default_rng(0)
+    plane = np.c_[rng.uniform(-5, 5, (3000, 2)), np.zeros(3000)]
+    line = np.c_[np.linspace(0, 10, 400), np.zeros(400), np.zeros(400)]
+    cases = [
+        (rng.normal(size=(5, 3)), rng.normal(size=(500, 3)), {}),
+        (rng.normal(size=(500, 3)), rng.normal(size=(1, 3)), {}),
+        (np.ones((300, 3)), np.ones((300, 3)), {}),
+        (line, line + [0.1, 0, 0], {}),
+        (plane, plane + [0.05, 0.02, 0], {}),
+        (rng.normal(size=(500, 3)), rng.normal(size=(500, 3)) + 1000, {"max_correspondence_distance": 1.0}),
+        (np.r_[rng.normal(size=(400, 3)), [[np.nan, 0, 0]]], rng.normal(size=(400, 3)), {}),
+        (np.repeat(rng.normal(size=(50, 3)), 20, 0), np.repeat(rng.normal(size=(50, 3)), 20, 0), {}),
+    ]
+    for i, (src, tgt, kw) in enumerate(cases):
+        b = gicp.GicpBatch(1)
+        b.set_params(**kw)
+        b.set_sources([src.astype(np.float32)]); b.set_targets([tgt.astype(np.float32)])
+        T, conv, its = b.align()
+        assert np.isfinite(T).all(), i
+        f = b.fitness(T, 1.0)[0]
+        assert f >= 0 and not np.isnan(f), i
+        if i == 5:
+            assert not conv[0] and f > 1e300
