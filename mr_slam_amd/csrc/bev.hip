@@ -6,9 +6,11 @@
 //   feat  : generate_bev_pointfeat_cython/src/kernel.cu:106-164
 //
 // Design (HBM-bound byte/integer work, no MFMA):
-//   * one workgroup (16 waves) per scan streams the three SoA planes with 16-byte loads and
-//     rasterises into an LDS-private grid (ds_max / ds_or), then writes the grid once,
-//     coalesced: HBM traffic = 12 B/point + 4 B/cell, no global atomics on the hot path;
+//   * one workgroup (16 waves) per scan streams the three SoA planes with non-temporal 16-byte loads
+//     and rasterises into an LDS-private grid (ds_max on the Cartesian max-z grid; an interleaved
+//     power-of-two occupancy bitset with read-before-ds_or for the polar one), then writes the grid
+//     once, coalesced: HBM traffic = 12 B/point + 4 B/cell, no global atomics on the hot path;
+//     the common case is ONE combined test per point (fast path), everything else re-evaluates exactly;
 //   * cell indices are bit-exact with the CPU reference, which evaluates atan/sqrt/div in
 //     double: each axis takes an fp32 fast path whose error is bounded far below `eps`
 //     bins, and any lane whose quotient lands within eps of a bin edge re-evaluates the
