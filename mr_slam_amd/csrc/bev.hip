@@ -286,7 +286,11 @@ __global__ __launch_bounds__(kWG) void k_cart_lds(const float* __restrict__ xyz,
         const float ex = 0.5f - fabsf((gx - fx) - 0.5f), ey = 0.5f - fabsf((gy - fy) - 0.5f);  // distance to a bin edge
         const bool fast = (bool)((int)(z > 0.0f) & (int)(z < 1.0f) & (int)(fmaxf(fabsf(x), fabsf(y)) <= 1.0f) & (int)(x * y != 0.0f) & (int)(fminf(ex, ey) >= eps));
         if (fast) {
-            atomicMax(&grid[(int)fy + (int)fx * NY], __float_as_int(z));
+            // consecutive lidar returns share cells: a plain read broadcasts where same-address atomics serialise,
+            // and most points do not raise the maximum
+            int* cell = &grid[(int)fy + (int)fx * NY];
+            const int zi = __float_as_int(z);
+            if (*cell < zi) atomicMax(cell, zi);
         } else if (z > 0.0f) {
             int col;
             const int lin = cart_lin(p, x, y, z, col);
