@@ -135,7 +135,9 @@ typedef struct mrs_radon_plan mrs_radon_plan;
  * (torch_radon/radon.py:139-167) for a fixed image size; volume centre 0, voxel size 1
  * (torch_radon/volumes.py:13-21), which is how every MR_SLAM call site uses it
  * (RING_ros/util.py:192-195,241-245).  h_angles: n_angles floats on the HOST (radians);
- * their cos/sin are evaluated once, in double, when the plan is built. */
+ * their cos/sin are evaluated once, in double, when the plan is built, together with the per-ray
+ * geometry table.  Images whose zero-bordered copy fits the LDS (up to ~190 x 190) take the LDS-resident
+ * kernel; larger ones run the same sample loop against a padded copy in global memory. */
 int mrs_radon_plan_create(mrs_ctx* ctx, const float* h_angles, int32_t n_angles, int32_t det_count,
                           float det_spacing, int32_t height, int32_t width, mrs_radon_plan** out_plan);
 int mrs_radon_plan_destroy(mrs_radon_plan* plan);

@@ -16,6 +16,7 @@
 // LDS array (79 % busy, 42 % of it bank conflicts: adjacent rays are 1-1.41 texels apart), not by HBM.
 // Numerics are shared with oracle/radon_oracle.c op for op (cos/sin evaluated on the host in
 // double when the plan is built), so HIP == oracle bit for bit.
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -25,6 +26,7 @@ struct mrs_radon_plan {
     mrs_ctx* ctx = nullptr;
     int n_angles = 0, det = 0, H = 0, W = 0;
     float spacing = 1.0f;
+    bool in_lds = true;      // the zero-bordered image fits the LDS (else: global-memory path)
     int* d_meta = nullptr;   // ray table, one allocation: meta | base | q | vm | n, each [n_angles*det]
 };
 
@@ -125,9 +127,11 @@ __device__ __forceinline__ float lds_at(unsigned addr) { return *(lds_fptr)(uint
 // (t0,t1)*(1-fr,fr) -> two running sums; both taps in one ds_read2_b32 whose immediate offsets absorb
 // the line advance of the unrolled samples.  The chain of each running sum is strictly sequential
 // (matches the oracle bit for bit).
-template <bool YDOM, int STRIDE>
-__device__ __forceinline__ float march(unsigned off, float q, float vm, int n_steps, int rstride)
+// GLOBAL: the padded image sits in global memory (images too large for the LDS); off is then a byte offset from gbase.
+template <bool YDOM, int STRIDE, bool GLOBAL = false>
+__device__ __forceinline__ float march(unsigned off, float q, float vm, int n_steps, int rstride, const char* gbase = nullptr)
 {
+    auto tap = [&](unsigned a) { return GLOBAL ? *reinterpret_cast<const float*>(gbase + a) : lds_at(a); };
     const int stride = STRIDE > 0 ? STRIDE : rstride;
     const int unit = (YDOM ? 1 : stride) * 4;   // bytes between the two taps == bytes per minor index
     const int lstep = (YDOM ? stride : 1) * 4;  // bytes per sample along the dominant axis
@@ -143,8 +147,8 @@ __device__ __forceinline__ float march(unsigned off, float q, float vm, int n_st
         for (int u = 0; u < U; ++u) {
             const float fr = __builtin_amdgcn_fractf(q);
             const unsigned a = (u < 3 ? off : off2) + (unsigned)minor_bytes<YDOM>((int)q, unit);
-            t[u].x = lds_at(a + (u % 3) * lstep);
-            t[u].y = lds_at(a + (u % 3) * lstep + unit);
+            t[u].x = tap(a + (u % 3) * lstep);
+            t[u].y = tap(a + (u % 3) * lstep + unit);
             w[u].x = 1.0f - fr;
             w[u].y = fr;
             q += vm;
@@ -158,8 +162,8 @@ __device__ __forceinline__ float march(unsigned off, float q, float vm, int n_st
         const float fr = __builtin_amdgcn_fractf(q);
         const unsigned a = off + (unsigned)minor_bytes<YDOM>((int)q, unit);
         v2f t, w;
-        t.x = lds_at(a);
-        t.y = lds_at(a + unit);
+        t.x = tap(a);
+        t.y = tap(a + unit);
         w.x = 1.0f - fr;
         w.y = fr;
         acc = __builtin_elementwise_fma(t, w, acc);
@@ -189,6 +193,18 @@ __device__ __forceinline__ double wave_sum(double v)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+
+// the same ray against a padded image in global memory (generic row stride)
+__device__ __forceinline__ float trace_ray_global(const float* padded, const RadonP& p, int ray)
+{
+    const int meta = p.meta[ray];
+    const int n_steps = meta & 0xffff;
+    if (n_steps == 0) return 0.0f;
+    const char* g = reinterpret_cast<const char*>(padded);
+    const float acc = (meta >> 16) ? march<true, 0, true>((unsigned)p.base[ray], p.q[ray], p.vm[ray], n_steps, p.stride, g)
+                                   : march<false, 0, true>((unsigned)p.base[ray], p.q[ray], p.vm[ray], n_steps, p.stride, g);
+    return acc * p.nrm[ray];
 }
 
 // One workgroup per image.  sino_raw / sino_norm may each be null.
@@ -279,6 +295,27 @@ __global__ __launch_bounds__(kRadonWG) void k_radon_big(const float* __restrict_
         sino_raw[(size_t)b * rays + ray] = trace_ray<0>(tile, p, ray);
 }
 
+// Images that do not fit the LDS (torch_radon.ParallelBeam takes any size; MR_SLAM itself only uses 120 x 120):
+// k_radon_pad builds the zero-bordered copy in global memory, k_radon_global traces the rays against it through L2.
+__global__ void k_radon_pad(const float* __restrict__ img, RadonP p, float* __restrict__ padded)
+{
+    const int b = blockIdx.y;
+    const size_t plane = (size_t)(p.H + 2 * kPad) * p.stride;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < p.H * p.W; i += gridDim.x * blockDim.x) {
+        const int y = i / p.W, x = i - y * p.W;
+        padded[b * plane + (size_t)(y + kPad) * p.stride + x + kPad] = img[(size_t)b * p.H * p.W + i];
+    }
+}
+
+__global__ void k_radon_global(const float* __restrict__ padded, RadonP p, float* __restrict__ sino_raw)
+{
+    const int b = blockIdx.y;
+    const size_t plane = (size_t)(p.H + 2 * kPad) * p.stride;
+    const int rays = p.A * p.D;
+    for (int ray = blockIdx.x * blockDim.x + threadIdx.x; ray < rays; ray += gridDim.x * blockDim.x)
+        sino_raw[(size_t)b * rays + ray] = trace_ray_global(padded + b * plane, p, ray);
+}
+
 // (x - mean) / std over `group` consecutive floats per block (unbiased std), in place or not.
 // util.py:339-340 (RING++ normalises a whole [C,H,W] descriptor with one mean/std).
 __global__ __launch_bounds__(1024) void k_normalize(const float* __restrict__ in, float* __restrict__ out, int group)
@@ -323,10 +360,7 @@ int mrs_radon_plan_create(mrs_ctx* ctx, const float* h_angles, int32_t n_angles,
     *out_plan = nullptr;
     const int stride = (width + 2 * kPad) | 1;
     const size_t lds = (size_t)(height + 2 * kPad) * stride * sizeof(float);
-    if (lds > ctx->lds_bytes) {
-        mrs::set_error("Radon image %dx%d does not fit the %zu-byte LDS tile", height, width, ctx->lds_bytes);
-        return MRS_ERR_UNSUPPORTED;
-    }
+    MRS_REQUIRE((size_t)(height + 2 * kPad) * stride * sizeof(float) < (1ull << 31), "image too large");
     MRS_HIP_TRY(hipSetDevice(ctx->device));
     MRS_REQUIRE(height + width < 60000, "image too large for the 16-bit step count");
     const size_t rays = (size_t)n_angles * det_count;
@@ -361,6 +395,7 @@ int mrs_radon_plan_create(mrs_ctx* ctx, const float* h_angles, int32_t n_angles,
     pl->ctx = ctx;
     pl->n_angles = n_angles; pl->det = det_count; pl->H = height; pl->W = width;
     pl->spacing = det_spacing;
+    pl->in_lds = lds <= ctx->lds_bytes;
     if (hipMalloc(&pl->d_meta, tab.size() * sizeof(int)) != hipSuccess ||
         hipMemcpy(pl->d_meta, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
         mrs::set_error("could not upload the ray table");
@@ -412,6 +447,23 @@ int mrs_radon_forward(mrs_radon_plan* plan, const float* d_img, int32_t batch, f
     hipStream_t s = (hipStream_t)stream;
     const int rays = p.A * p.D;
     const int per_lane = (rays + kRadonWG - 1) / kRadonWG;
+    if (!plan->in_lds) {
+        mrs::Scratch padded, tmp;
+        const size_t plane = (size_t)(p.H + 2 * kPad) * p.stride;
+        int st = padded.alloc((size_t)batch * plane * sizeof(float), s);
+        if (st != MRS_OK) return st;
+        MRS_HIP_TRY(hipMemsetAsync(padded.p, 0, (size_t)batch * plane * sizeof(float), s));
+        float* raw = d_sino;
+        if (!raw) {
+            if ((st = tmp.alloc((size_t)batch * rays * sizeof(float), s)) != MRS_OK) return st;
+            raw = tmp.as<float>();
+        }
+        hipLaunchKernelGGL(k_radon_pad, dim3(std::min((p.H * p.W + 255) / 256, 1024), batch), dim3(256), 0, s, d_img, p, padded.as<float>());
+        hipLaunchKernelGGL(k_radon_global, dim3(std::min((rays + 255) / 256, 4096), batch), dim3(256), 0, s, padded.as<float>(), p, raw);
+        if (d_sino_norm) hipLaunchKernelGGL(k_normalize, dim3(batch), dim3(1024), 0, s, raw, d_sino_norm, rays);
+        MRS_HIP_TRY(hipGetLastError());
+        return MRS_OK;
+    }
     if (per_lane <= 16) {
         auto kern = per_lane <= 15 ? (p.stride == 125 ? k_radon<15, 125> : k_radon<15, 0>) : k_radon<16, 0>;
         if (lds > 48 * 1024)
