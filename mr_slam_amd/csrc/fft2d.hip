@@ -233,31 +233,80 @@ __global__ __launch_bounds__(1024) void k_relori_argmax(const double2* __restric
 }
 
 // N4: nearest DiSCO signature (the role of the kd-tree of global_manager.cpp:993-1188 / src/kdtree.cpp):
-// exact brute-force squared-L2 1-NN; one workgroup per query, database streamed once per query.
-__global__ __launch_bounds__(256) void k_signature_nn(const float* __restrict__ q, const float* __restrict__ db, int n, int dim,
-                                                      int* __restrict__ out_idx, float* __restrict__ out_d2)
+// exact brute-force squared-L2 1-NN in the difference form sum (q - r)^2 (what an L2 kd-tree metric evaluates;
+// no |q|^2 + |r|^2 - 2 q.r cancellation).  Register-tiled like an SGEMM: a workgroup owns 64 queries x 64
+// database rows, every lane a 4 x 4 block of distances, the operands staged through LDS in slices of 16
+// dimensions (transposed, so that the inner loop reads two float4 per dimension for 16 sub+fma pairs); the
+// database is read once per 64 queries.  Winners are merged with a 64-bit atomicMin on (distance bits, index):
+// distances are >= 0, so their bit patterns order like the values and ties go to the smaller index.
+constexpr int kSigTile = 64, kSigSlice = 16;
+
+__global__ __launch_bounds__(256) void k_signature_tile(const float* __restrict__ q, int nq, const float* __restrict__ db, int n,
+                                                        int dim, unsigned long long* __restrict__ best)
 {
-    __shared__ float bv[4];
-    __shared__ int bi[4];
-    const float* qq = q + (size_t)blockIdx.x * dim;
-    float best = INFINITY;
-    int bidx = 0x7fffffff;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int j = wave; j < n; j += 4) {          // one wave per database row, lanes stride the dimension
-        const float* r = db + (size_t)j * dim;
-        float acc = 0.0f;
-        for (int c = lane; c < dim; c += 64) { const float d = qq[c] - r[c]; acc = __builtin_fmaf(d, d, acc); }
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (acc < best) { best = acc; bidx = j; }
+    __shared__ __attribute__((aligned(16))) float qs[kSigSlice][kSigTile];
+    __shared__ __attribute__((aligned(16))) float rs[kSigSlice][kSigTile];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int r0 = blockIdx.x * kSigTile, q0 = blockIdx.y * kSigTile;
+    const int lrow = threadIdx.x >> 2, lc = (threadIdx.x & 3) * 4;   // staging: row lrow of the tile, 4 consecutive dimensions
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0f;
+    for (int c0 = 0; c0 < dim; c0 += kSigSlice) {
+        float qv[4], rv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = c0 + lc + e;
+            qv[e] = (q0 + lrow < nq && c < dim) ? q[(size_t)(q0 + lrow) * dim + c] : 0.0f;
+            rv[e] = (r0 + lrow < n && c < dim) ? db[(size_t)(r0 + lrow) * dim + c] : 0.0f;
+        }
+        __syncthreads();   // previous slice consumed
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { qs[lc + e][lrow] = qv[e]; rs[lc + e][lrow] = rv[e]; }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < kSigSlice; ++c) {
+            const float4 qa = *reinterpret_cast<const float4*>(&qs[c][4 * ty]);
+            const float4 rb = *reinterpret_cast<const float4*>(&rs[c][4 * tx]);
+            const float qe[4] = {qa.x, qa.y, qa.z, qa.w}, re[4] = {rb.x, rb.y, rb.z, rb.w};
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float d = qe[a] - re[b];
+                    acc[a][b] = __builtin_fmaf(d, d, acc[a][b]);
+                }
+        }
     }
-    if (lane == 0) { bv[wave] = best; bi[wave] = bidx; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w)
-            if (bv[w] < best || (bv[w] == best && bi[w] < bidx)) { best = bv[w]; bidx = bi[w]; }
-        out_idx[blockIdx.x] = bidx;
-        out_d2[blockIdx.x] = best;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        unsigned long long key = ~0ull;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int row = r0 + 4 * tx + b;
+            if (row < n) {
+                const unsigned long long k = ((unsigned long long)__float_as_uint(acc[a][b]) << 32) | (unsigned)row;
+                key = k < key ? k : key;
+            }
+        }
+        for (int o = 1; o < 16; o <<= 1) {   // the 16 lanes that share this query are consecutive
+            const unsigned long long other = __shfl_xor(key, o, 64);
+            key = other < key ? other : key;
+        }
+        const int qi = q0 + 4 * ty + a;
+        if (tx == 0 && qi < nq && key != ~0ull) atomicMin(&best[qi], key);
     }
+}
+
+__global__ void k_signature_unpack(const unsigned long long* __restrict__ best, int nq, int* __restrict__ out_idx,
+                                   float* __restrict__ out_d2)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    out_idx[i] = (int)(unsigned)(best[i] & 0xffffffffull);
+    out_d2[i] = __uint_as_float((unsigned)(best[i] >> 32));
 }
 
 inline int grid_for(size_t n) { size_t b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b ? b : 1)); }
@@ -373,7 +422,15 @@ int mrs_signature_search(mrs_ctx* ctx, const float* d_query, int32_t n_query, co
     MRS_REQUIRE(ctx && d_query && d_db && d_index && d_dist2, "null pointer");
     MRS_REQUIRE(n_query > 0 && n_db > 0 && dim > 0, "sizes must be positive");
     MRS_HIP_TRY(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_signature_nn, dim3(n_query), dim3(256), 0, (hipStream_t)stream, d_query, d_db, n_db, dim, d_index, d_dist2);
+    hipStream_t s = (hipStream_t)stream;
+    mrs::Scratch best;
+    int st = best.alloc((size_t)n_query * sizeof(unsigned long long), s);
+    if (st != MRS_OK) return st;
+    MRS_HIP_TRY(hipMemsetAsync(best.p, 0xff, (size_t)n_query * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(k_signature_tile, dim3((n_db + kSigTile - 1) / kSigTile, (n_query + kSigTile - 1) / kSigTile), dim3(256), 0, s,
+                       d_query, n_query, d_db, n_db, dim, best.as<unsigned long long>());
+    hipLaunchKernelGGL(k_signature_unpack, dim3((n_query + 255) / 256), dim3(256), 0, s, best.as<unsigned long long>(), n_query,
+                       d_index, d_dist2);
     MRS_HIP_TRY(hipGetLastError());
     return MRS_OK;
 }

@@ -110,6 +110,13 @@ def test_mapping_side_calc_rel_ori_and_signature_search(dev):
     np.testing.assert_array_equal(idx.cpu().numpy(), pick)
     want = ((qn[:, None, :].astype(np.float64) - dbn[None]) ** 2).sum(-1).min(1)
     np.testing.assert_allclose(d2.cpu().numpy(), want, rtol=1e-5)
+    # ragged sizes (tiles of 64 x 64 x 16 inside): odd dimension, database / query counts off the tile grid
+    dbr = rng.normal(size=(777, 37)).astype(np.float32)
+    qr = rng.normal(size=(130, 37)).astype(np.float32)
+    idx, d2 = disco.signature_search(torch.from_numpy(qr).to(dev), torch.from_numpy(dbr).to(dev))
+    full = ((qr[:, None, :].astype(np.float64) - dbr[None]) ** 2).sum(-1)
+    np.testing.assert_array_equal(idx.cpu().numpy(), full.argmin(1))
+    np.testing.assert_allclose(d2.cpu().numpy(), full.min(1), rtol=1e-5)
     # rotation invariance of the DiSCO signature: all three rotated copies are (near-)zero distance apart
     _, d2r = disco.signature_search(sig, sig[:1].contiguous())
     assert float(d2r.max()) < 1e-3 * float((sig ** 2).sum(1).max())
