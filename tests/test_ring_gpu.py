@@ -302,3 +302,40 @@ def test_ringpp_fft_domain_matches_restatement(dev):
     d1, a1 = ring.fast_corr_RINGplusplus(q[0], db[1], device=dev)     # the drop-in, now on the FFT-domain kernel
     assert abs(float(d1) - float(K.fast_corr_ringplusplus(q[0], db[1])[0])) < 1e-5 and int(a1) == -13
     # throughput note (not asserted): see bench.py sweep leg
+
+
+def test_bench_sized_batch_is_deterministic_and_matches_oracle_samples(dev, oracle):
+    """The bench.py step at its real size (512 scans x 120k points): two runs are bitwise identical, sampled
+    entries are bit-exact with the restatements (BEV, sinogram), every self-pair scores the same distance with
+    angle 0, and pairing each scan with its neighbour is symmetric in distance and antisymmetric in angle."""
+    import torch
+    from mr_slam_amd import bev, ring, synth
+    B = 512
+    base = [synth.lidar_scan(s) for s in range(8)]
+    xyz, offs = bev.pack_scans([base[i % 8] for i in range(B)], dev)
+    plan = ring.ring_plan(0)
+
+    def run():
+        img = bev.cart_bev(xyz, offs, 1, 1, 120, 120, 1)
+        raw, norm = plan.forward(img.view(B, 120, 120), raw=True, normalized=True)
+        spec = ring.half_spectrum(norm)
+        d, a = ring.corr_pairs_fft(spec, spec.roll(1, 0).contiguous())
+        return img, raw, norm, spec, d, a
+
+    r1, r2 = run(), run()
+    for x, y in zip(r1, r2):
+        assert torch.equal(x, y)
+    img, raw, norm, spec, d, a = r1
+    ang = np.linspace(0, 2 * np.pi, 120).astype(np.float32)
+    for i in (0, 3, 257, 511):
+        want = oracle.bev_cart(synth.to_soa(base[i % 8]), 1, 1, 120, 120, 1).reshape(-1, 3)[:, 2].reshape(120, 120)
+        np.testing.assert_array_equal(img[i].cpu().numpy().reshape(120, 120), want)
+        np.testing.assert_array_equal(raw[i].cpu().numpy(), oracle.radon_parallel(want, ang, 120, 1.0))
+    ds, as_ = ring.corr_pairs_fft(spec, spec)
+    assert int(as_.abs().max()) == 0
+    # scans repeat with period 8, so entry i and i + 8 are the same scan: identical results
+    assert torch.equal(d[8:], d[:-8]) and torch.equal(a[8:], a[:-8])
+    d_rev, a_rev = ring.corr_pairs_fft(spec.roll(1, 0).contiguous(), spec)
+    assert float((d - d_rev).abs().max()) < 1e-6
+    clear = (d < 0.9 * float(d.max()))        # a clear peak: the reversed pair must report the opposite rotation
+    assert int(((a + a_rev) % 120)[clear].abs().max() if clear.any() else 0) == 0
