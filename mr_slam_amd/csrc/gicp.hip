@@ -240,7 +240,11 @@ __device__ __forceinline__ void nn_scan(const float4* __restrict__ tgt, int m, c
     const float reach = fmaxf(fmaxf(sh.wbest[0], sh.wbest[1]), fmaxf(sh.wbest[2], sh.wbest[3]));
     for (int k = 0; k < tb.ntiles; ++k) {
         const int t = k < kMaxOrder ? (int)sh.order[k] : k;
-        if (k < kMaxOrder && !(sh.lb[t] * 0.9999f <= reach)) break;  // this and every later tile: out of reach
+        if (k < kMaxOrder && !(sh.lb[t] * 0.9999f <= reach)) {  // this and every later ORDERED tile: out of reach
+            if (tb.ntiles <= kMaxOrder) break;
+            k = kMaxOrder - 1;  // clouds beyond kMaxOrder tiles: the tail is not ordered, test every tile of it
+            continue;
+        }
         const float4 blo = tb.lo[t], bhi = tb.hi[t];
         bool need = false;
 #pragma unroll

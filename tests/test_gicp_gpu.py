@@ -232,3 +232,25 @@ def test_degenerate_clouds_terminate_with_finite_results(dev):
         assert f >= 0 and not np.isnan(f), i
         if i == 5:
             assert not conv[0] and f > 1e300
+
+
+def test_cloud_beyond_the_ordered_tile_window(dev, oracle):
+    """More than 512 tiles of 1024 points per cloud: the tiles past the distance-ordered window are still visited
+    (neighbours stay exact)."""
+    from mr_slam_amd import gicp, synth
+    rng = np.random.default_rng(5)
+    base = np.concatenate([synth.lidar_scan(60 + i, 120000, metric=True) + [0.0, 0.0, 0.001 * i] for i in range(5)]).astype(np.float64)
+    base = base[rng.permutation(base.shape[0])[:560000]]
+    R = Rot.from_rotvec([0.004, -0.003, 0.01]).as_matrix()
+    src = (base + rng.normal(0, 0.01, base.shape)).astype(np.float32)
+    tgt = (base @ R.T + [0.15, -0.1, 0.02] + rng.normal(0, 0.01, base.shape)).astype(np.float32)
+    b = gicp.GicpBatch(1)
+    b.set_params(max_correspondence_distance=2.0)
+    b.set_sources([src]); b.set_targets([tgt])
+    T = np.eye(4)
+    e, H, bb, corr = b.linearize(T[None], want_corr=True)
+    g = oracle.Gicp(k=20, max_corr=2.0)
+    g.set_source(src); g.set_target(tgt)
+    we, wH, wb, wcorr = g.linearize(T)
+    assert (corr == wcorr).mean() > 0.9995 and (wcorr >= 0).mean() > 0.9
+    assert abs(e[0] - we) < 2e-3 * abs(we)
