@@ -805,6 +805,7 @@ int mrs_bev_polar_batch(mrs_ctx* ctx, const float* d_xyz, const int64_t* d_offse
     st = kidx.alloc(slots * sizeof(int), s);
     if (st != MRS_OK) return st;
     hipLaunchKernelGGL(k_fill_i32, dim3(blocks_for(slots, 256, 4096)), dim3(256), 0, s, kidx.as<int>(), slots, INT_MAX);
+    MRS_REQUIRE(batch <= mrs::kMaxGridY, "at most 65535 scans per call in this layout (split the batch)");
     const dim3 pg(512, batch);
     for (int k = 0; k < p.K; ++k)
         hipLaunchKernelGGL(k_polar_kth, pg, dim3(256), 0, s, d_xyz, d_offsets, p, k, kidx.as<int>());
@@ -848,6 +849,7 @@ int mrs_bev_cart_batch(mrs_ctx* ctx, const float* d_xyz, const int64_t* d_offset
     hipLaunchKernelGGL(k_fill_i32, dim3(fb), dim3(256), 0, s, last_idx, tot, -1);
     hipLaunchKernelGGL(k_fill_i32, dim3(fb), dim3(256), 0, s, zbits, tot, 0);
     if (first_pos) hipLaunchKernelGGL(k_fill_i32, dim3(fb), dim3(256), 0, s, first_pos, tot, INT_MAX);
+    MRS_REQUIRE(batch <= mrs::kMaxGridY, "at most 65535 scans per call in this layout (split the batch)");
     const dim3 pg(512, batch);
     hipLaunchKernelGGL(k_cart_pass1, pg, dim3(256), 0, s, d_xyz, d_offsets, p, last_idx, zbits, first_pos);
     if (first_pos) hipLaunchKernelGGL(k_cart_pass2, pg, dim3(256), 0, s, d_xyz, d_offsets, p, first_pos, zbits);
@@ -881,6 +883,7 @@ int mrs_bev_feat_batch(mrs_ctx* ctx, const float* d_pts, const int64_t* d_offset
     const size_t tot = (size_t)batch * cells * (layout == MRS_BEV_OUT_COMPACT ? p.F - 3 : p.F);
     // positive floats order like ints: accumulate straight into the output buffer
     MRS_HIP_TRY(hipMemsetAsync(d_out, 0, tot * sizeof(float), s));
+    MRS_REQUIRE(batch <= mrs::kMaxGridY, "at most 65535 scans per call in this layout (split the batch)");
     const dim3 pg(512, batch);
     if (layout == MRS_BEV_OUT_COMPACT)
         hipLaunchKernelGGL(k_feat_max<true>, pg, dim3(256), 0, s, d_pts, d_offsets, p, reinterpret_cast<int*>(d_out));

@@ -13,6 +13,8 @@
 #include "../../include/mrslam_hip.h"
 
 namespace mrs {
+constexpr int kMaxGridY = 65535;  // HIP grid limit in y: entry points that put the batch there check or chunk
+
 
 void set_error(const char* fmt, ...);
 

@@ -1524,6 +1524,7 @@ int mrs_gicp_batch_create(mrs_ctx* ctx, int32_t n_pairs, mrs_gicp_batch** out)
 {
     MRS_REQUIRE(ctx && out, "null pointer");
     MRS_REQUIRE(n_pairs > 0, "n_pairs must be positive");
+    MRS_REQUIRE(n_pairs <= mrs::kMaxGridY, "at most 65535 pairs per batch (create several batches)");
     *out = nullptr;
     MRS_HIP_TRY(hipSetDevice(ctx->device));
     mrs_gicp_batch* h = new mrs_gicp_batch();

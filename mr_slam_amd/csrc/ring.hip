@@ -16,6 +16,7 @@
 // per 15 FMA).  HBM bytes per pair = C*A*D*4.
 // The literal spectral form (any complex input, k_corr_spectra) backs the drop-in
 // fast_corr(a, b) signature.
+#include <algorithm>
 #include <cmath>
 
 #include "common.hpp"
@@ -399,8 +400,14 @@ static int corr_launch(mrs_ctx* ctx, const float* d_query, int32_t n_query, cons
     if (n_query > 1) blocks = (blocks + n_query - 1) / n_query;
     if (blocks > n_db) blocks = n_db;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_ring_corr, dim3(blocks, n_query), dim3(kWG), lds, (hipStream_t)stream, d_query, d_db, p,
-                       d_dist, d_angle, d_corr);
+    const size_t entry = (size_t)channels * n_angles * det;
+    for (int q0 = 0; q0 < n_query; q0 += mrs::kMaxGridY) {   // grid.y is limited to 65535 rows
+        const int nq = std::min(n_query - q0, mrs::kMaxGridY);
+        p.nq = nq;
+        const size_t ro = (size_t)q0 * (pairwise ? 1 : n_db);
+        hipLaunchKernelGGL(k_ring_corr, dim3(blocks, nq), dim3(kWG), lds, (hipStream_t)stream, d_query + q0 * entry,
+                           pairwise ? d_db + q0 * entry : d_db, p, d_dist + ro, d_angle + ro, d_corr ? d_corr + ro * n_angles : nullptr);
+    }
     MRS_HIP_TRY(hipGetLastError());
     return MRS_OK;
 }

@@ -14,6 +14,7 @@
 // (64 M pairs/s = 3.8 TB/s); with several queries per launch the database is fetched once (L2 shares it
 // between the query rows) and the in-register FFT (VALU) binds at ~90-100 M pairs/s.  RING++ descriptors
 // ([C][61][120]) run the same code in a channel loop; fp16 replicas of the database are accepted as well.
+#include <algorithm>
 #include <cmath>
 
 #include <hip/hip_fp16.h>
@@ -299,27 +300,38 @@ static int corr_fft_launch(mrs_ctx* ctx, const float* d_q, int32_t n_q, const vo
     hipStream_t s = (hipStream_t)stream;
     const float2* q2 = reinterpret_cast<const float2*>(d_q);
     const DBT* db2 = reinterpret_cast<const DBT*>(d_db);
-    if (pairwise) {
-        if (channels == 1)
-            hipLaunchKernelGGL((k_ring_corr_fft<1, false, true, false, DBT>), dim3(1, n_q), dim3(kSlotThreads), 0, s, q2, db2, p, d_dist,
-                               d_angle, d_corr);
-        else
-            hipLaunchKernelGGL((k_ring_corr_fft<1, false, true, true, DBT>), dim3(1, n_q), dim3(kSlotThreads), 0, s, q2, db2, p, d_dist,
-                               d_angle, d_corr);
-    } else {
-        int blocks = 2 * (ctx->num_cu > 0 ? ctx->num_cu : 256);
-        if (n_q > 1) blocks = (blocks + n_q - 1) / n_q;
-        const int need = (n_db + NSLOT - 1) / NSLOT;
-        if (blocks > need) blocks = need;
-        if (blocks < 1) blocks = 1;
-        if (channels == 1) {
-            const size_t lds = (size_t)kHalf * kD * sizeof(float2);
-            auto kern = k_ring_corr_fft<NSLOT, true, false, false, DBT>;
-            MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3(blocks, n_q), dim3(NSLOT * kSlotThreads), lds, s, q2, db2, p, d_dist, d_angle, d_corr);
+    const size_t entry = (size_t)channels * kHalf * kD;
+    for (int q0 = 0; q0 < n_q; q0 += mrs::kMaxGridY) {   // grid.y is limited to 65535 rows
+        const int nq = std::min(n_q - q0, mrs::kMaxGridY);
+        p.nq = nq;
+        const size_t ro = (size_t)q0 * (pairwise ? 1 : n_db);
+        const float2* qq = q2 + q0 * entry;
+        const DBT* dd = pairwise ? db2 + q0 * entry : db2;
+        float* dist_c = d_dist + ro;
+        int32_t* angle_c = d_angle + ro;
+        float* corr_c = d_corr ? d_corr + ro * kA : nullptr;
+        if (pairwise) {
+            if (channels == 1)
+                hipLaunchKernelGGL((k_ring_corr_fft<1, false, true, false, DBT>), dim3(1, nq), dim3(kSlotThreads), 0, s, qq, dd, p, dist_c,
+                                   angle_c, corr_c);
+            else
+                hipLaunchKernelGGL((k_ring_corr_fft<1, false, true, true, DBT>), dim3(1, nq), dim3(kSlotThreads), 0, s, qq, dd, p, dist_c,
+                                   angle_c, corr_c);
         } else {
-            hipLaunchKernelGGL((k_ring_corr_fft<NSLOT, false, false, true, DBT>), dim3(blocks, n_q), dim3(NSLOT * kSlotThreads), 0, s, q2, db2, p,
-                               d_dist, d_angle, d_corr);
+            int blocks = 2 * (ctx->num_cu > 0 ? ctx->num_cu : 256);
+            if (n_q > 1) blocks = (blocks + n_q - 1) / n_q;
+            const int need = (n_db + NSLOT - 1) / NSLOT;
+            if (blocks > need) blocks = need;
+            if (blocks < 1) blocks = 1;
+            if (channels == 1) {
+                const size_t lds = (size_t)kHalf * kD * sizeof(float2);
+                auto kern = k_ring_corr_fft<NSLOT, true, false, false, DBT>;
+                MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, dim3(blocks, nq), dim3(NSLOT * kSlotThreads), lds, s, qq, dd, p, dist_c, angle_c, corr_c);
+            } else {
+                hipLaunchKernelGGL((k_ring_corr_fft<NSLOT, false, false, true, DBT>), dim3(blocks, nq), dim3(NSLOT * kSlotThreads), 0, s, qq, dd, p,
+                                   dist_c, angle_c, corr_c);
+            }
         }
     }
     MRS_HIP_TRY(hipGetLastError());

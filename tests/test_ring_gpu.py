@@ -339,3 +339,24 @@ def test_bench_sized_batch_is_deterministic_and_matches_oracle_samples(dev, orac
     assert float((d - d_rev).abs().max()) < 1e-6
     clear = (d < 0.9 * float(d.max()))        # a clear peak: the reversed pair must report the opposite rotation
     assert int(((a + a_rev) % 120)[clear].abs().max() if clear.any() else 0) == 0
+
+
+def test_more_pairs_than_one_grid_dimension(dev):
+    """70 000 pairs in one call (HIP limits grid.y to 65 535): the entry point chunks; every pair still gets its result."""
+    import torch
+    from mr_slam_amd import ring
+    g = torch.Generator(device=dev).manual_seed(3)
+    base = ring.half_spectrum(ring.normalize(torch.randn((64, 120, 120), device=dev, generator=g)))
+    P = 70000
+    idx = torch.arange(P, device=dev) % 64
+    a = base[idx].contiguous()
+    b = base[(idx + 1) % 64].contiguous()
+    d, ang = ring.corr_pairs_fft(a, b)
+    d64, a64 = ring.corr_pairs_fft(base, base.roll(-1, 0).contiguous())
+    assert torch.equal(d, d64[idx]) and torch.equal(ang, a64[idx])
+    # direct (sinogram-domain) kernel: same limit, same chunking
+    sino = ring.normalize(torch.randn((8, 1, 60, 40), device=dev, generator=g))
+    i2 = torch.arange(P, device=dev) % 8
+    d2, a2 = ring.corr_pairs(sino[i2].contiguous(), sino[(i2 + 3) % 8].contiguous())
+    d8, a8 = ring.corr_pairs(sino, sino.roll(-3, 0).contiguous())
+    assert torch.equal(d2, d8[i2]) and torch.equal(a2, a8[i2])
