@@ -215,11 +215,9 @@ def main():
         e1 = mark() if record else None
         _, norm = plan.forward(img.view(B, 120, 120), raw=False, normalized=True)
         e2 = mark() if record else None
-        if dist_on:
-            spec, spec16 = ring.half_spectrum_f16(norm)
-        else:
-            spec = ring.half_spectrum(norm)
-        ring.corr_pairs_fft(spec, cand, out=(out_dist, out_ang))
+        # half spectrum of the new descriptors (kept: they are the next database entries; fp16 replica for the
+        # other ranks) + correlation with the candidates, one launch
+        spec, spec16, _, _ = ring.spectrum_corr_pairs(norm, cand, want_f16=dist_on, out=(out_dist, out_ang))
         e3 = mark() if record else None
         if dist_on:
             if pending["work"] is not None:

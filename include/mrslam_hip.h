@@ -351,6 +351,14 @@ int mrs_ring_corr_fft_sweep(mrs_ctx* ctx, const float* d_query_spec, int32_t n_q
 int mrs_ring_corr_fft_pairs(mrs_ctx* ctx, const float* d_a_spec, const float* d_b_spec, int32_t n_pairs,
                             float* d_dist, int32_t* d_angle, float* d_corr, mrs_stream stream);
 
+/* One launch for the new-descriptor side of a batch of loop checks: half spectra of n_pairs freshly normalised
+ * sinograms (d_half_spec and/or its fp16 replica, either may be null) and their correlation with one candidate
+ * spectrum each (d_cand_spec [n_pairs][61][120] complex64).  Results are bitwise those of mrs_ring_half_spectrum
+ * followed by mrs_ring_corr_fft_pairs. */
+int mrs_ring_spectrum_corr_pairs(mrs_ctx* ctx, const float* d_norm_sino, const float* d_cand_spec, int32_t n_pairs,
+                                 int32_t n_angles, int32_t det, float* d_half_spec, void* d_half_spec_f16, float* d_dist,
+                                 int32_t* d_angle, mrs_stream stream);
+
 /* Multi-channel forms (RING++, fast_corr_RINGplusplus, RING_ros/util.py:337-358): descriptors are
  * [channels][61][120] complex64 half spectra of the jointly normalised channels (mrs_normalize_groups over
  * channels*120*120, then mrs_ring_half_spectrum with n_img = n * channels); |corr| is summed over channels and

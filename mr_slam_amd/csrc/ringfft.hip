@@ -252,6 +252,75 @@ __global__ __launch_bounds__(NSLOT* kSlotThreads) void k_ring_corr_fft(const flo
     }
 }
 
+// New-descriptor path of a loop check in ONE launch (row R2 + C1 for pairs): half spectrum of the freshly
+// normalised sinogram (written out: it becomes a database entry / travels to the other ranks) and, straight from
+// the LDS copy of that spectrum, its correlation with the candidate's.  Same arithmetic, op for op, as
+// k_ring_half_spectrum followed by the pairwise k_ring_corr_fft (bitwise identical results), one launch and one
+// round trip of the spectrum through HBM less.  grid = pairs, 128 lanes.
+__global__ __launch_bounds__(kSlotThreads) void k_ring_spec_corr_pairs(const float* __restrict__ x, const float2* __restrict__ cand,
+                                                                       float2* __restrict__ out, __half2* __restrict__ out16,
+                                                                       float denom, float* __restrict__ dist,
+                                                                       int* __restrict__ angle)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 qs[];  // [61][120]
+    __shared__ float xbuf[128];
+    const int pair = blockIdx.x;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int d = min(t, kD - 1);
+    const bool live_col = t < kD;
+    {
+        const float* src = x + (size_t)pair * kA * kD + d;
+        float re[60], im[60];
+#pragma unroll
+        for (int m = 0; m < 60; ++m) {
+            re[m] = src[(2 * m) * kD];
+            im[m] = src[(2 * m + 1) * kD];
+        }
+        const float sc = 0.09128709291752769f;  // 1/sqrt(120)
+        const size_t o = (size_t)pair * kHalf * kD + d;
+        rfft120(re, im, [&](int k, float xr, float xi) {
+            if (!live_col) return;
+            const float2 v = make_float2(xr * sc, xi * sc);
+            qs[k * kD + d] = v;
+            if (out) out[o + k * kD] = v;
+            if (out16) out16[o + k * kD] = __floats2half2_rn(v.x, v.y);
+        });
+    }
+    __syncthreads();
+    float re[60], im[60];
+    const float2* b = cand + (size_t)pair * kHalf * kD + d;
+    corr_irfft120([&](int k, float& ar, float& ai, float& br, float& bi) {
+        const float2 bv = b[k * kD];
+        const float2 av = qs[k * kD + d];
+        ar = av.x; ai = av.y; br = bv.x; bi = bv.y;
+    }, re, im);
+    float v0, v1;
+    wave_abs_reduce_scatter(re, im, live_col, v0, v1);
+    if (wave == 1) { xbuf[2 * lane] = v0; xbuf[2 * lane + 1] = v1; }
+    __syncthreads();
+    if (wave == 0) {
+        const float sc = 0.09128709291752769f;
+        const float s0 = (v0 + xbuf[2 * lane]) * sc, s1 = (v1 + xbuf[2 * lane + 1]) * sc;
+        const int n0 = 2 * lane, n1 = 2 * lane + 1;
+        const int m0 = n0 < 60 ? n0 + 60 : n0 - 60, m1 = n1 < 60 ? n1 + 60 : n1 - 60;
+        float best = -1.0f;
+        int bm = 1 << 30;
+        if (lane < 60) {
+            best = s0; bm = m0;
+            if (s1 > best || (s1 == best && m1 < bm)) { best = s1; bm = m1; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ob = __shfl_xor(best, off, 64);
+            const int om = __shfl_xor(bm, off, 64);
+            if (ob > best || (ob == best && om < bm)) { best = ob; bm = om; }
+        }
+        if (lane == 0) {
+            dist[pair] = 1.0f - best / denom;
+            angle[pair] = kA / 2 - bm;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -368,6 +437,27 @@ int mrs_ring_corr_fft_pairs_mc(mrs_ctx* ctx, const float* d_a_spec, const float*
                                float* d_dist, int32_t* d_angle, float* d_corr, mrs_stream stream)
 {
     return corr_fft_launch<float2>(ctx, d_a_spec, n_pairs, d_b_spec, n_pairs, channels, d_dist, d_angle, d_corr, stream, true);
+}
+
+int mrs_ring_spectrum_corr_pairs(mrs_ctx* ctx, const float* d_norm_sino, const float* d_cand_spec, int32_t n_pairs,
+                                 int32_t n_angles, int32_t det, float* d_half_spec, void* d_half_spec_f16, float* d_dist,
+                                 int32_t* d_angle, mrs_stream stream)
+{
+    MRS_REQUIRE(ctx && d_norm_sino && d_cand_spec && d_dist && d_angle, "null pointer");
+    MRS_REQUIRE(n_pairs > 0, "n_pairs must be positive");
+    if (n_angles != kA || det != kD) {
+        mrs::set_error("ring_spectrum_corr_pairs is specialised for 120 x 120 (got %d x %d)", n_angles, det);
+        return MRS_ERR_UNSUPPORTED;
+    }
+    MRS_HIP_TRY(hipSetDevice(ctx->device));
+    const size_t lds = (size_t)kHalf * kD * sizeof(float2);
+    MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring_spec_corr_pairs), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+    hipLaunchKernelGGL(k_ring_spec_corr_pairs, dim3(n_pairs), dim3(kSlotThreads), lds, (hipStream_t)stream, d_norm_sino,
+                       reinterpret_cast<const float2*>(d_cand_spec), reinterpret_cast<float2*>(d_half_spec),
+                       reinterpret_cast<__half2*>(d_half_spec_f16), (float)(0.15 * kA * kD), d_dist, d_angle);
+    MRS_HIP_TRY(hipGetLastError());
+    return MRS_OK;
 }
 
 }  // extern "C"

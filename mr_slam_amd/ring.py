@@ -292,6 +292,23 @@ def half_spectrum_f16(norm, want_f32=True):
     return (torch.view_as_complex(out) if want_f32 else None), out16
 
 
+def spectrum_corr_pairs(norm, cand_spec, want_f32=True, want_f16=False, out=None):
+    """half_spectrum(norm) and corr_pairs_fft(that, cand_spec) in one launch.  norm float32 [P,120,120], cand_spec
+    complex64 [P,61,120].  Returns (spec | None, spec16 | None, dist [P], angle [P])."""
+    d = _dev(norm)
+    x, c = norm.contiguous(), cand_spec.contiguous()
+    P = x.shape[0]
+    assert x.shape[-2:] == (120, 120) and c.shape == (P, 61, 120)
+    spec = torch.empty((P, 61, 120, 2), dtype=torch.float32, device=x.device) if want_f32 else None
+    spec16 = torch.empty((P, 61, 120, 2), dtype=torch.float16, device=x.device) if want_f16 else None
+    dist, ang = out if out is not None else (torch.empty(P, dtype=torch.float32, device=x.device),
+                                             torch.empty(P, dtype=torch.int32, device=x.device))
+    _lib.check(_lib.load().mrs_ring_spectrum_corr_pairs(_lib.ctx(d), _lib.ptr(x), _lib.ptr(torch.view_as_real(c)), P, 120, 120,
+                                                        _lib.ptr(spec) if want_f32 else None, _lib.ptr(spec16) if want_f16 else None,
+                                                        _lib.ptr(dist), _lib.ptr(ang), _lib.current_stream(d)))
+    return (torch.view_as_complex(spec) if want_f32 else None), spec16, dist, ang
+
+
 def corr_sweep_fft(query_spec, db_spec, want_corr=False):
     """C1 sweep on half spectra: query_spec [Q,61,120] complex64, db_spec [N,61,120] complex64 or its fp16
     replica [N,61,120,2] float16 (device)."""

@@ -360,3 +360,19 @@ def test_more_pairs_than_one_grid_dimension(dev):
     d2, a2 = ring.corr_pairs(sino[i2].contiguous(), sino[(i2 + 3) % 8].contiguous())
     d8, a8 = ring.corr_pairs(sino, sino.roll(-3, 0).contiguous())
     assert torch.equal(d2, d8[i2]) and torch.equal(a2, a8[i2])
+
+
+def test_fused_spectrum_and_pair_correlation_is_bitwise_the_two_step_path(dev):
+    import torch
+    from mr_slam_amd import ring
+    g = torch.Generator(device=dev).manual_seed(5)
+    norm = ring.normalize(torch.randn((37, 120, 120), device=dev, generator=g))
+    cand = ring.half_spectrum(ring.normalize(torch.randn((37, 120, 120), device=dev, generator=g)))
+    cand[3] = ring.half_spectrum(norm[3:4].roll(25, 1))[0]
+    spec, spec16, d, a = ring.spectrum_corr_pairs(norm, cand, want_f16=True)
+    want_spec, want16 = ring.half_spectrum_f16(norm)
+    wd, wa = ring.corr_pairs_fft(want_spec, cand)
+    assert torch.equal(spec, want_spec) and torch.equal(spec16, want16)
+    assert torch.equal(d, wd) and torch.equal(a, wa) and int(a[3]) == 25
+    none, only16, d2, a2 = ring.spectrum_corr_pairs(norm, cand, want_f32=False, want_f16=True)
+    assert none is None and torch.equal(only16, want16) and torch.equal(d2, wd) and torch.equal(a2, wa)
