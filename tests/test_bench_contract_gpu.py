@@ -1,0 +1,43 @@
+"""bench.py prints ONE JSON line with the fields the driver reads (small configuration, one GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra_env=None):
+    env = dict(os.environ)
+    env.update(extra_env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "32",
+                        "--db", "512", "--gicp-pairs", "2", "--gicp-iters", "3"], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    return json.loads(lines[-1])          # the JSON is the LAST line of stdout
+
+
+def test_bench_line_contract():
+    d = _run()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["unit"] == "pairs/s"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 32 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+    assert d["gicp"]["iterations"] == 3 and d["gicp"]["iters_per_s"] > 0 and d["sweep"]["pairs_per_s"] > 0
+
+
+def test_bench_collective_path_on_one_gpu():
+    """MRS_BENCH_FORCE_DIST=1: the N > 1 code path (process group, fp16 replicas, asynchronous RCCL all-gather, max over
+    ranks) with world size 1."""
+    d = _run({"MRS_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"})
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "all-gather" in d["config"]["parallelism"]
