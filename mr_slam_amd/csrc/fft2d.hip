@@ -325,6 +325,7 @@ int mrs_disco_descriptor(mrs_ctx* ctx, const float* d_bev, int32_t batch, int32_
     hipStream_t s = (hipStream_t)stream;
     const int cells = num_ring * num_sector;
     float2* spec = reinterpret_cast<float2*>(d_spectrum);
+    MRS_REQUIRE(batch <= mrs::kMaxGridY, "at most 65535 scans per call (split the batch)");
     hipLaunchKernelGGL(k_height_sum, dim3(grid_for(cells), batch), dim3(256), 0, s, d_bev, num_height, cells, spec);
     int st = fft2_inplace(ctx, spec, num_ring, num_sector, batch, false, s);
     if (st != MRS_OK) return st;
@@ -427,6 +428,7 @@ int mrs_signature_search(mrs_ctx* ctx, const float* d_query, int32_t n_query, co
     int st = best.alloc((size_t)n_query * sizeof(unsigned long long), s);
     if (st != MRS_OK) return st;
     MRS_HIP_TRY(hipMemsetAsync(best.p, 0xff, (size_t)n_query * sizeof(unsigned long long), s));
+    MRS_REQUIRE((n_query + kSigTile - 1) / kSigTile <= mrs::kMaxGridY, "too many queries per call (split the batch)");
     hipLaunchKernelGGL(k_signature_tile, dim3((n_db + kSigTile - 1) / kSigTile, (n_query + kSigTile - 1) / kSigTile), dim3(256), 0, s,
                        d_query, n_query, d_db, n_db, dim, best.as<unsigned long long>());
     hipLaunchKernelGGL(k_signature_unpack, dim3((n_query + 255) / 256), dim3(256), 0, s, best.as<unsigned long long>(), n_query,
@@ -442,6 +444,7 @@ int mrs_rotate_nearest(mrs_ctx* ctx, const float* d_img, int32_t n_images, int32
     MRS_REQUIRE(n_images > 0 && images_per_angle > 0 && height > 0 && width > 0, "sizes must be positive");
     MRS_REQUIRE(d_img != d_out, "in-place rotation is not supported");
     MRS_HIP_TRY(hipSetDevice(ctx->device));
+    MRS_REQUIRE(n_images <= mrs::kMaxGridY, "at most 65535 images per call (split the batch)");
     hipLaunchKernelGGL(k_rotate_nearest, dim3(grid_for((size_t)height * width), n_images), dim3(256), 0,
                        (hipStream_t)stream, d_img, height, width, d_angle_deg, images_per_angle, d_out);
     MRS_HIP_TRY(hipGetLastError());
