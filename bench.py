@@ -164,7 +164,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="scan pairs per rank per step")
+    ap.add_argument("--batch", type=int, default=1024, help="scan pairs per rank per step")
     ap.add_argument("--db", type=int, default=16384, help="database size for the sweep-rate leg (x 58 560 B)")
     ap.add_argument("--gicp-pairs", type=int, default=256, help="120k-pt pairs per rank in the GICP leg (BASELINE configs[2]: 256; 0 = skip)")
     ap.add_argument("--gicp-iters", type=int, default=20)

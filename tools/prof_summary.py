@@ -51,7 +51,7 @@ json.dump(traffic, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), inde
 with open(os.path.join(dst, f"{tag}_summary.md"), "w") as o:
     o.write(f"# rocprofv3 summary, round tag `{tag}`\n\n")
     o.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 2 "
-            "--no-cpu-baseline` (1 x MI355X, B = 512 scan pairs/step, GICP leg 256 pairs x 120k x 20 iterations).\n"
+            "--no-cpu-baseline` (1 x MI355X, B = 1024 scan pairs/step, GICP leg 256 pairs x 120k x 20 iterations).\n"
             "PMC passes (separate runs, `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, no tracing).\n\n")
     o.write("| kernel | calls | avg us | min us | max us | % of GPU time |\n|---|---|---|---|---|---|\n")
     for r in rows[:14]:
