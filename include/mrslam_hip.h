@@ -234,6 +234,9 @@ typedef struct mrs_gicp_params {
     int32_t voxel_neighbors;            /* 1 / 7 / 27 = DIRECT1 / DIRECT7 / DIRECT27
                                            (setNeighborSearchMethod, global_manager.cpp:2452)  */
     int32_t reserved;
+    double convergence_factor;          /* LsqRegistration::is_converged: max(f |R - I| / rotation_epsilon,
+                                           f |t| / transformation_epsilon) < 1 with upstream's f = 10
+                                           (0 selects 10)                                      */
 } mrs_gicp_params;
 
 void mrs_gicp_default_params(mrs_gicp_params* p);

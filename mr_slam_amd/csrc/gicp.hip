@@ -26,9 +26,11 @@
 // the per-point 3x3 algebra and the 28-term fp64 reductions (wave __shfl butterflies -> one
 // partial per workgroup -> fixed-order final sum) are noise next to it.  All pairs of a batch
 // advance together; the Levenberg-Marquardt bookkeeping runs on the device (one lane per
-// pair), so the host only polls a "pairs still active" counter.  The evaluation at an accepted
-// candidate is reused as the next iteration's linearisation, which halves the number of NN
-// passes per iteration relative to the reference without changing results.
+// pair), so the host only polls two counters (pairs to linearise, pairs in an LM trial).
+// LM trial semantics are upstream's: linearize(x0) is the only step that searches (one NN pass per
+// outer iteration); every trial pose delta * x0 is scored by compute_error, i.e. on the cached
+// correspondences with the Mahalanobis matrices of the linearisation pose (recomputed on the fly
+// from x0 -- the same values, cheaper than storing 48 B per point).
 #include <hipcub/hipcub.hpp>
 
 #include <cfloat>
@@ -45,8 +47,8 @@ constexpr int kTerms = 28;       // 21 (H upper) + 6 (b) + 1 (error)
 constexpr int kMaxOrder = 512;   // tiles per cloud that get distance-ordered traversal (512k points)
 
 struct LmState {
-    double x[16];      // accepted pose (row-major 4x4)
-    double xi[16];     // candidate pose being evaluated
+    double x[16];      // accepted pose (row-major 4x4) = linearisation pose of the current outer iteration
+    double xi[16];     // pose being evaluated: == x while linearising (phase 0), the LM candidate in phase 1
     double delta[16];  // last increment
     double H[36];      // linearisation at x
     double b[6];
@@ -55,7 +57,7 @@ struct LmState {
     double lambda;
     double nu;
     double final_H[36];
-    int phase;         // 0: first evaluation at the guess, 1: LM trial, 2: done
+    int phase;         // 0: linearize at x (NN search + H, b, y0), 1: LM trial (compute_error at xi), 2: done
     int inner;
     int outer;
     int trials;
@@ -68,6 +70,7 @@ struct LmState {
 struct GicpParams {
     double max_corr2;     // squared correspondence distance threshold (inf if unbounded)
     double rot_eps, trans_eps;
+    double conv_factor;   // upstream is_converged: factor 10 on both scaled deltas
     double lm_init_factor;
     int max_iter;
     int lm_max_iter;
@@ -887,7 +890,7 @@ __global__ __launch_bounds__(kNNThreads) void k_nn_scan(
     __shared__ ScanShared sh;
     const int pair = blockIdx.y;
     const LmState& S = st[pair];
-    if (!S.active) return;
+    if (!S.active || S.phase != 0) return;   // LM trials reuse the cached correspondences (upstream compute_error)
     const int64_t so = src_offs[pair], to = tgt_offs[pair];
     const int n = (int)(src_offs[pair + 1] - so), m = (int)(tgt_offs[pair + 1] - to);
     const float4* src = src_all + so;
@@ -899,7 +902,7 @@ __global__ __launch_bounds__(kNNThreads) void k_nn_scan(
     const float maxc2 = prm.max_corr2 < 3.0e38 ? (float)prm.max_corr2 * 1.0001f : INFINITY;
     float Tf[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) Tf[i] = (float)S.xi[i];
+    for (int i = 0; i < 12; ++i) Tf[i] = (float)S.x[i];
     float glo[3];
     const float gsc = morton_grid(tgt_bbox, pair, glo);
     const int per_block = kNNThreads * P;
@@ -934,6 +937,9 @@ __global__ __launch_bounds__(kNNThreads) void k_nn_scan(
 
 // G3b + G4: Mahalanobis matrices, residuals and the 28 fp64 sums for the correspondences found by
 // k_nn_scan.  grid = (blocks, pairs), one source point per lane; partial[pair][block][28].
+// Two poses: the Mahalanobis matrices belong to the linearisation pose S.x (upstream caches them in
+// update_correspondences), the residuals to the evaluated pose S.xi.  Phase 0: xi == x, all 28 sums
+// (FastGICP::linearize); phase 1: only the error sum (FastGICP::compute_error of an LM trial).
 __global__ __launch_bounds__(kNNThreads) void k_linearize(
     const float4* __restrict__ src_all, const int64_t* __restrict__ src_offs, const double* __restrict__ src_cov,
     const float4* __restrict__ tgt_all, const int64_t* __restrict__ tgt_offs, const double* __restrict__ tgt_cov,
@@ -948,9 +954,10 @@ __global__ __launch_bounds__(kNNThreads) void k_linearize(
     const float4* src = src_all + so;
     const float4* tgt = tgt_all + to;
     double* pout = partial + ((size_t)pair * max_blocks + blockIdx.x) * kTerms;
-    double T[12];
+    const bool error_only = S.phase == 1;
+    double T[12], TL[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) T[i] = S.xi[i];
+    for (int i = 0; i < 12; ++i) { T[i] = S.xi[i]; TL[i] = S.x[i]; }
     double acc[kTerms];
 #pragma unroll
     for (int i = 0; i < kTerms; ++i) acc[i] = 0.0;
@@ -972,12 +979,12 @@ __global__ __launch_bounds__(kNNThreads) void k_linearize(
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    RC[3 * r + c] = T[4 * r] * CA[c] + T[4 * r + 1] * CA[3 + c] + T[4 * r + 2] * CA[6 + c];
+                    RC[3 * r + c] = TL[4 * r] * CA[c] + TL[4 * r + 1] * CA[3 + c] + TL[4 * r + 2] * CA[6 + c];
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    RCR[3 * r + c] = RC[3 * r] * T[4 * c] + RC[3 * r + 1] * T[4 * c + 1] + RC[3 * r + 2] * T[4 * c + 2];
+                    RCR[3 * r + c] = RC[3 * r] * TL[4 * c] + RC[3 * r + 1] * TL[4 * c + 1] + RC[3 * r + 2] * TL[4 * c + 2];
             RCR[0] += cb[0]; RCR[1] += cb[1]; RCR[2] += cb[2];
             RCR[3] += cb[1]; RCR[4] += cb[3]; RCR[5] += cb[4];
             RCR[6] += cb[2]; RCR[7] += cb[4]; RCR[8] += cb[5];
@@ -990,6 +997,7 @@ __global__ __launch_bounds__(kNNThreads) void k_linearize(
 #pragma unroll
             for (int r = 0; r < 3; ++r) Me[r] = M[3 * r] * e[0] + M[3 * r + 1] * e[1] + M[3 * r + 2] * e[2];
             acc[27] += e[0] * Me[0] + e[1] * Me[1] + e[2] * Me[2];
+            if (error_only) continue;
             const double J[18] = {0, -ta[2], ta[1], -1, 0, 0,
                                   ta[2], 0, -ta[0], 0, -1, 0,
                                   -ta[1], ta[0], 0, 0, 0, -1};
@@ -1029,7 +1037,12 @@ __global__ __launch_bounds__(kNNThreads) void k_linearize(
 // covariances (ADDITIVE accumulation).  A transformed source point corresponds to the voxel that contains it
 // (DIRECT1) and optionally its 6 / 26 neighbours; each correspondence is a distribution-to-distribution term
 // weighted by sqrt(points in the voxel).  max_correspondence_distance is not used.  Parity unpinned: restated
-// from the publication and SURVEY.md row G7 (the submodule is absent).
+// from the publication and SURVEY.md row G7 (the submodule is absent).  Conventions of upstream's CUDA voxel map:
+// voxel coordinate = floor(x / resolution - 0.5) in float arithmetic on the float-transformed point
+// (calc_voxel_coord); correspondences and (C_voxel + R C_A R^T)^-1 belong to the linearisation pose, LM trials
+// (compute_error) only re-evaluate the residuals (x_linearized / x_eval in upstream's kernels).
+__device__ __forceinline__ int voxel_coord_f(float v, float res) { return (int)floorf(v / res - 0.5f); }
+
 __device__ __forceinline__ unsigned long long voxel_key(int cloud, int ix, int iy, int iz)
 {
     return ((unsigned long long)cloud << 48) | ((unsigned long long)(ix & 0xffff) << 32) |
@@ -1044,8 +1057,9 @@ __global__ void k_vox_keys(const float4* __restrict__ pts, const int64_t* __rest
     const int n = (int)(offs[c + 1] - o);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float4 p = pts[o + i];
-        keys[o + i] = voxel_key(c, (int)floor((double)p.x / res) + 32768, (int)floor((double)p.y / res) + 32768,
-                                (int)floor((double)p.z / res) + 32768);
+        const float resf = (float)res;
+        keys[o + i] = voxel_key(c, voxel_coord_f(p.x, resf) + 32768, voxel_coord_f(p.y, resf) + 32768,
+                                voxel_coord_f(p.z, resf) + 32768);
         vals[o + i] = (int)(o + i);
     }
 }
@@ -1093,14 +1107,17 @@ __global__ __launch_bounds__(kNNThreads) void k_linearize_voxel(
     const int n = (int)(src_offs[pair + 1] - so);
     const float4* src = src_all + so;
     double* pout = partial + ((size_t)pair * max_blocks + blockIdx.x) * kTerms;
-    double T[12];
+    const bool error_only = S.phase == 1;
+    double T[12], TL[12];
+    float Tf[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) T[i] = S.xi[i];
+    for (int i = 0; i < 12; ++i) { T[i] = S.xi[i]; TL[i] = S.x[i]; Tf[i] = (float)S.x[i]; }
     double acc[kTerms];
 #pragma unroll
     for (int i = 0; i < kTerms; ++i) acc[i] = 0.0;
     const int per_block = kNNThreads * kPts;
     const int nn = prm.voxel_neighbors;
+    const float resf = (float)prm.voxel_res;
     for (int base = blockIdx.x * per_block; base < n; base += gridDim.x * per_block) {
 #pragma unroll 1
         for (int p = 0; p < kPts; ++p) {
@@ -1111,8 +1128,10 @@ __global__ __launch_bounds__(kNNThreads) void k_linearize_voxel(
 #pragma unroll
             for (int r = 0; r < 3; ++r)
                 ta[r] = T[4 * r] * (double)a.x + T[4 * r + 1] * (double)a.y + T[4 * r + 2] * (double)a.z + T[4 * r + 3];
-            const int cx = (int)floor(ta[0] / prm.voxel_res) + 32768, cy = (int)floor(ta[1] / prm.voxel_res) + 32768,
-                      cz = (int)floor(ta[2] / prm.voxel_res) + 32768;
+            // voxel of the float-transformed point at the LINEARISATION pose
+            const int cx = voxel_coord_f(Tf[0] * a.x + Tf[1] * a.y + Tf[2] * a.z + Tf[3], resf) + 32768,
+                      cy = voxel_coord_f(Tf[4] * a.x + Tf[5] * a.y + Tf[6] * a.z + Tf[7], resf) + 32768,
+                      cz = voxel_coord_f(Tf[8] * a.x + Tf[9] * a.y + Tf[10] * a.z + Tf[11], resf) + 32768;
             const double* ca = src_cov + 6 * (size_t)(so + i);
             const double CA[9] = {ca[0], ca[1], ca[2], ca[1], ca[3], ca[4], ca[2], ca[4], ca[5]};
             double RC[9], RCRa[9];
@@ -1120,12 +1139,12 @@ __global__ __launch_bounds__(kNNThreads) void k_linearize_voxel(
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    RC[3 * r + c] = T[4 * r] * CA[c] + T[4 * r + 1] * CA[3 + c] + T[4 * r + 2] * CA[6 + c];
+                    RC[3 * r + c] = TL[4 * r] * CA[c] + TL[4 * r + 1] * CA[3 + c] + TL[4 * r + 2] * CA[6 + c];
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    RCRa[3 * r + c] = RC[3 * r] * T[4 * c] + RC[3 * r + 1] * T[4 * c + 1] + RC[3 * r + 2] * T[4 * c + 2];
+                    RCRa[3 * r + c] = RC[3 * r] * TL[4 * c] + RC[3 * r + 1] * TL[4 * c + 1] + RC[3 * r + 2] * TL[4 * c + 2];
 #pragma unroll 1
             for (int o = 0; o < 27; ++o) {
                 const int dx = o % 3 - 1, dy = (o / 3) % 3 - 1, dz = o / 9 - 1;
@@ -1150,6 +1169,7 @@ __global__ __launch_bounds__(kNNThreads) void k_linearize_voxel(
 #pragma unroll
                 for (int r = 0; r < 3; ++r) Me[r] = M[3 * r] * e[0] + M[3 * r + 1] * e[1] + M[3 * r + 2] * e[2];
                 acc[27] += w * (e[0] * Me[0] + e[1] * Me[1] + e[2] * Me[2]);
+                if (error_only) continue;
                 const double J[18] = {0, -ta[2], ta[1], -1, 0, 0,
                                       ta[2], 0, -ta[0], 0, -1, 0,
                                       -ta[1], ta[0], 0, 0, 0, -1};
@@ -1259,8 +1279,8 @@ __device__ bool is_converged_d(const GicpParams& p, const double* delta)
 {
     double mr = 0, mt = 0;
     for (int i = 0; i < 3; ++i) {
-        for (int j = 0; j < 3; ++j) mr = fmax(mr, fabs(delta[4 * i + j] - (i == j ? 1.0 : 0.0)) / p.rot_eps);
-        mt = fmax(mt, fabs(delta[4 * i + 3]) / p.trans_eps);
+        for (int j = 0; j < 3; ++j) mr = fmax(mr, p.conv_factor * fabs(delta[4 * i + j] - (i == j ? 1.0 : 0.0)) / p.rot_eps);
+        mt = fmax(mt, p.conv_factor * fabs(delta[4 * i + 3]) / p.trans_eps);
     }
     return fmax(mr, mt) < 1.0;
 }
@@ -1277,9 +1297,13 @@ __device__ void propose(LmState& S)
     ++S.trials;
 }
 
-// LsqRegistration::step_lm / computeTransformation bookkeeping; grid = pairs, 64 lanes each
+// LsqRegistration::step_lm / computeTransformation bookkeeping; grid = pairs, 64 lanes each.
+//   phase 0 result = linearize(x0): H, b, y0 -> first LM candidate, phase 1
+//   phase 1 result = compute_error(delta * x0) on the cached correspondences -> rho -> accept (x0 <- xi, next
+//   outer iteration linearises again: phase 0) or reject (lambda *= nu, next candidate, stay in phase 1)
+// n_next[0] counts the pairs that need a linearisation next tick, n_next[1] the pairs in an LM trial.
 __global__ void k_lm_update(LmState* __restrict__ st, const double* __restrict__ partial, const int* __restrict__ nblocks,
-                            int max_blocks, GicpParams prm, int* __restrict__ n_active)
+                            int max_blocks, GicpParams prm, int* __restrict__ n_next)
 {
     const int pair = blockIdx.x;
     LmState& S = st[pair];
@@ -1289,7 +1313,7 @@ __global__ void k_lm_update(LmState* __restrict__ st, const double* __restrict__
         // in ascending order, then one wave butterfly per term
         const double* p = partial + (size_t)pair * max_blocks * kTerms;
         const int nb = nblocks[pair];
-        for (int t = 0; t < kTerms; ++t) {
+        for (int t = S.phase == 1 ? kTerms - 1 : 0; t < kTerms; ++t) {
             double v = 0;
             for (int b = threadIdx.x; b < nb; b += 64) v += p[(size_t)b * kTerms + t];
             v = wave_sum_d(v);
@@ -1298,32 +1322,34 @@ __global__ void k_lm_update(LmState* __restrict__ st, const double* __restrict__
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
-    double H[36], b[6];
-    int t = 0;
-    for (int r = 0; r < 6; ++r)
-        for (int c = r; c < 6; ++c) { H[6 * r + c] = sum[t]; H[6 * c + r] = sum[t]; ++t; }
-    for (int r = 0; r < 6; ++r) b[r] = sum[21 + r];
     const double y = sum[27];
+    const int limit = prm.force_iters > 0 ? prm.force_iters : prm.max_iter;
 
-    bool take = false;  // adopt the evaluation at xi as the linearisation of the next iteration
     if (S.phase == 0) {
-        double mx = 0;
-        for (int i = 0; i < 6; ++i) mx = fmax(mx, fabs(H[7 * i]));
-        S.lambda = prm.lm_init_factor * mx;
-        take = true;
+        int t = 0;
+        for (int r = 0; r < 6; ++r)
+            for (int c = r; c < 6; ++c) { S.H[6 * r + c] = sum[t]; S.H[6 * c + r] = sum[t]; ++t; }
+        for (int r = 0; r < 6; ++r) S.b[r] = sum[21 + r];
+        S.y0 = y;
+        if (S.lambda < 0.0) {
+            double mx = 0;
+            for (int i = 0; i < 6; ++i) mx = fmax(mx, fabs(S.H[7 * i]));
+            S.lambda = prm.lm_init_factor * mx;
+        }
+        S.nu = 2.0;
+        S.inner = 0;
+        S.phase = 1;
+        propose(S);
     } else {
         double denom = 0;
         for (int i = 0; i < 6; ++i) denom += S.d[i] * (S.lambda * S.d[i] - S.b[i]);
         const double rho = (S.y0 - y) / denom;
+        bool stepped = false;   // step_lm returned true: one outer iteration is complete
         if (!(rho == rho)) {
             S.failed = 1; S.active = 0; S.phase = 2;
         } else if (rho < 0) {
             if (is_converged_d(prm, S.delta)) {
-                // step_lm returns true without moving; the outer loop then sees a converged delta
-                ++S.outer;
-                if (prm.force_iters <= 0) { S.converged = 1; S.active = 0; S.phase = 2; }
-                else if (S.outer >= prm.force_iters) { S.active = 0; S.phase = 2; }
-                else { S.nu = 2.0; S.inner = 0; propose(S); }
+                stepped = true;     // returns true without moving; the outer loop then sees a converged delta
             } else {
                 S.lambda = S.nu * S.lambda;
                 S.nu = 2 * S.nu;
@@ -1336,24 +1362,20 @@ __global__ void k_lm_update(LmState* __restrict__ st, const double* __restrict__
             const double w = 2 * rho - 1;
             S.lambda = S.lambda * fmax(1.0 / 3.0, 1.0 - w * w * w);
             for (int i = 0; i < 36; ++i) S.final_H[i] = S.H[i];
+            stepped = true;
+        }
+        if (stepped) {
             ++S.outer;
-            const int limit = prm.force_iters > 0 ? prm.force_iters : prm.max_iter;
             const bool conv = prm.force_iters > 0 ? false : is_converged_d(prm, S.delta);
             if (conv) S.converged = 1;
             if (conv || S.outer >= limit) { S.active = 0; S.phase = 2; }
-            else take = true;
+            else {
+                for (int i = 0; i < 16; ++i) S.xi[i] = S.x[i];
+                S.phase = 0;
+            }
         }
     }
-    if (take) {
-        for (int i = 0; i < 36; ++i) S.H[i] = H[i];
-        for (int i = 0; i < 6; ++i) S.b[i] = b[i];
-        S.y0 = y;
-        S.nu = 2.0;
-        S.inner = 0;
-        S.phase = 1;
-        propose(S);
-    }
-    if (S.active) atomicAdd(n_active, 1);
+    if (S.active) atomicAdd(&n_next[S.phase == 0 ? 0 : 1], 1);
 }
 
 // G6: fitness partials: [pair][block][2] = (sum of d^2 <= max_range, count)
@@ -1515,6 +1537,7 @@ void mrs_gicp_default_params(mrs_gicp_params* p)
     p->transformation_epsilon = 5e-4;
     p->lm_max_iterations = 10;
     p->lm_init_lambda_factor = 1e-9;
+    p->convergence_factor = 10.0;       // upstream LsqRegistration::is_converged scales both deltas by 10
     p->force_iterations = 0;
     p->voxel_resolution = 0.0;          // FastVGICP(Cuda) default is 1.0; Mapping sets 0.5 (global_manager.cpp:2450)
     p->voxel_neighbors = 1;             // DIRECT1 (global_manager.cpp:2452)
@@ -1570,6 +1593,8 @@ int mrs_gicp_batch_set_params(mrs_gicp_batch* h, const mrs_gicp_params* p)
     h->prm.trans_eps = p->transformation_epsilon;
     h->prm.lm_max_iter = p->lm_max_iterations;
     h->prm.lm_init_factor = p->lm_init_lambda_factor;
+    MRS_REQUIRE(p->convergence_factor >= 0.0, "convergence_factor must be >= 0 (0 selects upstream's 10)");
+    h->prm.conv_factor = p->convergence_factor > 0.0 ? p->convergence_factor : 10.0;
     h->prm.force_iters = p->force_iterations;
     MRS_REQUIRE(p->voxel_resolution >= 0.0, "voxel_resolution must be >= 0");
     MRS_REQUIRE(p->voxel_neighbors == 1 || p->voxel_neighbors == 7 || p->voxel_neighbors == 27, "voxel_neighbors must be 1, 7 or 27");
@@ -1723,7 +1748,7 @@ static int ensure_state(mrs_gicp_batch* h)
     if (!h->d_state) {
         MRS_HIP_TRY(hipMalloc(&h->d_state, h->n_pairs * sizeof(LmState)));
         MRS_HIP_TRY(hipMalloc(&h->d_nblocks, h->n_pairs * sizeof(int)));
-        MRS_HIP_TRY(hipMalloc(&h->d_nactive, sizeof(int)));
+        MRS_HIP_TRY(hipMalloc(&h->d_nactive, 2 * sizeof(int)));
     }
     if (mb > h->max_blocks) {
         if (h->d_partial) (void)hipFree(h->d_partial);
@@ -1813,28 +1838,30 @@ int mrs_gicp_batch_align(mrs_gicp_batch* h, const double* h_guess, double* h_fin
     MRS_HIP_TRY(hipMemcpyAsync(h->d_state, init.data(), init.size() * sizeof(LmState), hipMemcpyHostToDevice, s));
     const dim3 grid(h->max_blocks, h->n_pairs);
     const int limit = h->prm.force_iters > 0 ? h->prm.force_iters : h->prm.max_iter;
-    const long max_ticks = 1 + (long)limit * (h->prm.lm_max_iter + 1);
-    long ticks = 0;
-    int active = h->n_pairs;
-    while (active > 0 && ticks < max_ticks) {
-        MRS_HIP_TRY(hipMemsetAsync(h->d_nactive, 0, sizeof(int), s));
+    const long max_ticks = (long)limit * (h->prm.lm_max_iter + 1) + 1;
+    long ticks = 0, nn_ticks = 0;
+    int next[2] = {h->n_pairs, 0};   // pairs to linearise (phase 0), pairs in an LM trial (phase 1)
+    while (next[0] + next[1] > 0 && ticks < max_ticks) {
+        MRS_HIP_TRY(hipMemsetAsync(h->d_nactive, 0, 2 * sizeof(int), s));
         if (h->prm.voxel_res > 0.0) {
             hipLaunchKernelGGL(k_linearize_voxel, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_cov[0], h->d_vkeys,
                                h->d_vmean, h->d_vcov, h->n_voxels, h->d_state, h->prm, h->d_partial, h->max_blocks);
         } else {
-            launch_nn_scan(h->longest_src, h->n_pairs, h->ctx->num_cu, s, h->d_pts[0], h->d_offs[0], h->d_pts[1], h->d_offs[1],
-                           h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_state, h->prm, h->d_corr, h->d_seed, (const int*)h->d_bbox[1]);
+            if (next[0] > 0)   // only linearisations search; LM trials score the cached correspondences
+                launch_nn_scan(h->longest_src, h->n_pairs, h->ctx->num_cu, s, h->d_pts[0], h->d_offs[0], h->d_pts[1], h->d_offs[1],
+                               h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_state, h->prm, h->d_corr, h->d_seed, (const int*)h->d_bbox[1]);
             hipLaunchKernelGGL(k_linearize, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_cov[0],
                                h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->d_corr, h->d_partial, h->max_blocks);
         }
+        if (next[0] > 0) ++nn_ticks;
         hipLaunchKernelGGL(k_lm_update, dim3(h->n_pairs), dim3(64), 0, s, h->d_state, h->d_partial, h->d_nblocks,
                            h->max_blocks, h->prm, h->d_nactive);
         MRS_HIP_TRY(hipGetLastError());
-        MRS_HIP_TRY(hipMemcpyAsync(&active, h->d_nactive, sizeof(int), hipMemcpyDeviceToHost, s));
+        MRS_HIP_TRY(hipMemcpyAsync(next, h->d_nactive, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
         MRS_HIP_TRY(hipStreamSynchronize(s));
         ++ticks;
     }
-    h->last_nn_passes = (double)ticks;
+    h->last_nn_passes = (double)nn_ticks;
     MRS_HIP_TRY(hipMemcpy(init.data(), h->d_state, init.size() * sizeof(LmState), hipMemcpyDeviceToHost));
     for (int p = 0; p < h->n_pairs; ++p) {
         const LmState& S = init[p];

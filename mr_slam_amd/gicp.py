@@ -12,7 +12,8 @@ class GicpParams(C.Structure):
                 ("lm_max_iterations", C.c_int32), ("force_iterations", C.c_int32),
                 ("max_correspondence_distance", C.c_double), ("rotation_epsilon", C.c_double),
                 ("transformation_epsilon", C.c_double), ("lm_init_lambda_factor", C.c_double),
-                ("voxel_resolution", C.c_double), ("voxel_neighbors", C.c_int32), ("reserved", C.c_int32)]
+                ("voxel_resolution", C.c_double), ("voxel_neighbors", C.c_int32), ("reserved", C.c_int32),
+                ("convergence_factor", C.c_double)]
 
 
 def default_params():

@@ -19,6 +19,23 @@
  *
  * Nearest neighbours come from an exact kd-tree (the reference uses pcl::search::KdTree, also
  * exact), so results do not depend on the search structure except for exact distance ties.
+ *
+ * Upstream semantics this file follows function by function (recalled from upstream master; there
+ * is no network and no vendored copy, so no tag could be checked -- see DESIGN.md section 2):
+ *   FastGICP::update_correspondences  (fast_gicp_impl.hpp): float-transformed source point, 1-NN,
+ *       reject d^2 >= max^2, mahalanobis_[i] = (C_B + T C_A T^T)^-1 at the LINEARISATION pose,
+ *       both cached in correspondences_ / mahalanobis_.
+ *   FastGICP::linearize               : update_correspondences(trans), then H, b, sum of e^T M e.
+ *   FastGICP::compute_error           : NO new search: iterates the cached correspondences_ and
+ *       mahalanobis_ left by the last linearize, only e = mu_B - trans mu_A is re-evaluated.
+ *   LsqRegistration::step_lm          : y0 = linearize(x0); trials yi = compute_error(delta * x0).
+ *   LsqRegistration::is_converged     : max(10 |R - I| / rotation_epsilon, 10 |t| / transformation_epsilon) < 1
+ *       (the factor 10 is upstream's; exposed as conv_factor).
+ *   GaussianVoxelMap / calc_voxel_coord (FastVGICPCuda): coord = floor(x / resolution - 0.5) on the
+ *       float-transformed point in float arithmetic; voxel mean = mean of points, voxel covariance =
+ *       mean of the points' regularised covariances; correspondences = voxel index per source point
+ *       (DIRECT1/7/27 offsets), cached by linearize and reused by compute_error with the matrices of
+ *       the linearisation pose (x_linearized / x_eval in the CUDA kernels); weight sqrt(points in voxel).
  */
 #include <algorithm>
 #include <cmath>
@@ -250,6 +267,7 @@ struct Gicp {
     double max_corr = std::numeric_limits<double>::max();
     int max_iter = 64;
     double rot_eps = 2e-3, trans_eps = 5e-4;
+    double conv_factor = 10.0;   // upstream is_converged scales both deltas by 10 before the test
     int lm_max_iter = 10;
     double lm_init_factor = 1e-9;
     double lm_lambda = -1.0;
@@ -267,7 +285,14 @@ struct Gicp {
     struct Voxel { double mean[3] = {0, 0, 0}; double cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; int n = 0; };
     std::map<std::tuple<int, int, int>, Voxel> voxels;
     double voxels_built_for = 0.0;
+    // cached by linearize_voxel (upstream voxel_correspondences_ + matrices of the linearisation pose)
+    struct VoxCorr { int src; const Voxel* vox; double M[9]; };
+    std::vector<VoxCorr> vox_corr;
+    int nn_passes = 0;           // update_correspondences calls of the last align
 };
+
+// calc_voxel_coord of upstream's CUDA voxel map: float arithmetic, floor(x / res - 0.5)
+inline int voxel_coord_f(float v, float res) { return (int)std::floor(v / res - 0.5f); }
 
 // Gaussian voxel map of the target (ADDITIVE accumulation): mean of the points, mean of their covariances
 void build_voxels(Gicp& g)
@@ -276,8 +301,8 @@ void build_voxels(Gicp& g)
     g.voxels.clear();
     for (int i = 0; i < g.tgt.n; ++i) {
         const float* p = &g.tgt.pts[3 * (size_t)i];
-        auto key = std::make_tuple((int)std::floor((double)p[0] / g.voxel_res), (int)std::floor((double)p[1] / g.voxel_res),
-                                   (int)std::floor((double)p[2] / g.voxel_res));
+        const float resf = (float)g.voxel_res;
+        auto key = std::make_tuple(voxel_coord_f(p[0], resf), voxel_coord_f(p[1], resf), voxel_coord_f(p[2], resf));
         Gicp::Voxel& v = g.voxels[key];
         for (int a = 0; a < 3; ++a) v.mean[a] += (double)p[a];
         for (int a = 0; a < 9; ++a) v.cov[a] += g.tgt.cov[9 * (size_t)i + a];
@@ -290,20 +315,25 @@ void build_voxels(Gicp& g)
     g.voxels_built_for = g.voxel_res;
 }
 
-// row G7 linearisation: every source point against the voxel containing its transformed position
-// (+ 6 / 26 neighbours), weight sqrt(points in the voxel)
-double linearize_voxel(Gicp& g, const double* T, double* H, double* b)
+// row G7, upstream FastVGICPCuda::update_correspondences: the voxel containing the float-transformed source
+// point (+ 6 / 26 neighbours) and the matrix (C_voxel + R C_A R^T)^-1 of THIS pose, cached per correspondence
+void update_voxel_correspondences(Gicp& g, const double* T)
 {
     build_voxels(g);
+    ++g.nn_passes;
+    g.vox_corr.clear();
     const double R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
-    double Hs[36] = {0}, bs[6] = {0}, err = 0;
+    double Rt[9];
+    for (int a = 0; a < 3; ++a) for (int bb = 0; bb < 3; ++bb) Rt[3 * a + bb] = R[3 * bb + a];
+    float Tf[16];
+    for (int i = 0; i < 16; ++i) Tf[i] = (float)T[i];
+    const float resf = (float)g.voxel_res;
     for (int i = 0; i < g.src.n; ++i) {
         const float* pa = &g.src.pts[3 * (size_t)i];
-        double ta[3];
-        for (int a = 0; a < 3; ++a) ta[a] = T[4 * a] * (double)pa[0] + T[4 * a + 1] * (double)pa[1] + T[4 * a + 2] * (double)pa[2] + T[4 * a + 3];
-        const int c[3] = {(int)std::floor(ta[0] / g.voxel_res), (int)std::floor(ta[1] / g.voxel_res), (int)std::floor(ta[2] / g.voxel_res)};
-        double RC[9], RCRa[9], Rt[9];
-        for (int a = 0; a < 3; ++a) for (int bb = 0; bb < 3; ++bb) Rt[3 * a + bb] = R[3 * bb + a];
+        float q[3];
+        for (int a = 0; a < 3; ++a) q[a] = Tf[4 * a] * pa[0] + Tf[4 * a + 1] * pa[1] + Tf[4 * a + 2] * pa[2] + Tf[4 * a + 3];
+        const int c[3] = {voxel_coord_f(q[0], resf), voxel_coord_f(q[1], resf), voxel_coord_f(q[2], resf)};
+        double RC[9], RCRa[9];
         mul3(R, &g.src.cov[9 * (size_t)i], RC);
         mul3(RC, Rt, RCRa);
         for (int o = 0; o < 27; ++o) {
@@ -312,28 +342,50 @@ double linearize_voxel(Gicp& g, const double* T, double* H, double* b)
             if ((g.voxel_neighbors == 1 && man != 0) || (g.voxel_neighbors == 7 && man > 1)) continue;
             auto it = g.voxels.find(std::make_tuple(c[0] + dx, c[1] + dy, c[2] + dz));
             if (it == g.voxels.end()) continue;
-            const Gicp::Voxel& v = it->second;
-            double RCR[9], M[9];
-            for (int a = 0; a < 9; ++a) RCR[a] = RCRa[a] + v.cov[a];
-            if (!inv3(RCR, M)) continue;
-            const double w = std::sqrt((double)v.n);
-            double e[3], Me[3];
-            for (int a = 0; a < 3; ++a) e[a] = v.mean[a] - ta[a];
-            for (int a = 0; a < 3; ++a) Me[a] = M[3 * a] * e[0] + M[3 * a + 1] * e[1] + M[3 * a + 2] * e[2];
-            err += w * (e[0] * Me[0] + e[1] * Me[1] + e[2] * Me[2]);
-            if (!H) continue;
-            double J[18] = {0, -ta[2], ta[1], -1, 0, 0, ta[2], 0, -ta[0], 0, -1, 0, -ta[1], ta[0], 0, 0, 0, -1};
-            double MJ[18];
-            for (int a = 0; a < 3; ++a)
-                for (int cc = 0; cc < 6; ++cc) MJ[6 * a + cc] = M[3 * a] * J[cc] + M[3 * a + 1] * J[6 + cc] + M[3 * a + 2] * J[12 + cc];
-            for (int r = 0; r < 6; ++r) {
-                for (int cc = 0; cc < 6; ++cc) Hs[6 * r + cc] += w * (J[r] * MJ[cc] + J[6 + r] * MJ[6 + cc] + J[12 + r] * MJ[12 + cc]);
-                bs[r] += w * (J[r] * Me[0] + J[6 + r] * Me[1] + J[12 + r] * Me[2]);
-            }
+            Gicp::VoxCorr vc;
+            vc.src = i; vc.vox = &it->second;
+            double RCR[9];
+            for (int a = 0; a < 9; ++a) RCR[a] = RCRa[a] + it->second.cov[a];
+            if (!inv3(RCR, vc.M)) continue;
+            g.vox_corr.push_back(vc);
+        }
+    }
+}
+
+// sums over the cached voxel correspondences at the evaluation pose T (upstream compute_error(trans, H, b):
+// correspondences and matrices of the linearisation pose, residuals of the evaluation pose)
+double evaluate_voxel(const Gicp& g, const double* T, double* H, double* b)
+{
+    double Hs[36] = {0}, bs[6] = {0}, err = 0;
+    for (const Gicp::VoxCorr& vc : g.vox_corr) {
+        const float* pa = &g.src.pts[3 * (size_t)vc.src];
+        double ta[3];
+        for (int a = 0; a < 3; ++a) ta[a] = T[4 * a] * (double)pa[0] + T[4 * a + 1] * (double)pa[1] + T[4 * a + 2] * (double)pa[2] + T[4 * a + 3];
+        const Gicp::Voxel& v = *vc.vox;
+        const double* M = vc.M;
+        const double w = std::sqrt((double)v.n);
+        double e[3], Me[3];
+        for (int a = 0; a < 3; ++a) e[a] = v.mean[a] - ta[a];
+        for (int a = 0; a < 3; ++a) Me[a] = M[3 * a] * e[0] + M[3 * a + 1] * e[1] + M[3 * a + 2] * e[2];
+        err += w * (e[0] * Me[0] + e[1] * Me[1] + e[2] * Me[2]);
+        if (!H) continue;
+        double J[18] = {0, -ta[2], ta[1], -1, 0, 0, ta[2], 0, -ta[0], 0, -1, 0, -ta[1], ta[0], 0, 0, 0, -1};
+        double MJ[18];
+        for (int a = 0; a < 3; ++a)
+            for (int cc = 0; cc < 6; ++cc) MJ[6 * a + cc] = M[3 * a] * J[cc] + M[3 * a + 1] * J[6 + cc] + M[3 * a + 2] * J[12 + cc];
+        for (int r = 0; r < 6; ++r) {
+            for (int cc = 0; cc < 6; ++cc) Hs[6 * r + cc] += w * (J[r] * MJ[cc] + J[6 + r] * MJ[6 + cc] + J[12 + r] * MJ[12 + cc]);
+            bs[r] += w * (J[r] * Me[0] + J[6 + r] * Me[1] + J[12 + r] * Me[2]);
         }
     }
     if (H) { std::memcpy(H, Hs, sizeof(Hs)); std::memcpy(b, bs, sizeof(bs)); }
     return err;
+}
+
+double linearize_voxel(Gicp& g, const double* T, double* H, double* b)
+{
+    update_voxel_correspondences(g, T);
+    return evaluate_voxel(g, T, H, b);
 }
 
 void compute_covariances(Cloud& c, int k, int threads)
@@ -367,6 +419,7 @@ void compute_covariances(Cloud& c, int k, int threads)
 void update_correspondences(Gicp& g, const double* T)
 {
     const int n = g.src.n;
+    ++g.nn_passes;
     g.corr.assign(n, -1);
     g.mahal.assign((size_t)n * 9, 0.0);
     float Tf[16];
@@ -394,10 +447,9 @@ void update_correspondences(Gicp& g, const double* T)
 // linearize (H, b optional) -> sum of e^T M e
 double linearize_voxel(Gicp& g, const double* T, double* H, double* b);
 
-double linearize(Gicp& g, const double* T, double* H, double* b)
+// sums over the cached correspondences_ / mahalanobis_ at the evaluation pose T
+double evaluate(const Gicp& g, const double* T, double* H, double* b)
 {
-    if (g.voxel_res > 0.0) return linearize_voxel(g, T, H, b);
-    update_correspondences(g, T);
     const int n = g.src.n;
     const int nt = g.threads;
     std::vector<double> Hs((size_t)nt * 36, 0.0), bs((size_t)nt * 6, 0.0), es(nt, 0.0);
@@ -443,12 +495,26 @@ double linearize(Gicp& g, const double* T, double* H, double* b)
     return err;
 }
 
+// upstream FastGICP::linearize: the only place that searches
+double linearize(Gicp& g, const double* T, double* H, double* b)
+{
+    if (g.voxel_res > 0.0) return linearize_voxel(g, T, H, b);
+    update_correspondences(g, T);
+    return evaluate(g, T, H, b);
+}
+
+// upstream FastGICP::compute_error / FastVGICPCuda::compute_error: cached correspondences and matrices
+double compute_error(const Gicp& g, const double* T)
+{
+    return g.voxel_res > 0.0 ? evaluate_voxel(g, T, nullptr, nullptr) : evaluate(g, T, nullptr, nullptr);
+}
+
 bool is_converged(const Gicp& g, const double* delta)
 {
     double mr = 0, mt = 0;
     for (int i = 0; i < 3; ++i) {
-        for (int j = 0; j < 3; ++j) mr = std::max(mr, std::fabs(delta[4 * i + j] - (i == j ? 1.0 : 0.0)) / g.rot_eps);
-        mt = std::max(mt, std::fabs(delta[4 * i + 3]) / g.trans_eps);
+        for (int j = 0; j < 3; ++j) mr = std::max(mr, g.conv_factor * std::fabs(delta[4 * i + j] - (i == j ? 1.0 : 0.0)) / g.rot_eps);
+        mt = std::max(mt, g.conv_factor * std::fabs(delta[4 * i + 3]) / g.trans_eps);
     }
     return std::max(mr, mt) < 1.0;
 }
@@ -473,7 +539,7 @@ bool step_lm(Gicp& g, double* x0, double* delta)
         se3_exp(d, delta);
         double xi[16];
         mul4(delta, x0, xi);
-        const double yi = linearize(g, xi, nullptr, nullptr);
+        const double yi = compute_error(g, xi);
         double denom = 0;
         for (int i = 0; i < 6; ++i) denom += d[i] * (g.lm_lambda * d[i] - b[i]);
         const double rho = (y0 - yi) / denom;
@@ -544,6 +610,7 @@ int orc_gicp_align(void* h, const double* guess, double* final_T, int force_iter
     g->converged = 0;
     g->iterations = 0;
     g->lm_trials = 0;
+    g->nn_passes = 0;
     const int limit = force_iters > 0 ? force_iters : g->max_iter;
     for (int i = 0; i < limit && !g->converged; ++i) {
         double delta[16];
@@ -558,6 +625,8 @@ int orc_gicp_align(void* h, const double* guess, double* final_T, int force_iter
 
 int orc_gicp_iterations(void* h) { return static_cast<Gicp*>(h)->iterations; }
 int orc_gicp_lm_trials(void* h) { return static_cast<Gicp*>(h)->lm_trials; }
+int orc_gicp_nn_passes(void* h) { return static_cast<Gicp*>(h)->nn_passes; }
+void orc_gicp_set_conv_factor(void* h, double f) { static_cast<Gicp*>(h)->conv_factor = f; }
 
 /* one linearisation at T (for kernel-level parity): returns the error, fills H[36], b[6] and,
  * if non-null, the per-source correspondences */
@@ -600,6 +669,22 @@ void orc_knn(const float* xyz, int n, int k, int* out_idx)
     for (int i = 0; i < n; ++i) {
         std::vector<float> d(k);
         t.knn(&xyz[3 * (size_t)i], k, &out_idx[(size_t)i * k], d.data());
+    }
+}
+
+/* d^2 (float, the searches' operation chain) of every float-transformed source point to tgt[idx[i]] */
+void orc_pair_d2(const float* src, int n, const double* T, const float* tgt, const int* idx, float* out)
+{
+    float Tf[16];
+    for (int i = 0; i < 16; ++i) Tf[i] = (float)T[i];
+    for (int i = 0; i < n; ++i) {
+        if (idx[i] < 0) { out[i] = std::numeric_limits<float>::infinity(); continue; }
+        const float* p = &src[3 * (size_t)i];
+        float q[3];
+        for (int a = 0; a < 3; ++a) q[a] = Tf[4 * a] * p[0] + Tf[4 * a + 1] * p[1] + Tf[4 * a + 2] * p[2] + Tf[4 * a + 3];
+        const float* t = &tgt[3 * (size_t)idx[i]];
+        const float dx = q[0] - t[0], dy = q[1] - t[1], dz = q[2] - t[2];
+        out[i] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
     }
 }
 

@@ -195,7 +195,7 @@ class RefSymbolicFunction:
 class Gicp:
     """ctypes handle on oracle/gicp_oracle.cpp (restated fast_gicp FastGICP; parity unpinned)."""
 
-    def __init__(self, k=20, max_corr=1e300, max_iter=64, rot_eps=2e-3, trans_eps=5e-4, threads=None):
+    def __init__(self, k=20, max_corr=1e300, max_iter=64, rot_eps=2e-3, trans_eps=5e-4, threads=None, conv_factor=10.0):
         L = lib()
         L.orc_gicp_create.restype = C.c_void_p
         L.orc_gicp_linearize.restype = C.c_double
@@ -203,6 +203,12 @@ class Gicp:
         self._l = L
         self._h = C.c_void_p(L.orc_gicp_create())
         self.set_params(k, max_corr, max_iter, rot_eps, trans_eps, threads or os.cpu_count() or 1)
+        L.orc_gicp_set_conv_factor(self._h, C.c_double(conv_factor))
+
+    @property
+    def nn_passes(self):
+        """update_correspondences calls of the last align (upstream: one per outer iteration)."""
+        return int(self._l.orc_gicp_nn_passes(self._h))
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -252,6 +258,17 @@ def knn(pts, k):
     p = _f32(np.asarray(pts)[:, :3])
     out = np.empty((p.shape[0], k), np.int32)
     lib().orc_knn(_p(p), p.shape[0], int(k), _p(out))
+    return out
+
+
+def pair_d2(src, T, tgt, idx):
+    """float32 squared distance of every float-transformed source point to tgt[idx[i]] (same operation chain as the
+    searches; -1 indices give inf): lets a test prove that two different neighbour indices are an exact tie."""
+    s = _f32(np.asarray(src)[:, :3]); t = _f32(np.asarray(tgt)[:, :3])
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    out = np.empty(s.shape[0], np.float32)
+    lib().orc_pair_d2(_p(s), s.shape[0], _p(T), _p(t), _p(idx), _p(out))
     return out
 
 
