@@ -193,7 +193,8 @@ int mrs_ring_corr_pairs(mrs_ctx* ctx, const float* d_a, const float* d_b, int32_
                         mrs_stream stream);
 
 /* C1 literal: fast_corr(a, b) on complex spectra, pair by pair (RING_ros/util.py:362-374).
- * d_a, d_b interleaved complex64 [n_pairs][channels][n_angles][det]; outputs per pair. */
+ * d_a, d_b interleaved complex64 [n_pairs][channels][n_angles][det]; outputs per pair.
+ * dist = 1 - max / (0.15 * n_angles * det): like the reference, NO channel factor (util.py:369). */
 int mrs_ring_corr_spectra(mrs_ctx* ctx, const float* d_a, const float* d_b, int32_t n_pairs, int32_t channels,
                           int32_t n_angles, int32_t det, float* d_dist, int32_t* d_angle, float* d_corr,
                           mrs_stream stream);

@@ -284,7 +284,9 @@ __global__ __launch_bounds__(kWG) void k_cart_lds(const float* __restrict__ xyz,
         const float gx = __builtin_fmaf(x, inv_x, inv_x), gy = __builtin_fmaf(y, inv_y, inv_y);
         const float fx = floorf(gx), fy = floorf(gy);
         const float ex = 0.5f - fabsf((gx - fx) - 0.5f), ey = 0.5f - fabsf((gy - fy) - 0.5f);  // distance to a bin edge
-        const bool fast = (bool)((int)(z > 0.0f) & (int)(z < 1.0f) & (int)(fmaxf(fabsf(x), fabsf(y)) <= 1.0f) & (int)(x * y != 0.0f) & (int)(fminf(ex, ey) >= eps));
+        // every comparison is false for a NaN operand (fmaxf / fminf would drop the NaN instead): NaN x or y leave the fast path
+        const bool fast = (bool)((int)(z > 0.0f) & (int)(z < 1.0f) & (int)(fabsf(x) <= 1.0f) & (int)(fabsf(y) <= 1.0f) & (int)(x * y != 0.0f) &
+                                 (int)(ex >= eps) & (int)(ey >= eps));
         if (fast) {
             // consecutive lidar returns share cells: a plain read broadcasts where same-address atomics serialise,
             // and most points do not raise the maximum

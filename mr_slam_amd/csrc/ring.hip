@@ -447,7 +447,7 @@ int mrs_ring_corr_spectra(mrs_ctx* ctx, const float* d_a, const float* d_b, int3
     CorrP p;
     p.C = channels; p.A = n_angles; p.D = det; p.nq = 1; p.ndb = n_pairs; p.pairwise = 0;
     p.inv_sqrt_a = 1.0f / sqrtf((float)n_angles);
-    p.denom = (float)(0.15 * channels * n_angles * det);
+    p.denom = (float)(0.15 * n_angles * det);   // util.py:369: no channel factor in fast_corr (only fast_corr_RINGplusplus has one)
     hipLaunchKernelGGL(k_corr_spectra, dim3(n_pairs), dim3(kWG), lds, (hipStream_t)stream,
                        reinterpret_cast<const float2*>(d_a), reinterpret_cast<const float2*>(d_b), p, tw, d_dist,
                        d_angle, d_corr);

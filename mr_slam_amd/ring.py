@@ -182,8 +182,16 @@ def fast_corr_RINGplusplus(a, b, device="cuda:0"):
     return dist.cpu().numpy()[0, 0], ang.cpu().numpy()[0, 0]
 
 
-def solve_translation(query, positive, rot_angle, device="cuda:0", want_shifts=False):
-    """util.py:388-423: query, positive float32 [C,H,W]; returns (x, y, error)."""
+def solve_translation(query, positive, rot_angle, device="cuda:0", want_shifts=False, literal=False):
+    """util.py:388-423: query, positive float32 [C,H,W]; returns (x, y, error).
+
+    The 120 row correlations and their integer shifts always run on the GPU.  The final 120 x 2 solve has two readings:
+    literal=False (default) is the least-squares (pseudo-inverse) solution the function intends, evaluated in the kernel;
+    literal=True reproduces the reference's SVD branch as written (util.py:488-506: `v.t() @ s_inv @ u.t() @ b`, where
+    torch.svd already returns V, so the product is the least-squares solution turned by an orthogonal matrix that
+    depends on the SVD routine's sign / ordering choices).  A is almost isotropic (both singular values ~ sqrt(H/2)), so V
+    is not a property of the data but of the LAPACK build: the literal value is formed on the host with the same
+    torch.svd call the reference makes on CPU tensors (tests/golden/ref_corr.npz holds the reference-run numbers)."""
     q = torch.as_tensor(query, dtype=torch.float32).to(device).contiguous()
     p = torch.as_tensor(positive, dtype=torch.float32).to(device).contiguous()
     Cc, H, W = q.shape
@@ -191,12 +199,24 @@ def solve_translation(query, positive, rot_angle, device="cuda:0", want_shifts=F
     angles = torch.from_numpy(np.linspace(0, 2 * np.pi, H).astype(np.float32)).to(q.device)
     rot = torch.tensor([float(rot_angle)], dtype=torch.float32, device=q.device)
     res = torch.empty(3, dtype=torch.float32, device=q.device)
-    sh = torch.empty(H, dtype=torch.float32, device=q.device) if want_shifts else None
+    sh = torch.empty(H, dtype=torch.float32, device=q.device) if (want_shifts or literal) else None
     _lib.check(_lib.load().mrs_ring_solve_translation(_lib.ctx(d), _lib.ptr(q), _lib.ptr(p), 1, Cc, H, W,
                                                       _lib.ptr(angles), _lib.ptr(rot), _lib.ptr(res),
-                                                      _lib.ptr(sh) if want_shifts else None, _lib.current_stream(d)))
-    r = res.cpu().numpy()
-    out = (r[0:1].copy(), r[1:2].copy(), r[2])
+                                                      _lib.ptr(sh) if sh is not None else None, _lib.current_stream(d)))
+    if literal:
+        b = sh.cpu()
+        ang = torch.FloatTensor(np.linspace(0, 2 * np.pi, H).astype(np.float32)) + rot_angle
+        A = torch.stack([torch.cos(ang), torch.sin(ang)], dim=1)
+        u, s, v = torch.svd(A, some=False)
+        s_new = torch.zeros(A.shape)
+        for i in range(len(s)):
+            s_new[i, i] = 1 / s[i]
+        sol = v.t() @ s_new.t() @ u.t() @ b.view(H, -1)
+        err = torch.norm(torch.matmul(A, sol) - b.view(H, -1))
+        out = (sol[0].numpy(), sol[1].numpy(), err.numpy())
+    else:
+        r = res.cpu().numpy()
+        out = (r[0:1].copy(), r[1:2].copy(), r[2])
     return out + (sh.cpu().numpy(),) if want_shifts else out
 
 

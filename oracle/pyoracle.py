@@ -43,6 +43,18 @@ def ref_polar():
     return _REF
 
 
+_REFS = {}
+
+
+def ref_lib(name):
+    """oracle/_ref/libref_<name>.so (the reference's own sources compiled by oracle/Makefile), or None if it was
+    never built (no /root/reference at build time)."""
+    if name not in _REFS:
+        path = os.path.join(_HERE, "_ref", f"libref_{name}.so")
+        _REFS[name] = C.CDLL(path) if os.path.exists(path) else None
+    return _REFS[name]
+
+
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
@@ -121,6 +133,53 @@ def bev_feat(pts_cm, F, max_length, max_height, NX, NY, H):
     out = np.zeros(NX * NY * H * F, np.float32)
     lib().orc_bev_feat(_p(pts), n, F, max_length, max_height, NX, NY, H, _p(out))
     return out
+
+
+def ref_bev_cart(xyz_soa, max_length, max_height, NX, NY, H, enough_large=1):
+    """The reference's voxelocc.GPUTransformer(...).transform(); .retreive() (generate_bev_cython_binary) on the host."""
+    r = ref_lib("cart")
+    if r is None:
+        raise RuntimeError("oracle/_ref/libref_cart.so not built")
+    xyz = _f32(xyz_soa).copy()
+    out = np.zeros(3 * NX * NY * H * enough_large, np.float32)
+    r.ref_cart_bev(_p(xyz), xyz.size // 3, max_length, max_height, NX, NY, H, enough_large, _p(out))
+    return out
+
+
+def ref_bev_cart_indices(xyz_soa, max_length, max_height, NX, NY, H):
+    r = ref_lib("cart")
+    if r is None:
+        raise RuntimeError("oracle/_ref/libref_cart.so not built")
+    xyz = _f32(xyz_soa).copy()
+    n = xyz.size // 3
+    ix = np.zeros(n, np.int32); iy = np.zeros(n, np.int32); ih = np.zeros(n, np.int32)
+    r.ref_cart_indices(_p(xyz), n, max_length, max_height, NX, NY, H, _p(ix), _p(iy), _p(ih))
+    return ix, iy, ih
+
+
+def ref_bev_feat(pts_cm, F, max_length, max_height, NX, NY, H):
+    """The reference's voxelfeat.GPUTransformer (generate_bev_pointfeat_cython), threads run in gid order."""
+    r = ref_lib("feat")
+    if r is None:
+        raise RuntimeError("oracle/_ref/libref_feat.so not built")
+    pts = _f32(pts_cm).copy()
+    out = np.zeros(NX * NY * H * F, np.float32)
+    r.ref_feat_bev(_p(pts), pts.size // F, max_length, max_height, NX, NY, H, F, _p(out))
+    return out
+
+
+def ref_point_features(pts, knn, eigens):
+    """The reference's voxelfeat.GPUFeatureExtractor(pts, n, 13, k, knn, eigens).get_features() -> [n,13]."""
+    r = ref_lib("feat")
+    if r is None:
+        raise RuntimeError("oracle/_ref/libref_feat.so not built")
+    p = _f32(pts).reshape(-1).copy()
+    knn = np.ascontiguousarray(knn, dtype=np.int32)
+    e = _f32(eigens).reshape(-1).copy()
+    n, k = knn.shape
+    out = np.zeros(n * 13, np.float32)
+    r.ref_point_features(_p(p), n, 13, k, _p(knn), _p(e), _p(out))
+    return out.reshape(n, 13)
 
 
 def occupied_fingerprint(out3):

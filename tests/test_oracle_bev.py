@@ -135,3 +135,77 @@ def test_nclt_scan_reference_golden(oracle, golden_dir):
         out = oracle.bev_polar(soa, 1, 1, R, S, H, 1)
         np.testing.assert_array_equal(np.flatnonzero(out.reshape(-1, 3)[:, 2]).astype(np.int32), g[f"occupied_{tag}"])
         assert oracle.occupied_fingerprint(out)[0] == int(g[f"fingerprint_{tag}"][0])
+
+
+# ---- rows A3 / A4 / A5: the reference's own generate_bev_* sources, compiled for the host (oracle/_ref/libref_cart.so,
+# ---- libref_feat.so) and their committed outputs (tests/golden/bev_cart_ref.npz)
+def _golden_clouds(golden_dir):
+    yield "testbin", np.load(os.path.join(golden_dir, "bev_polar_1.npz"))["xyz_soa"].reshape(3, -1).T   # == test.bin
+    yield "nclt", np.load(os.path.join(golden_dir, "nclt_scan.npz"))["hits"].astype(np.float32)
+
+
+def test_cart_oracle_matches_reference_golden(oracle, golden_dir):
+    import zlib
+    g = np.load(os.path.join(golden_dir, "bev_cart_ref.npz"))
+    for name, xyz in _golden_clouds(golden_dir):
+        soa = np.ascontiguousarray(xyz.astype(np.float32).T).reshape(-1)
+        for (NX, NY, H) in ((120, 120, 1), (40, 120, 20)):
+            tag = f"{name}_{NX}x{NY}x{H}"
+            ix, iy, ih, valid = oracle.bev_cart_indices(soa, 1, 1, NX, NY, H)
+            assert valid.all()
+            np.testing.assert_array_equal(ix, g[f"ix_{tag}"]); np.testing.assert_array_equal(iy, g[f"iy_{tag}"])
+            np.testing.assert_array_equal(ih, g[f"ih_{tag}"])
+            out = oracle.bev_cart(soa, 1, 1, NX, NY, H)
+            occ = np.flatnonzero(out.reshape(-1, 3)[:, 2]).astype(np.int32)
+            np.testing.assert_array_equal(occ, g[f"occ_{tag}"])
+            np.testing.assert_array_equal(out.reshape(-1, 3)[occ, 2], g[f"z_{tag}"])
+            assert zlib.crc32(out.tobytes()) == int(g[f"crc_{tag}"][0])      # all three channels, every cell
+
+
+def _cart_stress_cloud(rng, n):
+    """Everything the reference handles without undefined behaviour: zeros (-> 1e-4), |v| > 1 (-> +-0.9999), negative z,
+    several points per cell.  Exactly +-1.0 is left out: the reference indexes out of bounds there (idx == num)."""
+    xyz = rng.uniform(-1.3, 1.3, size=(3, n)).astype(np.float32)
+    xyz[0, :50] = 0.0; xyz[1, 25:75] = 0.0; xyz[2, 50:100] = 0.0
+    xyz[:, 100:400] = np.round(xyz[:, 100:400] * 8) / 8      # many exact bin-edge values and duplicates
+    xyz[np.abs(xyz) == 1.0] = 0.5
+    return xyz
+
+
+def test_cart_oracle_matches_reference_build_random(oracle):
+    if oracle.ref_lib("cart") is None:
+        pytest.skip("oracle/_ref/libref_cart.so not built (no /root/reference here)")
+    rng = np.random.default_rng(11)
+    for (NX, NY, H) in ((120, 120, 1), (40, 120, 20), (64, 50, 3), (7, 5, 2)):
+        soa = _cart_stress_cloud(rng, 30_000).reshape(-1)
+        a = oracle.ref_bev_cart_indices(soa, 1, 1, NX, NY, H)
+        b = oracle.bev_cart_indices(soa, 1, 1, NX, NY, H)
+        for u, v in zip(a, b[:3]):
+            np.testing.assert_array_equal(u, v)
+        np.testing.assert_array_equal(oracle.ref_bev_cart(soa, 1, 1, NX, NY, H), oracle.bev_cart(soa, 1, 1, NX, NY, H))
+    # other extents: max_length / max_height enter the gap only (kernel.cu:22-24)
+    soa = _cart_stress_cloud(rng, 10_000).reshape(-1)
+    np.testing.assert_array_equal(oracle.ref_bev_cart(soa, 2, 3, 60, 60, 4), oracle.bev_cart(soa, 2, 3, 60, 60, 4))
+
+
+def test_feat_oracle_matches_reference_golden_and_build(oracle, golden_dir):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_bev_cart", os.path.join(golden_dir, "make_golden_bev_cart.py"))
+    mk = importlib.util.module_from_spec(spec); spec.loader.exec_module(mk)
+    g = np.load(os.path.join(golden_dir, "bev_cart_ref.npz"))
+    F = 9
+    for name, xyz in _golden_clouds(golden_dir):
+        xyz = xyz.astype(np.float32)
+        cm = np.ascontiguousarray(np.concatenate([xyz, mk.extra_channels(xyz, F)], 1).T).reshape(-1)
+        out = oracle.bev_feat(cm, F, 1, 1, 120, 120, 1)
+        nz = np.flatnonzero(out).astype(np.int32)
+        np.testing.assert_array_equal(nz, g[f"feat_nz_{name}"])
+        np.testing.assert_array_equal(out[nz], g[f"feat_val_{name}"])
+    if oracle.ref_lib("feat") is None:
+        return
+    rng = np.random.default_rng(13)
+    for F in (9, 4):
+        pts = rng.uniform(-1.2, 1.2, size=(F, 20_000)).astype(np.float32)
+        pts[np.abs(pts) == 1.0] = 0.5
+        np.testing.assert_array_equal(oracle.ref_bev_feat(pts.reshape(-1), F, 1, 1, 120, 120, 1),
+                                      oracle.bev_feat(pts.reshape(-1), F, 1, 1, 120, 120, 1))
