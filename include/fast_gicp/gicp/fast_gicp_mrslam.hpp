@@ -7,8 +7,16 @@
 // getFinalTransformation).  All arithmetic happens in libmrslam_hip.so through the C ABI
 // (include/mrslam_hip.h); this header only adapts types.  It needs PCL + Eigen, which are not in
 // the build image: tests/cpp/ compiles it against a minimal mock of the pcl::Registration
-// surface it touches.  A maintainer installs it as <fast_gicp/gicp/fast_gicp.hpp> (see
-// INTEGRATION.md).
+// surface it touches.  The forwarding headers next to this file carry upstream's names
+// (<fast_gicp/gicp/fast_gicp.hpp>, fast_vgicp.hpp, fast_vgicp_cuda.hpp: the three includes of
+// Mapping/src/global_manager/include/global_manager/global_manager.h:76-81), so adding
+// <repo>/include to the include path is the whole source-side change.
+//
+// getFitnessScore: pcl::Registration::getFitnessScore is NOT virtual and upstream fast_gicp does not
+// override it, so `icp->getFitnessScore(1.0)` through the pcl::Registration::Ptr of ICPCheck
+// (global_manager.cpp:2058) runs PCL's own kd-tree implementation on the host -- with upstream and with
+// this adapter alike.  The GPU score is available on the derived type (getFitnessScore below, same
+// definition: mean squared NN distance over d^2 <= max_range).
 #pragma once
 #include <cfloat>
 #include <stdexcept>
@@ -28,6 +36,17 @@ template <typename PointSource, typename PointTarget>
 class FastGICP : public pcl::Registration<PointSource, PointTarget, float> {
 public:
     using Base = pcl::Registration<PointSource, PointTarget, float>;
+    // like upstream: Ptr / ConstPtr point at the DERIVED class, so that
+    //   fast_gicp::FastGICP<PointTI, PointTI>::Ptr gicp(new fast_gicp::FastGICP<PointTI, PointTI>());
+    //   gicp->setNumThreads(8); ... return gicp;          (global_manager.cpp:2436-2442)
+    // compiles and converts to pcl::Registration<...>::Ptr on return
+#if defined(PCL_VERSION) && PCL_VERSION >= PCL_VERSION_CALC(1, 10, 0)
+    using Ptr = pcl::shared_ptr<FastGICP<PointSource, PointTarget>>;
+    using ConstPtr = pcl::shared_ptr<const FastGICP<PointSource, PointTarget>>;
+#else
+    using Ptr = boost::shared_ptr<FastGICP<PointSource, PointTarget>>;
+    using ConstPtr = boost::shared_ptr<const FastGICP<PointSource, PointTarget>>;
+#endif
     using PointCloudSource = typename Base::PointCloudSource;
     using PointCloudSourceConstPtr = typename Base::PointCloudSourceConstPtr;
     using PointCloudTargetConstPtr = typename Base::PointCloudTargetConstPtr;
@@ -46,6 +65,7 @@ public:
     {
         mrs_gicp_batch_destroy(h_);
         mrs_ctx_destroy(ctx_);
+        if (stage_) (void)hipFree(stage_);
     }
     FastGICP(const FastGICP&) = delete;
     FastGICP& operator=(const FastGICP&) = delete;
@@ -111,14 +131,17 @@ private:
         // PCL points are 16-byte aligned structs whose first three floats are x, y, z
         const int stride = static_cast<int>(sizeof(typename Cloud::PointType) / sizeof(float));
         const size_t bytes = cloud.points.size() * sizeof(typename Cloud::PointType);
-        float* d = nullptr;
-        if (hipMalloc(reinterpret_cast<void**>(&d), bytes) != hipSuccess ||
-            hipMemcpy(d, cloud.points.data(), bytes, hipMemcpyHostToDevice) != hipSuccess)
+        if (bytes > stage_bytes_) {   // one staging buffer per object, grown on demand (no hipMalloc / hipFree per call)
+            if (stage_) (void)hipFree(stage_);
+            stage_ = nullptr; stage_bytes_ = 0;
+            if (hipMalloc(reinterpret_cast<void**>(&stage_), bytes + bytes / 4) != hipSuccess)
+                throw std::runtime_error("FastGICP(mrslam_hip): staging allocation failed");
+            stage_bytes_ = bytes + bytes / 4;
+        }
+        if (hipMemcpy(stage_, cloud.points.data(), bytes, hipMemcpyHostToDevice) != hipSuccess)
             throw std::runtime_error("FastGICP(mrslam_hip): point upload failed");
         const int64_t offs[2] = {0, static_cast<int64_t>(cloud.points.size())};
-        const int st = mrs_gicp_batch_set_clouds(h_, which, d, stride, offs, nullptr);
-        (void)hipFree(d);
-        check(st, "mrs_gicp_batch_set_clouds");
+        check(mrs_gicp_batch_set_clouds(h_, which, stage_, stride, offs, nullptr), "mrs_gicp_batch_set_clouds");   // copies out of the staging buffer
     }
     template <class M>
     static void to_row_major(const M& m, double* out)
@@ -136,6 +159,8 @@ private:
     mrs_gicp_batch* h_ = nullptr;
     mrs_gicp_params prm_;
     double hessian_[36] = {0};
+    float* stage_ = nullptr;
+    size_t stage_bytes_ = 0;
 };
 
 // Drop-in for fast_gicp::FastVGICPCuda (the launch-file default `registration_method=FAST_VGICP_CUDA`,
@@ -144,6 +169,13 @@ private:
 template <typename PointSource, typename PointTarget>
 class FastVGICPCuda : public FastGICP<PointSource, PointTarget> {
 public:
+#if defined(PCL_VERSION) && PCL_VERSION >= PCL_VERSION_CALC(1, 10, 0)
+    using Ptr = pcl::shared_ptr<FastVGICPCuda<PointSource, PointTarget>>;
+    using ConstPtr = pcl::shared_ptr<const FastVGICPCuda<PointSource, PointTarget>>;
+#else
+    using Ptr = boost::shared_ptr<FastVGICPCuda<PointSource, PointTarget>>;
+    using ConstPtr = boost::shared_ptr<const FastVGICPCuda<PointSource, PointTarget>>;
+#endif
     FastVGICPCuda()
     {
         this->reg_name_ = "FastVGICPCuda(mrslam_hip)";
@@ -155,7 +187,10 @@ public:
         nb_ = m == NeighborSearchMethod::DIRECT27 ? 27 : (m == NeighborSearchMethod::DIRECT7 ? 7 : 1);
         this->setVoxelMode(res_, nb_);
     }
-    void setKernelWidth(double) {}   // RBF-kernel covariances are not implemented (kNN covariances are used)
+    // upstream: kernel width of the GPU_RBF_KERNEL covariance estimator, which only takes effect after
+    // setNearestNeighborSearchMethod(GPU_RBF_KERNEL); MR_SLAM never selects it (global_manager.cpp:2446-2453), the
+    // default estimator (kNN covariances, what this class computes) ignores the width upstream too
+    void setKernelWidth(double, double = -1.0) {}
 private:
     double res_ = 1.0;
     int nb_ = 1;

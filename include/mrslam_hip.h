@@ -395,6 +395,14 @@ int mrs_ring_corr_fft_sweep_f16(mrs_ctx* ctx, const float* d_query_spec, int32_t
 int mrs_voxel_downsample(mrs_ctx* ctx, const void* d_points, int32_t is_double, int32_t stride, int32_t n,
                          double voxel_size, double* d_out, int32_t* h_count, mrs_stream stream);
 
+/* G1: pygicp.downsample(points, resolution) (RING_ros/main_RING.py:84-85, disco_ros/main.py:177-178, main_SC.py:111-112)
+ * = pcl::ApproximateVoxelGrid<pcl::PointXYZ> with leaf (r, r, r): points narrowed to float, a 512-entry direct-mapped
+ * history streamed in input order (a voxel evicted by a colliding one and met again yields another output point),
+ * centroids in float, output in flush order.  Same arguments as mrs_voxel_downsample; the result equals the sequential
+ * filter bit for bit, order included.  Synchronises `stream`. */
+int mrs_voxel_downsample_approx(mrs_ctx* ctx, const void* d_points, int32_t is_double, int32_t stride, int32_t n,
+                                double leaf_size, double* d_out, int32_t* h_count, mrs_stream stream);
+
 /* load_pc_infer (RING_ros/util.py:91-112, disco_ros/main.py:94-113) for a batch of raw clouds: float32
  * cast, keep |x|,|y| < 70 and 0 < z < 30, divide by 70/70/30.  Raw cloud b = points
  * [raw_offsets[b], raw_offsets[b+1]) (the offsets are needed on both sides: d_ device, h_ host).

@@ -8,16 +8,20 @@ import numpy as np
 from .. import gicp as _gicp
 
 
-def downsample(points, resolution):
-    """Voxel-grid centroid filter.  Upstream uses pcl::ApproximateVoxelGrid, a hash-bucketed,
-    input-order dependent approximation of exactly this filter (parity unpinned: PCL is not in the
-    tree); pre-processing is SURVEY.md row N2, done on the host here."""
-    p = np.asarray(points, dtype=np.float64)[:, :3]
-    key = np.floor(p / float(resolution)).astype(np.int64)
-    _, inv, cnt = np.unique(key, axis=0, return_inverse=True, return_counts=True)
-    out = np.zeros((cnt.size, 3), np.float64)
-    np.add.at(out, inv.reshape(-1), p)
-    return out / cnt[:, None]
+def downsample(points, resolution, approximate=True, device="cuda:0"):
+    """pygicp.downsample(points, resolution) -> float64 [m,3].
+
+    approximate=True (default) is upstream's filter: pcl::ApproximateVoxelGrid (512-entry hash history streamed in input
+    order, float centroids, flush order) on the GPU (mrs_voxel_downsample_approx), bit-identical to the sequential filter
+    as restated in oracle/voxel_oracle.c.  approximate=False is the exact voxel-grid centroid filter
+    (mrs_voxel_downsample, one centroid per occupied voxel)."""
+    import torch
+    from .. import preprocess
+    p = torch.from_numpy(np.ascontiguousarray(np.asarray(points, dtype=np.float64)[:, :3])).to(device)
+    if p.shape[0] == 0:
+        return np.zeros((0, 3), np.float64)
+    out = preprocess.approx_voxel_grid(p, float(resolution)) if approximate else preprocess.voxel_down_sample(p, float(resolution))
+    return out.cpu().numpy()
 
 
 class FastGICP:

@@ -6,6 +6,13 @@
 //     floor((p - (min_bound - voxel/2)) / voxel) in double, output = mean of the points of each voxel
 //     (double).  open3d's output ORDER is the iteration order of an unordered_map (unspecified);
 //     here voxels come out sorted by (ix, iy, iz), points of a voxel summed in input order.
+//   * pygicp.downsample(points, 0.2) (main_RING.py:84-85) = pcl::ApproximateVoxelGrid<PointXYZ>: a 512-entry
+//     direct-mapped history streamed over the points in input order (row G1).  The stream is a state machine, but
+//     its output has a closed form that parallelises exactly: the points of one hash bucket, in input order, split
+//     into maximal runs of equal voxel coordinates; every run is one output centroid (float sum in input order /
+//     float count); a run is flushed when the next run of its bucket starts (flush time = input index of that
+//     run's first point) and the last run of every bucket at the end, in bucket order.  So: stable radix sort by
+//     bucket, run heads, one thread per run, then a sort of the runs by flush time.  Bit-identical to the stream.
 //   * load_pc_infer: LoopDetection/src/RING_ros/util.py:91-112: float32 cast, keep |x|,|y| < 70 and
 //     0 < z < 30, divide by 70/70/30 (float32), order preserved.  The output is written straight in the
 //     ragged SoA layout the BEV kernels consume, with device-side offsets: no host round trip.
@@ -85,6 +92,70 @@ __global__ void k_voxel_means(const T* __restrict__ pts, int stride, const unsig
         }
         double* o = out + (size_t)slot[i] * 3;
         o[0] = s0 / c; o[1] = s1 / c; o[2] = s2 / c;
+    }
+}
+
+// ---- pcl::ApproximateVoxelGrid (row G1) -----------------------------------------------------------------------
+constexpr int kHist = 512;   // histsize_ of pcl::ApproximateVoxelGrid
+
+template <class T>
+__global__ void k_avg_keys(const T* __restrict__ pts, int stride, int n, float inv_leaf, unsigned* __restrict__ bucket,
+                           int3* __restrict__ vox, int* __restrict__ vals)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float x = (float)pts[(size_t)i * stride], y = (float)pts[(size_t)i * stride + 1], z = (float)pts[(size_t)i * stride + 2];
+        const int ix = (int)floorf(x * inv_leaf), iy = (int)floorf(y * inv_leaf), iz = (int)floorf(z * inv_leaf);
+        bucket[i] = (unsigned)((ix * 7171 + iy * 3079 + iz * 4231) & (kHist - 1));
+        vox[i] = make_int3(ix, iy, iz);
+        vals[i] = i;
+    }
+}
+
+// sorted position j (by bucket, then input index): head of a run?
+__global__ void k_avg_heads(const unsigned* __restrict__ sbucket, const int* __restrict__ perm, const int3* __restrict__ vox, int n,
+                            int* __restrict__ head)
+{
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        bool h = j == 0 || sbucket[j] != sbucket[j - 1];
+        if (!h) {
+            const int3 a = vox[perm[j]], b = vox[perm[j - 1]];
+            h = a.x != b.x || a.y != b.y || a.z != b.z;
+        }
+        head[j] = h ? 1 : 0;
+    }
+}
+
+// one thread per run: float sum in input order, centroid, flush time
+template <class T>
+__global__ void k_avg_runs(const T* __restrict__ pts, int stride, const unsigned* __restrict__ sbucket, const int* __restrict__ perm,
+                           const int* __restrict__ head, const int* __restrict__ slot, int n, float* __restrict__ centroid,
+                           unsigned* __restrict__ flush_key, int* __restrict__ run_id)
+{
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        if (!head[j]) continue;
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+        int c = 0, e = j;
+        do {
+            const T* p = pts + (size_t)perm[e] * stride;
+            s0 += (float)p[0]; s1 += (float)p[1]; s2 += (float)p[2];
+            ++c; ++e;
+        } while (e < n && !head[e]);
+        const int r = slot[j];
+        const float fc = (float)c;
+        centroid[3 * (size_t)r] = s0 / fc; centroid[3 * (size_t)r + 1] = s1 / fc; centroid[3 * (size_t)r + 2] = s2 / fc;
+        // evicted by the first point of the next run of the same bucket; the last run of a bucket is flushed at the end
+        flush_key[r] = (e < n && sbucket[e] == sbucket[j]) ? (unsigned)perm[e] : (unsigned)n + sbucket[j];
+        run_id[r] = r;
+    }
+}
+
+__global__ void k_avg_emit(const float* __restrict__ centroid, const int* __restrict__ order, int m, double* __restrict__ out)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const int r = order[i];
+        out[3 * (size_t)i] = (double)centroid[3 * (size_t)r];
+        out[3 * (size_t)i + 1] = (double)centroid[3 * (size_t)r + 1];
+        out[3 * (size_t)i + 2] = (double)centroid[3 * (size_t)r + 2];
     }
 }
 
@@ -176,6 +247,56 @@ int voxel_downsample_impl(mrs_ctx* ctx, const T* d_pts, int stride, int n, doubl
 }
 
 template <class T>
+int approx_voxel_grid_impl(mrs_ctx* ctx, const T* d_pts, int stride, int n, float leaf, double* d_out, int32_t* h_count, hipStream_t s)
+{
+    mrs::Scratch bucket, sbucket, vox, vals_in, perm, head, slot, cent, fkey, fkey_s, rid, order, tmp;
+    int st;
+    if ((st = bucket.alloc((size_t)n * 4, s)) != MRS_OK) return st;
+    if ((st = sbucket.alloc((size_t)n * 4, s)) != MRS_OK) return st;
+    if ((st = vox.alloc((size_t)n * sizeof(int3), s)) != MRS_OK) return st;
+    if ((st = vals_in.alloc((size_t)n * 4, s)) != MRS_OK) return st;
+    if ((st = perm.alloc((size_t)n * 4, s)) != MRS_OK) return st;
+    if ((st = head.alloc((size_t)n * 4, s)) != MRS_OK) return st;
+    if ((st = slot.alloc((size_t)n * 4, s)) != MRS_OK) return st;
+    if ((st = cent.alloc((size_t)n * 12, s)) != MRS_OK) return st;
+    if ((st = fkey.alloc((size_t)n * 4, s)) != MRS_OK) return st;
+    if ((st = fkey_s.alloc((size_t)n * 4, s)) != MRS_OK) return st;
+    if ((st = rid.alloc((size_t)n * 4, s)) != MRS_OK) return st;
+    if ((st = order.alloc((size_t)n * 4, s)) != MRS_OK) return st;
+    const float inv_leaf = 1.0f / leaf;   // inverse_leaf_size_ = Ones / leaf_size_ (float)
+    hipLaunchKernelGGL(k_avg_keys<T>, dim3(grid_for(n)), dim3(256), 0, s, d_pts, stride, n, inv_leaf, bucket.as<unsigned>(),
+                       vox.as<int3>(), vals_in.as<int>());
+    size_t b1 = 0, b2 = 0, b3 = 0;
+    MRS_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, b1, bucket.as<unsigned>(), sbucket.as<unsigned>(), vals_in.as<int>(),
+                                                   perm.as<int>(), n, 0, 9, s));
+    MRS_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, b2, head.as<int>(), slot.as<int>(), n, s));
+    MRS_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, b3, fkey.as<unsigned>(), fkey_s.as<unsigned>(), rid.as<int>(), order.as<int>(),
+                                                   n, 0, 32, s));
+    if ((st = tmp.alloc(std::max(b1, std::max(b2, b3)), s)) != MRS_OK) return st;
+    // 9-bit keys, stable: bucket-major, input order inside a bucket
+    MRS_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, b1, bucket.as<unsigned>(), sbucket.as<unsigned>(), vals_in.as<int>(),
+                                                   perm.as<int>(), n, 0, 9, s));
+    hipLaunchKernelGGL(k_avg_heads, dim3(grid_for(n)), dim3(256), 0, s, sbucket.as<unsigned>(), perm.as<int>(), vox.as<int3>(), n,
+                       head.as<int>());
+    MRS_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, b2, head.as<int>(), slot.as<int>(), n, s));
+    int last_head = 0, last_slot = 0;
+    MRS_HIP_TRY(hipMemcpyAsync(&last_head, head.as<int>() + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    MRS_HIP_TRY(hipMemcpyAsync(&last_slot, slot.as<int>() + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(k_avg_runs<T>, dim3(grid_for(n)), dim3(256), 0, s, d_pts, stride, sbucket.as<unsigned>(), perm.as<int>(),
+                       head.as<int>(), slot.as<int>(), n, cent.as<float>(), fkey.as<unsigned>(), rid.as<int>());
+    MRS_HIP_TRY(hipGetLastError());
+    MRS_HIP_TRY(hipStreamSynchronize(s));
+    const int m = last_head + last_slot;
+    MRS_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, b3, fkey.as<unsigned>(), fkey_s.as<unsigned>(), rid.as<int>(), order.as<int>(),
+                                                   m, 0, 32, s));
+    hipLaunchKernelGGL(k_avg_emit, dim3(grid_for(m)), dim3(256), 0, s, cent.as<float>(), order.as<int>(), m, d_out);
+    MRS_HIP_TRY(hipGetLastError());
+    MRS_HIP_TRY(hipStreamSynchronize(s));
+    *h_count = m;
+    return MRS_OK;
+}
+
+template <class T>
 int crop_scale_impl(mrs_ctx* ctx, const T* d_pts, int stride, const int64_t* d_raw_offs, int64_t total_raw, int longest,
                     int batch, float* d_xyz_soa, int64_t* d_out_offs, hipStream_t s)
 {
@@ -211,6 +332,17 @@ int mrs_voxel_downsample(mrs_ctx* ctx, const void* d_points, int32_t is_double, 
     MRS_HIP_TRY(hipSetDevice(ctx->device));
     return is_double ? voxel_downsample_impl<double>(ctx, (const double*)d_points, stride, n, voxel_size, d_out, h_count, (hipStream_t)stream)
                      : voxel_downsample_impl<float>(ctx, (const float*)d_points, stride, n, voxel_size, d_out, h_count, (hipStream_t)stream);
+}
+
+int mrs_voxel_downsample_approx(mrs_ctx* ctx, const void* d_points, int32_t is_double, int32_t stride, int32_t n,
+                                double leaf_size, double* d_out, int32_t* h_count, mrs_stream stream)
+{
+    MRS_REQUIRE(ctx && d_points && d_out && h_count, "null pointer");
+    MRS_REQUIRE(n > 0 && stride >= 3, "n must be positive and stride >= 3");
+    MRS_REQUIRE(leaf_size > 0.0, "leaf_size must be positive");
+    MRS_HIP_TRY(hipSetDevice(ctx->device));
+    return is_double ? approx_voxel_grid_impl<double>(ctx, (const double*)d_points, stride, n, (float)leaf_size, d_out, h_count, (hipStream_t)stream)
+                     : approx_voxel_grid_impl<float>(ctx, (const float*)d_points, stride, n, (float)leaf_size, d_out, h_count, (hipStream_t)stream);
 }
 
 int mrs_crop_scale_batch(mrs_ctx* ctx, const void* d_points, int32_t is_double, int32_t stride, const int64_t* d_raw_offsets,

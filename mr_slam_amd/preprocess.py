@@ -22,6 +22,21 @@ def voxel_down_sample(points, voxel_size):
     return out[: cnt.value]
 
 
+def approx_voxel_grid(points, leaf_size):
+    """pcl::ApproximateVoxelGrid as pygicp.downsample(points, leaf) applies it (main_RING.py:84-85; row G1): points device
+    tensor [n, s>=3] float32/float64 -> float64 device tensor [m,3] (float-precision centroids in the filter's flush
+    order, bit-identical to the sequential filter)."""
+    assert points.is_cuda and points.dtype in (torch.float32, torch.float64)
+    d = points.device.index or 0
+    p = points.contiguous()
+    n = p.shape[0]
+    out = torch.empty((n, 3), dtype=torch.float64, device=p.device)
+    cnt = C.c_int32(0)
+    _lib.check(_lib.load().mrs_voxel_downsample_approx(_lib.ctx(d), _lib.ptr(p), int(p.dtype == torch.float64), int(p.shape[1]),
+                                                       n, C.c_double(leaf_size), _lib.ptr(out), C.byref(cnt), _lib.current_stream(d)))
+    return out[: cnt.value]
+
+
 def load_pc_infer_batch(points, raw_offsets):
     """util.py:91-112 for a batch: points device tensor [N, s>=3] (float32/float64) of raw clouds,
     raw_offsets host int64 [B+1].  Returns (xyz_soa float32 device [3*N] (upper bound, ragged SoA),

@@ -331,6 +331,15 @@ def pair_d2(src, T, tgt, idx):
     return out
 
 
+def approx_voxel_grid(points, leaf):
+    """pygicp.downsample(points, leaf) = pcl::ApproximateVoxelGrid restated (oracle/voxel_oracle.c): float64 [n,3] in,
+    float64 [m,3] out (float precision, flush order)."""
+    p = _f32(np.asarray(points)[:, :3])
+    out = np.empty((p.shape[0], 3), np.float32)
+    m = lib().orc_approx_voxel_grid(_p(p), p.shape[0], C.c_float(leaf), _p(out))
+    return out[:m].astype(np.float64)
+
+
 def se3_exp(a):
     a = np.ascontiguousarray(a, dtype=np.float64)
     T = np.empty((4, 4), np.float64)

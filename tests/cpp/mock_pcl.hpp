@@ -2,9 +2,14 @@
 // image).  Mirrors names and members of pcl::Registration<S,T,float> (pcl/registration/registration.h)
 // that fast_gicp-style subclasses use.  Test scaffolding only.
 #pragma once
+#include <cfloat>
+#include <limits>
 #include <memory>
 #include <string>
 #include <vector>
+
+#define PCL_VERSION_CALC(MAJ, MIN, PATCH) ((MAJ)*100000 + (MIN)*100 + (PATCH))
+#define PCL_VERSION PCL_VERSION_CALC(1, 12, 0)   // pcl/pcl_config.h: a PCL with pcl::shared_ptr (>= 1.10)
 
 namespace Eigen {
 struct Matrix4f {
@@ -16,6 +21,8 @@ struct Matrix4f {
 }  // namespace Eigen
 
 namespace pcl {
+template <class T>
+using shared_ptr = std::shared_ptr<T>;            // pcl/memory.h (PCL >= 1.10; boost::shared_ptr before)
 struct alignas(16) PointXYZI { float x, y, z, pad; float intensity, p1, p2, p3; };
 template <class P>
 struct PointCloud {
@@ -51,6 +58,24 @@ public:
     void setTransformationEpsilon(double e) { transformation_epsilon_ = e; }
     void setMaxCorrespondenceDistance(double d) { corr_dist_threshold_ = d; }
     bool hasConverged() const { return converged_; }
+    // NOT virtual in PCL (pcl/registration/registration.h): through a Registration::Ptr this host implementation
+    // runs, whatever the derived class defines.  Mean squared NN distance over d^2 <= max_range (brute force here).
+    double getFitnessScore(double max_range = std::numeric_limits<double>::max())
+    {
+        PointCloudSource moved;
+        transformPointCloud(*input_, moved, final_transformation_);
+        double sum = 0; long nr = 0;
+        for (const auto& p : moved.points) {
+            double best = std::numeric_limits<double>::max();
+            for (const auto& q : target_->points) {
+                const double dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+                const double d = dx * dx + dy * dy + dz * dz;
+                if (d < best) best = d;
+            }
+            if (best <= max_range) { sum += best; ++nr; }
+        }
+        return nr > 0 ? sum / nr : std::numeric_limits<double>::max();
+    }
     Matrix4 getFinalTransformation() const { return final_transformation_; }
     void align(PointCloudSource& output, const Matrix4& guess = Matrix4::Identity()) { computeTransformation(output, guess); }
 protected:

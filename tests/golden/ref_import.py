@@ -167,11 +167,17 @@ class reference_modules:
             compat.install()
         return self
 
+    _OURS = ("util", "config", "DiSCO", "models", "voxelocc", "voxelfeat", "gputransform", "torch_radon", "pygicp",
+             "torchvision", "torchvision.transforms", "torchvision.transforms.functional", "torchvision.utils",
+             "skimage", "skimage.morphology", "skimage.transform", "knn_cuda")
+
     def __exit__(self, *exc):
-        for k in list(sys.modules):
-            if k not in self._saved_modules:
-                del sys.modules[k]
-        sys.modules.update(self._saved_modules)
+        # drop only what this context registered or the reference pulled in under these names (never torch's own
+        # late-imported submodules), then put back whatever was there before
+        for k in self._OURS:
+            sys.modules.pop(k, None)
+            if k in self._saved_modules:
+                sys.modules[k] = self._saved_modules[k]
         sys.path[:] = self._saved_path
         return False
 

@@ -79,3 +79,27 @@ def test_wire_format():
     assert id0 == (97 << 56) + 42 and id1 == (99 << 56) + 8
     assert chr(id0 >> 56) == "a" and (id0 & ((1 << 56) - 1)) == 42
     assert P.loopinfo_line(0, 41, 2, 7, (1.0, 2.0, 3.0), (0.0, 0.0, 0.0, 1.0)) == "0 41 2 7 1.0 2.0 3.0 0.0 0.0 0.0 1.0"
+
+
+def test_approximate_voxel_grid_is_the_sequential_pcl_filter(oracle):
+    """Row G1: pygicp.downsample = pcl::ApproximateVoxelGrid.  The GPU form (stable sort by hash bucket, runs, flush-time
+    sort) reproduces the sequential 512-entry history filter bit for bit -- values AND output order -- on lidar-ordered,
+    shuffled, tiny and heavily colliding inputs, float32 and float64 sources."""
+    import torch
+    from mr_slam_amd import preprocess, synth
+    from mr_slam_amd.compat import pygicp
+    rng = np.random.default_rng(0)
+    lidar = synth.lidar_scan(3, 120000, metric=True)
+    cases = [(lidar, 0.2), (lidar[rng.permutation(lidar.shape[0])], 0.2), (lidar[:5], 0.2), (lidar[:1], 0.5),
+             (rng.normal(0, 30, (50000, 3)).astype(np.float32), 1.0),          # > 512 live voxels: constant evictions
+             (np.repeat(lidar[:300], 7, 0), 0.05), (rng.uniform(-0.01, 0.01, (4000, 3)).astype(np.float32), 0.2)]
+    for pts, leaf in cases:
+        want = oracle.approx_voxel_grid(pts, leaf)
+        for dt in (torch.float32, torch.float64):
+            got = preprocess.approx_voxel_grid(torch.from_numpy(np.ascontiguousarray(pts)).to(dt).cuda(), leaf).cpu().numpy()
+            assert got.shape == want.shape
+            np.testing.assert_array_equal(got, want)
+    got = pygicp.downsample(lidar.astype(np.float64), 0.2)                   # the drop-in's default is upstream's filter
+    np.testing.assert_array_equal(got, oracle.approx_voxel_grid(lidar, 0.2))
+    exact = pygicp.downsample(lidar.astype(np.float64), 0.2, approximate=False)
+    assert exact.shape[0] == np.unique(np.floor(lidar.astype(np.float64) / 0.2), axis=0).shape[0] <= got.shape[0]
