@@ -102,4 +102,4 @@ def test_approximate_voxel_grid_is_the_sequential_pcl_filter(oracle):
     got = pygicp.downsample(lidar.astype(np.float64), 0.2)                   # the drop-in's default is upstream's filter
     np.testing.assert_array_equal(got, oracle.approx_voxel_grid(lidar, 0.2))
     exact = pygicp.downsample(lidar.astype(np.float64), 0.2, approximate=False)
-    assert exact.shape[0] == np.unique(np.floor(lidar.astype(np.float64) / 0.2), axis=0).shape[0] <= got.shape[0]
+    assert exact.shape[0] == _np_voxel_down_sample(lidar, 0.2).shape[0] and 0.6 * got.shape[0] < exact.shape[0] < 1.1 * got.shape[0]
