@@ -151,10 +151,16 @@ int mrs_radon_plan_destroy(mrs_radon_plan* plan);
 int mrs_radon_forward(mrs_radon_plan* plan, const float* d_img, int32_t batch, float* d_sino,
                       float* d_sino_norm, mrs_stream stream);
 
+/* Sinograms whose fused normalisation met a zero or non-finite standard deviation since the plan was created (or since
+ * the last call with reset != 0): a blank / constant image.  The reference raises there (torchvision fn.normalize:
+ * ValueError, RING_ros/util.py:197); the kernels write an all-zero normalised sinogram (finite, correlates with nothing:
+ * dist = 1) and count the event so that the host mirror can raise the same error.  Synchronises the device. */
+int mrs_radon_plan_degenerate_count(mrs_radon_plan* plan, int32_t reset, int32_t* out_count);
+
 /* (x - mean) / std over n_groups consecutive groups of group_len floats (unbiased std):
  * torchvision fn.normalize(t, mean=t.mean(), std=t.std()) as RING_ros/util.py:197,339-340,429-430
  * use it (RING++ normalises a whole [C,H,W] descriptor with ONE mean/std -> group_len=C*H*W).
- * In-place allowed (d_out == d_in). */
+ * In-place allowed (d_out == d_in).  A constant group (std == 0; torchvision raises) is written as zeros. */
 int mrs_normalize_groups(mrs_ctx* ctx, const float* d_in, float* d_out, int32_t n_groups,
                          int32_t group_len, mrs_stream stream);
 

@@ -28,6 +28,8 @@ struct mrs_radon_plan {
     float spacing = 1.0f;
     bool in_lds = true;      // the zero-bordered image fits the LDS (else: global-memory path)
     int* d_meta = nullptr;   // ray table, one allocation: meta | base | q | vm | n, each [n_angles*det]
+    int* d_degenerate = nullptr;  // sinograms with zero / non-finite std seen by the fused normalisation
+    bool two_in_lds = false; // two interleaved images fit the LDS (k_radon2)
 };
 
 namespace {
@@ -189,6 +191,78 @@ __device__ __forceinline__ float trace_ray(const float* img, const RadonP& p, in
     return acc * n;
 }
 
+// ---- two images per workgroup -------------------------------------------------------------------------------
+// The geometry of a ray is the same for every image, so a lane that marches ray r through TWO images shares the whole
+// index chain (q += vm, fract, cvt, address, 1 - fr) between them: per sample and image 4.5 VALU instead of 7.  The two
+// images are interleaved texel by texel in the LDS ((A,B) cells of 8 bytes): one ds_read_b64 fetches a tap of both, and
+// the packed FMA (A_t, B_t) * (w, w) advances both images' running sums.  Arithmetic per image is exactly the
+// single-image loop's (same operations, same order): results are bit-identical.
+// volatile: keeps every tap a ds_read_b64 (2 LDS cycles per wave, 64 banks); the load/store optimiser would otherwise
+// fuse pairs into ds_read2_b64, which moves the same bytes at half the rate (MI355X_MICROARCH.md, LDS table)
+typedef const volatile __attribute__((address_space(3))) v2f* lds_v2ptr;
+__device__ __forceinline__ v2f lds_cell(unsigned addr) { return *(lds_v2ptr)(uintptr_t)addr; }
+
+template <bool YDOM, int STRIDE>
+__device__ __forceinline__ void march2(unsigned off, float q, float vm, int n_steps, int rstride, float& outA, float& outB)
+{
+    const int stride = STRIDE > 0 ? STRIDE : rstride;
+    const int unit = (YDOM ? 1 : stride) * 8;   // bytes between the two taps == bytes per minor index
+    const int lstep = (YDOM ? stride : 1) * 8;  // bytes per sample along the dominant axis
+    constexpr int U = 6;
+    v2f acc0 = {0.0f, 0.0f}, acc1 = {0.0f, 0.0f};   // per tap: (image A, image B)
+    int j = 0;
+#pragma nounroll
+    for (; j + U <= n_steps; j += U) {
+        v2f t0[U], t1[U];
+        float w0[U], w1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float fr = __builtin_amdgcn_fractf(q);
+            const unsigned a = off + (unsigned)(YDOM ? (int)q * 8 : __mul24((int)q, unit));
+            t0[u] = lds_cell(a + u * lstep);
+            t1[u] = lds_cell(a + u * lstep + unit);
+            w0[u] = 1.0f - fr;
+            w1[u] = fr;
+            q += vm;
+        }
+        off += U * lstep;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const v2f W0 = {w0[u], w0[u]}, W1 = {w1[u], w1[u]};
+            acc0 = __builtin_elementwise_fma(t0[u], W0, acc0);
+            acc1 = __builtin_elementwise_fma(t1[u], W1, acc1);
+        }
+    }
+    for (; j < n_steps; ++j) {
+        const float fr = __builtin_amdgcn_fractf(q);
+        const unsigned a = off + (unsigned)(YDOM ? (int)q * 8 : __mul24((int)q, unit));
+        const v2f t0 = lds_cell(a), t1 = lds_cell(a + unit);
+        const float w0 = 1.0f - fr;
+        const v2f W0 = {w0, w0}, W1 = {fr, fr};
+        acc0 = __builtin_elementwise_fma(t0, W0, acc0);
+        acc1 = __builtin_elementwise_fma(t1, W1, acc1);
+        q += vm;
+        off += lstep;
+    }
+    outA = acc0.x + acc1.x;
+    outB = acc0.y + acc1.y;
+}
+
+template <int STRIDE>
+__device__ __forceinline__ void trace_ray2(const v2f* cells, const RadonP& p, int ray, float& outA, float& outB)
+{
+    const int meta = p.meta[ray];
+    const int n_steps = meta & 0xffff;
+    if (n_steps == 0) { outA = 0.0f; outB = 0.0f; return; }
+    const float q = p.q[ray], vm = p.vm[ray], n = p.nrm[ray];
+    const unsigned tile = (unsigned)(uintptr_t)(lds_cptr)reinterpret_cast<const char*>(cells) + 2u * (unsigned)p.base[ray];
+    float a, b;
+    if (meta >> 16) march2<true, STRIDE>(tile, q, vm, n_steps, p.stride, a, b);
+    else march2<false, STRIDE>(tile, q, vm, n_steps, p.stride, a, b);
+    outA = a * n;
+    outB = b * n;
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -207,13 +281,55 @@ __device__ __forceinline__ float trace_ray_global(const float* padded, const Rad
     return acc * p.nrm[ray];
 }
 
+// Mean / unbiased std of `rays` values held as val[k] by the workgroup's lanes; returns (mean, sd).  A constant
+// sinogram (blank image) has sd == 0: torchvision's fn.normalize raises there (util.py:197); here the normalised
+// output is written as zeros and *degenerate is counted up so that the host mirror can raise the same error.
+template <int N>
+__device__ __forceinline__ void normalize_store(const float (&val)[N], int rays, double (&red)[2][16], float* __restrict__ dst,
+                                                int* __restrict__ degenerate)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        if (threadIdx.x + k * kRadonWG < rays) s1 += (double)val[k];
+    s1 = wave_sum(s1);
+    __syncthreads();
+    if (lane == 0) red[0][wave] = s1;
+    __syncthreads();
+    double tot = 0.0;
+    for (int w = 0; w < kRadonWG / 64; ++w) tot += red[0][w];
+    const double mean_d = tot / (double)rays;
+    const float mean = (float)mean_d;
+    double s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        if (threadIdx.x + k * kRadonWG < rays) {
+            const double dlt = (double)val[k] - mean_d;
+            s2 += dlt * dlt;
+        }
+    s2 = wave_sum(s2);
+    if (lane == 0) red[1][wave] = s2;
+    __syncthreads();
+    double tot2 = 0.0;
+    for (int w = 0; w < kRadonWG / 64; ++w) tot2 += red[1][w];
+    const float sd = (float)sqrt(tot2 / (double)(rays - 1));
+    const bool ok = sd > 0.0f && sd < INFINITY;
+    if (!ok && threadIdx.x == 0 && degenerate) atomicAdd(degenerate, 1);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int ray = threadIdx.x + k * kRadonWG;
+        if (ray < rays) dst[ray] = ok ? (val[k] - mean) / sd : 0.0f;
+    }
+}
+
 // One workgroup per image.  sino_raw / sino_norm may each be null.
 // sino_norm = (S - mean(S)) / std(S) with the unbiased std over the whole sinogram
 // (util.py:197: fn.normalize(pc_RING, mean=pc_RING.mean(), std=pc_RING.std())).
 template <int MAX_RAYS_PER_LANE, int STRIDE>
 __global__ __launch_bounds__(kRadonWG) void k_radon(const float* __restrict__ img, RadonP p,
                                                     float* __restrict__ sino_raw,
-                                                    float* __restrict__ sino_norm)
+                                                    float* __restrict__ sino_norm, int* __restrict__ degenerate)
 {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     __shared__ double red[2][16];
@@ -230,7 +346,6 @@ __global__ __launch_bounds__(kRadonWG) void k_radon(const float* __restrict__ im
 
     const int rays = p.A * p.D;
     float val[MAX_RAYS_PER_LANE];
-    double s1 = 0.0;
 #pragma unroll
     for (int k = 0; k < MAX_RAYS_PER_LANE; ++k) {
         const int ray = threadIdx.x + k * kRadonWG;
@@ -238,40 +353,55 @@ __global__ __launch_bounds__(kRadonWG) void k_radon(const float* __restrict__ im
         if (ray < rays) {
             v = trace_ray<STRIDE>(tile, p, ray);
             if (sino_raw) sino_raw[(size_t)b * rays + ray] = v;
-            s1 += (double)v;
         }
         val[k] = v;
     }
     if (!sino_norm) return;
-    // mean, then centred sum of squares (two-pass, double accumulation)
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    s1 = wave_sum(s1);
-    if (lane == 0) red[0][wave] = s1;
+    normalize_store<MAX_RAYS_PER_LANE>(val, rays, red, sino_norm + (size_t)b * rays, degenerate);
+}
+
+// Two images per workgroup (see march2).  grid = ceil(batch / 2); an odd batch leaves the last workgroup's second slot
+// empty (zero image, nothing stored).
+template <int MAX_RAYS_PER_LANE, int STRIDE>
+__global__ __launch_bounds__(kRadonWG) void k_radon2(const float* __restrict__ img, RadonP p, int batch,
+                                                     float* __restrict__ sino_raw, float* __restrict__ sino_norm,
+                                                     int* __restrict__ degenerate)
+{
+    extern __shared__ __attribute__((aligned(16))) v2f cells[];
+    __shared__ double red[2][16];
+    const int b0 = 2 * blockIdx.x, b1 = b0 + 1;
+    const bool two = b1 < batch;
+    const float* srcA = img + (size_t)b0 * p.H * p.W;
+    const float* srcB = img + (size_t)(two ? b1 : b0) * p.H * p.W;
+    const int rows = p.H + 2 * kPad;
+    const v2f zero = {0.0f, 0.0f};
+    for (int i = threadIdx.x; i < rows * p.stride; i += kRadonWG) cells[i] = zero;
     __syncthreads();
-    double tot = 0.0;
-    for (int w = 0; w < kRadonWG / 64; ++w) tot += red[0][w];
-    const double mean_d = tot / (double)rays;
-    const float mean = (float)mean_d;
-    double s2 = 0.0;
+    for (int i = threadIdx.x; i < p.H * p.W; i += kRadonWG) {
+        const int y = i / p.W, x = i - y * p.W;
+        const v2f c = {srcA[i], two ? srcB[i] : 0.0f};
+        cells[(y + kPad) * p.stride + x + kPad] = c;
+    }
+    __syncthreads();
+
+    const int rays = p.A * p.D;
+    float va[MAX_RAYS_PER_LANE], vb[MAX_RAYS_PER_LANE];
 #pragma unroll
     for (int k = 0; k < MAX_RAYS_PER_LANE; ++k) {
         const int ray = threadIdx.x + k * kRadonWG;
+        float a = 0.0f, b = 0.0f;
         if (ray < rays) {
-            const double dlt = (double)val[k] - mean_d;
-            s2 += dlt * dlt;
+            trace_ray2<STRIDE>(cells, p, ray, a, b);
+            if (sino_raw) {
+                sino_raw[(size_t)b0 * rays + ray] = a;
+                if (two) sino_raw[(size_t)b1 * rays + ray] = b;
+            }
         }
+        va[k] = a; vb[k] = b;
     }
-    s2 = wave_sum(s2);
-    if (lane == 0) red[1][wave] = s2;
-    __syncthreads();
-    double tot2 = 0.0;
-    for (int w = 0; w < kRadonWG / 64; ++w) tot2 += red[1][w];
-    const float sd = (float)sqrt(tot2 / (double)(rays - 1));
-#pragma unroll
-    for (int k = 0; k < MAX_RAYS_PER_LANE; ++k) {
-        const int ray = threadIdx.x + k * kRadonWG;
-        if (ray < rays) sino_norm[(size_t)b * rays + ray] = (val[k] - mean) / sd;
-    }
+    if (!sino_norm) return;
+    normalize_store<MAX_RAYS_PER_LANE>(va, rays, red, sino_norm + (size_t)b0 * rays, degenerate);
+    if (two) normalize_store<MAX_RAYS_PER_LANE>(vb, rays, red, sino_norm + (size_t)b1 * rays, degenerate);
 }
 
 // generic fallback for sinograms with more than 16 rays per lane: no register residency,
@@ -318,7 +448,8 @@ __global__ void k_radon_global(const float* __restrict__ padded, RadonP p, float
 
 // (x - mean) / std over `group` consecutive floats per block (unbiased std), in place or not.
 // util.py:339-340 (RING++ normalises a whole [C,H,W] descriptor with one mean/std).
-__global__ __launch_bounds__(1024) void k_normalize(const float* __restrict__ in, float* __restrict__ out, int group)
+__global__ __launch_bounds__(1024) void k_normalize(const float* __restrict__ in, float* __restrict__ out, int group,
+                                                    int* __restrict__ degenerate)
 {
     __shared__ double red[2][16];
     const float* src = in + (size_t)blockIdx.x * group;
@@ -344,7 +475,9 @@ __global__ __launch_bounds__(1024) void k_normalize(const float* __restrict__ in
     for (int w = 0; w < 16; ++w) tot2 += red[1][w];
     const float mean = (float)mean_d;
     const float sd = (float)sqrt(tot2 / (double)(group - 1));
-    for (int i = threadIdx.x; i < group; i += 1024) dst[i] = (src[i] - mean) / sd;
+    const bool ok = sd > 0.0f && sd < INFINITY;   // constant group: zeros instead of NaN (torchvision raises there)
+    if (!ok && threadIdx.x == 0 && degenerate) atomicAdd(degenerate, 1);
+    for (int i = threadIdx.x; i < group; i += 1024) dst[i] = ok ? (src[i] - mean) / sd : 0.0f;
 }
 
 }  // namespace
@@ -396,10 +529,13 @@ int mrs_radon_plan_create(mrs_ctx* ctx, const float* h_angles, int32_t n_angles,
     pl->n_angles = n_angles; pl->det = det_count; pl->H = height; pl->W = width;
     pl->spacing = det_spacing;
     pl->in_lds = lds <= ctx->lds_bytes;
-    if (hipMalloc(&pl->d_meta, tab.size() * sizeof(int)) != hipSuccess ||
+    pl->two_in_lds = 2 * lds + 1024 <= ctx->lds_bytes;
+    if (hipMalloc(&pl->d_degenerate, sizeof(int)) != hipSuccess || hipMemset(pl->d_degenerate, 0, sizeof(int)) != hipSuccess ||
+        hipMalloc(&pl->d_meta, tab.size() * sizeof(int)) != hipSuccess ||
         hipMemcpy(pl->d_meta, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
         mrs::set_error("could not upload the ray table");
         if (pl->d_meta) (void)hipFree(pl->d_meta);
+        if (pl->d_degenerate) (void)hipFree(pl->d_degenerate);
         delete pl;
         return MRS_ERR_HIP;
     }
@@ -412,7 +548,20 @@ int mrs_radon_plan_destroy(mrs_radon_plan* plan)
     if (!plan) return MRS_OK;
     (void)hipSetDevice(plan->ctx->device);
     if (plan->d_meta) (void)hipFree(plan->d_meta);
+    if (plan->d_degenerate) (void)hipFree(plan->d_degenerate);
     delete plan;
+    return MRS_OK;
+}
+
+int mrs_radon_plan_degenerate_count(mrs_radon_plan* plan, int32_t reset, int32_t* out_count)
+{
+    MRS_REQUIRE(plan && out_count, "null pointer");
+    MRS_HIP_TRY(hipSetDevice(plan->ctx->device));
+    MRS_HIP_TRY(hipDeviceSynchronize());
+    int v = 0;
+    MRS_HIP_TRY(hipMemcpy(&v, plan->d_degenerate, sizeof(int), hipMemcpyDeviceToHost));
+    if (reset) MRS_HIP_TRY(hipMemset(plan->d_degenerate, 0, sizeof(int)));
+    *out_count = v;
     return MRS_OK;
 }
 
@@ -422,7 +571,7 @@ int mrs_normalize_groups(mrs_ctx* ctx, const float* d_in, float* d_out, int32_t 
     MRS_REQUIRE(ctx && d_in && d_out, "null pointer");
     MRS_REQUIRE(n_groups > 0 && group_len > 1, "need n_groups > 0 and group_len > 1");
     MRS_HIP_TRY(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_normalize, dim3(n_groups), dim3(1024), 0, (hipStream_t)stream, d_in, d_out, group_len);
+    hipLaunchKernelGGL(k_normalize, dim3(n_groups), dim3(1024), 0, (hipStream_t)stream, d_in, d_out, group_len, (int*)nullptr);
     MRS_HIP_TRY(hipGetLastError());
     return MRS_OK;
 }
@@ -460,16 +609,24 @@ int mrs_radon_forward(mrs_radon_plan* plan, const float* d_img, int32_t batch, f
         }
         hipLaunchKernelGGL(k_radon_pad, dim3(std::min((p.H * p.W + 255) / 256, 1024), batch), dim3(256), 0, s, d_img, p, padded.as<float>());
         hipLaunchKernelGGL(k_radon_global, dim3(std::min((rays + 255) / 256, 4096), batch), dim3(256), 0, s, padded.as<float>(), p, raw);
-        if (d_sino_norm) hipLaunchKernelGGL(k_normalize, dim3(batch), dim3(1024), 0, s, raw, d_sino_norm, rays);
+        if (d_sino_norm) hipLaunchKernelGGL(k_normalize, dim3(batch), dim3(1024), 0, s, raw, d_sino_norm, rays, plan->d_degenerate);
         MRS_HIP_TRY(hipGetLastError());
         return MRS_OK;
     }
-    if (per_lane <= 16) {
+    if (per_lane <= 16 && plan->two_in_lds && batch > 1) {
+        // two images per workgroup share the per-sample index arithmetic (march2)
+        auto kern = per_lane <= 15 ? (p.stride == 125 ? k_radon2<15, 125> : k_radon2<15, 0>) : k_radon2<16, 0>;
+        if (2 * lds > 48 * 1024)
+            MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds)));
+        hipLaunchKernelGGL(kern, dim3((batch + 1) / 2), dim3(kRadonWG), 2 * lds, s, d_img, p, batch, d_sino, d_sino_norm,
+                           plan->d_degenerate);
+    } else if (per_lane <= 16) {
         auto kern = per_lane <= 15 ? (p.stride == 125 ? k_radon<15, 125> : k_radon<15, 0>) : k_radon<16, 0>;
         if (lds > 48 * 1024)
             MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(batch), dim3(kRadonWG), lds, s, d_img, p, d_sino, d_sino_norm);
+        hipLaunchKernelGGL(kern, dim3(batch), dim3(kRadonWG), lds, s, d_img, p, d_sino, d_sino_norm, plan->d_degenerate);
     } else {
         mrs::Scratch tmp;
         float* raw = d_sino;
@@ -483,7 +640,7 @@ int mrs_radon_forward(mrs_radon_plan* plan, const float* d_img, int32_t batch, f
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_radon_big, dim3(batch), dim3(kRadonWG), lds, s, d_img, p, raw);
         if (d_sino_norm)
-            hipLaunchKernelGGL(k_normalize, dim3(batch), dim3(1024), 0, s, raw, d_sino_norm, rays);
+            hipLaunchKernelGGL(k_normalize, dim3(batch), dim3(1024), 0, s, raw, d_sino_norm, rays, plan->d_degenerate);
     }
     MRS_HIP_TRY(hipGetLastError());
     return MRS_OK;

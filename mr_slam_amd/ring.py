@@ -42,6 +42,13 @@ class RadonPlan:
         except Exception:
             pass
 
+    def degenerate_count(self, reset=True):
+        """Sinograms whose fused normalisation met std == 0 (blank / constant image) since the last reset: the reference
+        raises there (fn.normalize, util.py:197), the kernel writes zeros and counts."""
+        n = C.c_int32(0)
+        _lib.check(_lib.load().mrs_radon_plan_degenerate_count(self._h, int(bool(reset)), C.byref(n)))
+        return n.value
+
     def forward(self, img, raw=True, normalized=False):
         """img float32 [B,H,W] (device, contiguous) -> (sino [B,A,D] | None, sino_norm | None)."""
         d = _dev(img)
@@ -117,6 +124,9 @@ def generate_RING(pc, device="cuda:0"):
     pc_RING [1,A,D] cpu tensor, pc_TIRING complex64 [1,A,D] cpu tensor)."""
     xyz, offs = bev.pack_scans([np.asarray(pc)[:, 0:3]], device)
     img, sino, norm = ring_descriptors(xyz, offs, want_bev=True)
+    if ring_plan(_dev(xyz)).degenerate_count():
+        # torchvision's fn.normalize at util.py:197 raises for a constant sinogram (blank scan)
+        raise ValueError("std evaluated to zero after conversion to torch.float32, leading to division by zero.")
     tiring = fft_angle(norm)
     return img.cpu().numpy(), sino.cpu(), tiring.cpu()
 

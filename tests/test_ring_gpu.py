@@ -376,3 +376,46 @@ def test_fused_spectrum_and_pair_correlation_is_bitwise_the_two_step_path(dev):
     assert torch.equal(d, wd) and torch.equal(a, wa) and int(a[3]) == 25
     none, only16, d2, a2 = ring.spectrum_corr_pairs(norm, cand, want_f32=False, want_f16=True)
     assert none is None and torch.equal(only16, want16) and torch.equal(d2, wd) and torch.equal(a2, wa)
+
+
+def test_blank_scan_is_reported_not_silently_nan(dev):
+    """A blank / fully cropped scan gives a constant sinogram (std == 0).  The reference's fn.normalize raises ValueError
+    (util.py:197); the kernels write a finite all-zero descriptor and count the event, the host mirror raises."""
+    import torch
+    from mr_slam_amd import ring
+    plan = ring.ring_plan(0)
+    plan.degenerate_count()
+    imgs = torch.zeros((5, 120, 120), device=dev)
+    imgs[1, 40:60, 30:90] = 0.5
+    imgs[3, 10, 10] = 1.0
+    sino, norm = plan.forward(imgs, raw=True, normalized=True)
+    assert plan.degenerate_count() == 3                      # images 0, 2, 4
+    assert plan.degenerate_count() == 0                      # reset by the read
+    assert torch.isfinite(norm).all() and (norm[0] == 0).all() and (norm[2] == 0).all() and norm[1].std() > 0.99
+    one, n1 = plan.forward(imgs[:1], raw=True, normalized=True)   # single image -> the one-image kernel: same behaviour
+    assert plan.degenerate_count() == 1 and (n1 == 0).all()
+    far = np.full((100, 3), 5.0, np.float32); far[:, 2] = -1.0   # nothing with z > 0 inside the grid: blank BEV
+    with pytest.raises(ValueError):
+        ring.generate_RING(far, dev)
+    x = ring.normalize(torch.ones((2, 1, 120, 120), device=dev))
+    assert (x == 0).all()
+
+
+def test_two_images_per_workgroup_equal_one_image_per_workgroup(dev, oracle):
+    """k_radon2 (pairs of images interleaved in the LDS) == k_radon (one image) == the checker, bit for bit, for even and odd
+    batches."""
+    import torch
+    from mr_slam_amd import ring
+    rng = np.random.default_rng(5)
+    imgs = (rng.random((7, 120, 120)) * (rng.random((7, 120, 120)) < 0.3)).astype(np.float32)
+    t = torch.from_numpy(imgs).to(dev)
+    plan = ring.ring_plan(0)
+    s7, n7 = plan.forward(t, raw=True, normalized=True)
+    singles = [plan.forward(t[i:i + 1], raw=True, normalized=True) for i in range(7)]
+    ang = np.linspace(0, 2 * np.pi, 120).astype(np.float32)
+    want = oracle.radon_parallel(imgs, ang, 120, 1.0)
+    np.testing.assert_array_equal(s7.cpu().numpy(), want)
+    for i in range(7):
+        assert torch.equal(singles[i][0][0], s7[i]) and torch.equal(singles[i][1][0], n7[i])
+    s6, n6 = plan.forward(t[:6], raw=True, normalized=True)
+    assert torch.equal(s6, s7[:6]) and torch.equal(n6, n7[:6])
