@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- loop-closure hot path throughput on N MI355X of one node.
 
-One "step" = one pass of the hot path over one batch of synthetic 120 000-point scans:
-  B scan pairs per rank:  Cartesian BEV (A3/A4) -> Radon sinogram + normalisation (R1/R2) ->
-  rotation correlation of every new descriptor with its loop candidate (C1)
-  [N > 1: + RCCL all-gather of the new descriptors so that every rank holds the whole DB].
-value = loop-candidate pairs/s summed over ranks (each pair includes building the descriptor of
-a 120k-point scan; the candidate descriptor comes from the resident database).
-Extra fields: database-sweep rate (pairs/s with descriptors resident), per-stage kernel times,
-the HBM roofline of the BEV scatter kernel and the CPU baseline (oracle port, rank 0, N=1).
+One "step" = one pass of the hot path over the rank's resident shard of synthetic 120 000-point scans
+(`--chunks` launches of `--batch` scan pairs each; every scan is distinct and already in HBM):
+  per launch:  Cartesian BEV (A3/A4) -> Radon sinogram + normalisation (R1/R2) -> half spectrum + rotation
+  correlation of every new descriptor with its loop candidate (C1) -> one query swept against the database
+  [N > 1: + RCCL all-gather of the new descriptors' fp16 replicas; the candidates and the swept database of the NEXT
+   launch are rows of that replicated database; candidates whose replica score falls within 2e-3 of the acceptance
+   threshold are re-scored exactly on the owner rank at the end of the step].
+value = loop-candidate pairs/s summed over ranks (each pair includes building the descriptor of a 120k-point scan).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+Besides the contract line this prints (same JSON object): per-stage kernel times, HBM rooflines of the Cartesian and the
+polar BEV scatter, the Radon kernel's VALU / LDS figures, database-sweep legs in the shape of BASELINE configs[3]
+(10 k-entry RING / RING++ / DiSCO databases, 1 and 4 queries), the single-GPU shard of configs[4] (RING++ database of
+50 000 / 8 entries, one elevation-map frame, GICP), the GICP leg of configs[2] (20 forced iterations, a cold 5-iteration
+run and a run to convergence), single-call drop-in latencies, and the CPU baseline (oracle port, rank 0, N = 1).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--chunks C]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 """
@@ -26,51 +32,90 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from mr_slam_amd import bev, ring, synth  # noqa: E402
+from mr_slam_amd import bev, ring, shard, synth  # noqa: E402
 
 N_POINTS = 120_000
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
+DIST_THRESHOLD = 0.48     # RING_ros/config.py:17
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
 
 
-def make_batch(batch, rank, device):
-    """`batch` distinct 120k-point scans: 4 ray-cast base scenes per rank, the rest are rigidly
-    rotated/translated copies (cheap to generate, different cell pattern each)."""
-    rng = np.random.default_rng(1000 + rank)
-    base = [synth.lidar_scan(100 * rank + s, N_POINTS, metric=True) for s in range(4)]
-    scans = []
-    for i in range(batch):
-        p = base[i % 4]
-        if i >= 4:
-            th = rng.uniform(0, 2 * np.pi)
-            R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]], np.float32)
-            p = p @ R.T + np.array([rng.uniform(-3, 3), rng.uniform(-3, 3), 0], np.float32)
-        q = synth.preprocess(p)
-        if q.shape[0] < N_POINTS:   # rotation pushed a few points out of the crop: pad by repeating
-            q = np.concatenate([q, q[: N_POINTS - q.shape[0]]])
-        scans.append(q[:N_POINTS])
-    return bev.pack_scans(scans, device), scans
+def make_shard(batch, chunks, rank, device):
+    """chunks x batch DISTINCT pre-processed scans, built on the GPU: 4 ray-cast base scenes per rank (host, ~0.3 s each),
+    every scan a rigidly rotated / translated copy pushed through the reference pre-processing (load_pc_infer,
+    RING_ros/util.py:91-112: crop |x|,|y| < 70, 0 < z < 30, scale by 70 / 70 / 30); points that leave the crop are replaced
+    by the scan's first surviving point so that every scan keeps exactly 120 000 points.  Returns a list of
+    (xyz_soa, offsets) per launch, in the ragged SoA layout of the rasterisers."""
+    base = torch.stack([torch.from_numpy(synth.lidar_scan(100 * rank + s, N_POINTS, metric=True)) for s in range(4)]).to(device)
+    g = torch.Generator(device=device).manual_seed(1000 + rank)
+    offs = torch.arange(batch + 1, dtype=torch.int64, device=device) * N_POINTS
+    out = []
+    sub = 64
+    for c in range(chunks):
+        xyz = torch.empty((batch, 3, N_POINTS), dtype=torch.float32, device=device)
+        for i0 in range(0, batch, sub):
+            n = min(sub, batch - i0)
+            th = torch.rand(n, generator=g, device=device) * (2 * np.pi)
+            t = torch.rand((n, 2), generator=g, device=device) * 6.0 - 3.0
+            if c == 0 and i0 == 0:
+                th[:4] = 0.0; t[:4] = 0.0                       # the base scenes themselves
+            p = base[(torch.arange(n, device=device) + i0) % 4]            # [n, N, 3]
+            cs, sn = torch.cos(th)[:, None], torch.sin(th)[:, None]
+            x = cs * p[:, :, 0] - sn * p[:, :, 1] + t[:, 0:1]
+            y = sn * p[:, :, 0] + cs * p[:, :, 1] + t[:, 1:2]
+            z = p[:, :, 2]
+            ok = (x.abs() < 70.0) & (y.abs() < 70.0) & (z < 30.0) & (z > 0.0)
+            first = ok.float().argmax(1, keepdim=True)
+            x = torch.where(ok, x, x.gather(1, first)); y = torch.where(ok, y, y.gather(1, first)); z = torch.where(ok, z, z.gather(1, first))
+            xyz[i0:i0 + n, 0] = x / 70.0; xyz[i0:i0 + n, 1] = y / 70.0; xyz[i0:i0 + n, 2] = z / 30.0
+        out.append((xyz.view(-1), offs))
+    return out
 
 
-def cpu_baseline(scans, n_sample=512):
-    """The same workload on the host cores with the oracle port (BEV restatement in C, Radon
-    restatement in C + OpenMP, fast_corr restatement on torch CPU).  Bounded sample."""
+def host_scans(xyz_soa, n):
+    """the first n scans of a launch back on the host as [N,3] arrays (CPU baseline sample)"""
+    a = xyz_soa.view(-1, 3, N_POINTS)[:n].permute(0, 2, 1).contiguous().cpu().numpy()
+    return [a[i] for i in range(n)]
+
+
+def ev_ms(fn, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def load_pmc():
+    try:
+        return json.load(open(PMC_FILE))
+    except (OSError, ValueError):
+        return {}
+
+
+# --------------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(scans):
+    """The same workload on the host cores with the oracle port (BEV restatement in C, Radon restatement in C + OpenMP,
+    fast_corr restatement on torch CPU) on a bounded sample."""
     from oracle import pyoracle as O
     from oracle import corr_oracle as K
     cores = min(os.cpu_count() or 1, 16)       # tiny FFTs do not scale past a few threads
     torch.set_num_threads(cores)
     os.environ["OMP_NUM_THREADS"] = str(cores)
     ang = np.linspace(0, 2 * np.pi, 120).astype(np.float32)
-    sample = scans[:n_sample]
-    soas = [synth.to_soa(s) for s in sample]
-    # warm-up (library load, thread pools)
+    soas = [synth.to_soa(s) for s in scans]
     w = O.bev_cart(soas[0], 1, 1, 120, 120, 1).reshape(-1, 3)[:, 2].reshape(1, 120, 120)
     ws = O.radon_parallel(w, ang, 120, 1.0)
     wt = K.tiring_from_sinogram(ws)
     K.fast_corr(wt, wt)
     from concurrent.futures import ThreadPoolExecutor
     t0 = time.perf_counter()
-    # the reference rasteriser is single-threaded per scan; scans are spread over the cores (ctypes drops the GIL)
-    with ThreadPoolExecutor(cores) as ex:
+    with ThreadPoolExecutor(cores) as ex:      # the reference rasteriser is single-threaded per scan; ctypes drops the GIL
         imgs = np.stack(list(ex.map(lambda s: O.bev_cart(s, 1, 1, 120, 120, 1).reshape(-1, 3)[:, 2].reshape(120, 120), soas)))
     t1 = time.perf_counter()
     sino = O.radon_parallel(imgs, ang, 120, 1.0)
@@ -79,50 +124,29 @@ def cpu_baseline(scans, n_sample=512):
     for i in range(len(tir)):
         K.fast_corr(tir[i], tir[(i + 1) % len(tir)])
     t3 = time.perf_counter()
-    out = {"value": len(sample) / (t3 - t0), "unit": "pairs/s", "cores": cores, "kind": "port",
-           "sample": f"{len(sample)} scans x 120k pts: C BEV restatement (1 thread per scan, scans over {cores} threads), "
+    out = {"value": len(scans) / (t3 - t0), "unit": "pairs/s", "cores": cores, "kind": "port",
+           "sample": f"{len(scans)} scans x 120k pts: C BEV restatement (1 thread per scan, scans over {cores} threads), "
                      f"C Radon restatement (OpenMP over images), torch-CPU fast_corr ({cores} threads)",
-           "ms_per_pair": {"bev": 1e3 * (t1 - t0) / len(sample), "radon": 1e3 * (t2 - t1) / len(sample),
-                           "fft_corr": 1e3 * (t3 - t2) / len(sample)}}
+           "ms_per_pair": {"bev": 1e3 * (t1 - t0) / len(scans), "radon": 1e3 * (t2 - t1) / len(scans),
+                           "fft_corr": 1e3 * (t3 - t2) / len(scans)}}
     out["gicp"] = cpu_gicp_baseline(cores)
-    if O.ref_polar() is not None:   # the reference's own CPU polar rasteriser, unmodified
+    if O.ref_polar() is not None:              # the reference's own CPU rasterisers, compiled from its sources
         t0 = time.perf_counter()
-        for s in soas:
+        for s in soas[:128]:
             O.ref_bev_polar(s, 1, 1, 40, 120, 20, 1)
-        out["reference_polar_bev_scans_per_s"] = len(sample) / (time.perf_counter() - t0)
+        out["reference_polar_bev_scans_per_s"] = min(128, len(soas)) / (time.perf_counter() - t0)
+    if O.ref_lib("cart") is not None:
+        t0 = time.perf_counter()
+        for s in soas[:128]:
+            O.ref_bev_cart(s, 1, 1, 120, 120, 1)
+        out["reference_cart_bev_scans_per_s"] = min(128, len(soas)) / (time.perf_counter() - t0)
     return out
 
 
-def cpu_gicp_baseline(cores, iters=20):
-    """fast_gicp restatement (kd-tree + OpenMP, oracle/gicp_oracle.cpp) on ONE 120k x 120k pair of the GICP leg's
-    shape: `iters` forced outer iterations, k = 15, max_corr 5.0; covariances timed separately, like the GPU leg."""
-    from oracle import pyoracle as O
-    from scipy.spatial.transform import Rotation as Rot
-    rng = np.random.default_rng(2000)
-    p = synth.lidar_scan(500, N_POINTS, metric=True).astype(np.float64)
-    R = Rot.from_rotvec([0.01, -0.02, 0.04]).as_matrix()
-    src = (p + rng.normal(0, 0.02, p.shape)).astype(np.float32)
-    tgt = (p @ R.T + [0.4, -0.3, 0.05] + rng.normal(0, 0.02, p.shape)).astype(np.float32)
-    g = O.Gicp(k=15, max_corr=5.0, threads=cores)
-    t0 = time.perf_counter()
-    g.set_source(src); g.set_target(tgt)        # builds both kd-trees
-    t1 = time.perf_counter()
-    g.covariances(0); g.covariances(1)
-    t2 = time.perf_counter()
-    _, _, its, trials = g.align(np.eye(4), force_iters=iters)
-    t3 = time.perf_counter()
-    return {"iters_per_s": its / (t3 - t2), "iterations": its, "lm_trials": trials, "align_s": t3 - t2,
-            "covariance_clouds_per_s": 2 / (t2 - t1), "kdtree_build_s": t1 - t0, "cores": cores,
-            "sample": f"1 pair x 120k pts, {its} forced iterations, k=15, max_corr 5.0 (restated fast_gicp, kd-tree + OpenMP)"}
-
-
-def gicp_leg(device_index, rank, n_pairs, iters):
-    """BASELINE configs[2] shape: submap pairs x 120k points, `iters` outer iterations with the
-    convergence test disabled; covariances are timed separately (they are cached per submap)."""
-    from mr_slam_amd import gicp
+def _gicp_pairs(n_pairs, rank, seed0=500):
     from scipy.spatial.transform import Rotation as Rot
     rng = np.random.default_rng(2000 + rank)
-    base = [synth.lidar_scan(500 + 10 * rank + s, N_POINTS, metric=True) for s in range(2)]
+    base = [synth.lidar_scan(seed0 + 10 * rank + s, N_POINTS, metric=True) for s in range(2)]
     srcs, tgts = [], []
     for i in range(n_pairs):
         p = base[i % 2].astype(np.float64)
@@ -132,43 +156,208 @@ def gicp_leg(device_index, rank, n_pairs, iters):
         t = rng.normal(size=3); t *= rng.uniform(0, 1) / np.linalg.norm(t)
         srcs.append((p + rng.normal(0, 0.02, p.shape)).astype(np.float32))
         tgts.append((p @ R.T + t + rng.normal(0, 0.02, p.shape)).astype(np.float32))
+    return srcs, tgts
+
+
+def cpu_gicp_baseline(cores, iters=20):
+    """fast_gicp restatement (kd-tree + OpenMP, oracle/gicp_oracle.cpp) on ONE 120k x 120k pair of the GICP leg's shape."""
+    from oracle import pyoracle as O
+    srcs, tgts = _gicp_pairs(1, 0)
+    g = O.Gicp(k=15, max_corr=5.0, threads=cores)
+    t0 = time.perf_counter()
+    g.set_source(srcs[0]); g.set_target(tgts[0])        # builds both kd-trees
+    t1 = time.perf_counter()
+    g.covariances(0); g.covariances(1)
+    t2 = time.perf_counter()
+    _, _, its, trials = g.align(np.eye(4), force_iters=iters)
+    t3 = time.perf_counter()
+    return {"iters_per_s": its / (t3 - t2), "iterations": its, "lm_trials": trials, "nn_passes": g.nn_passes, "align_s": t3 - t2,
+            "covariance_clouds_per_s": 2 / (t2 - t1), "kdtree_build_s": t1 - t0, "cores": cores,
+            "sample": f"1 pair x 120k pts, {its} forced iterations, k=15, max_corr 5.0 (restated fast_gicp, kd-tree + OpenMP)"}
+
+
+# ------------------------------------------------------------------------------------------------------- GICP leg
+def gicp_leg(device_index, rank, n_pairs, iters):
+    """BASELINE configs[2] shape: submap pairs x 120k points.  Three protocols on the same pairs:
+      forced : `iters` outer iterations with the convergence test disabled (most of them are warm-started
+               near-zero-motion passes once the pose has settled);
+      cold   : the first 5 iterations from the identity guess with no warm start (every NN pass searches from scratch);
+      natural: run to convergence (is_converged), pairs/s and iterations actually used.
+    Covariances are timed separately (they are cached per submap)."""
+    from mr_slam_amd import gicp
+    srcs, tgts = _gicp_pairs(n_pairs, rank)
+    w = gicp.GicpBatch(1, device_index)                # load the code objects before anything is timed
+    w.set_sources([srcs[0][:4000]]); w.set_targets([tgts[0][:4000]]); w.align(); del w
     b = gicp.GicpBatch(n_pairs, device_index)
-    b.set_params(k_correspondences=15, max_correspondence_distance=5.0, force_iterations=iters)
-    b.set_sources(srcs)
-    b.set_targets(tgts)
+    b.set_params(k_correspondences=15, max_correspondence_distance=5.0)
+    b.set_sources(srcs); b.set_targets(tgts)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    b.compute_covariances(0)
-    b.compute_covariances(1)
+    b.compute_covariances(0); b.compute_covariances(1)
     torch.cuda.synchronize()
     t_cov = time.perf_counter() - t0
-    b.set_params(force_iterations=2)
-    b.align()                                   # warm-up (2 iterations)
-    b.set_params(force_iterations=iters)
+
+    def timed(**prm):
+        b.set_params(**prm)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        T, conv, its = b.align()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t, conv, its, b.nn_passes
+
+    # cold: set_sources resets the warm-start seeds; nothing has been aligned yet
+    t_cold, _, its_c, nn_c = timed(force_iterations=5)
+    t_forced, _, its_f, nn_f = timed(force_iterations=iters)          # seeds now warm from the cold run (like a re-check)
+    assert (its_f == iters).all() and (its_c == 5).all()
+    b.set_sources(srcs)                                               # reset seeds (covariances recomputed lazily: not timed)
+    b.compute_covariances(0)
+    t_nat, conv, its_n, nn_n = timed(force_iterations=0)
+    return {"pairs": n_pairs, "iterations": iters, "points": N_POINTS,
+            "iters_per_s": n_pairs * iters / t_forced, "align_s": t_forced, "nn_passes": nn_f,
+            "nn_pass_ms": 1e3 * t_forced / (n_pairs * max(nn_f, 1)),
+            "cold": {"iterations": 5, "iters_per_s": n_pairs * 5 / t_cold, "align_s": t_cold, "nn_passes": nn_c,
+                     "note": "first 5 outer iterations from the identity guess, no warm start"},
+            "natural": {"pairs_per_s": n_pairs / t_nat, "align_s": t_nat, "converged": int(conv.sum()),
+                        "mean_iterations": float(np.mean(its_n)), "max_iterations": int(np.max(its_n)), "nn_passes": nn_n,
+                        "iters_per_s": float(np.sum(its_n)) / t_nat},
+            "nn_search": "exact brute force over Morton-ordered LDS tiles with conservative bounding-box culling; one NN pass per "
+                         "outer iteration, LM trials score the cached correspondences (upstream compute_error)",
+            "covariance_s": t_cov, "covariance_clouds_per_s": 2 * n_pairs / t_cov, "k": 15,
+            "max_correspondence_distance": 5.0,
+            "bound": {"k_linearize": "HBM: 132 B per source point and pass (16 B point + 48 B covariance + 4 B index + gathered "
+                                     "16 + 48 B); an LM trial re-reads the same bytes (Mahalanobis matrices are recomputed, not stored)",
+                      "k_knn_cov": "VALU: exact k-NN by culled brute force, sorted insertion into k register slots per candidate "
+                                   "that beats the current k-th distance; no HBM or MFMA bound applies (inputs are L2/LDS resident)",
+                      "k_nn_scan": "VALU: ~7 lane-ops per surviving (source, target) candidate after three levels of box culling"}}
+
+
+# ---------------------------------------------------------------------------------------------------- sweep legs
+def sweep_legs(device, spec_pool, n_db=10_000):
+    """BASELINE configs[3] shape on one GPU: databases of 10 000 descriptors, 1 and 4 queries per launch.
+    Bandwidth = database bytes streamed once per launch / launch time (the queries of a launch share the entry through
+    L2, so the rate is the same number for 1 and 4 queries only if the kernel is bandwidth bound)."""
+    from mr_slam_amd import disco
+    out = {}
+    idx = torch.arange(n_db, device=device) % spec_pool.shape[0]
+    db = spec_pool[idx].contiguous()                                   # RING: [n_db][61][120] complex64 = 58 560 B each
+    for nq in (1, 4):
+        q = spec_pool[:nq].contiguous()
+        ms = ev_ms(lambda: ring.corr_sweep_fft(q, db))
+        out[f"ring_q{nq}"] = {"pairs_per_s": nq * n_db / ms * 1e3, "ms": ms, "db_entries": n_db, "bytes_per_entry": 58560,
+                              "db_gbs": n_db * 58560 / ms / 1e6, "hbm_frac": n_db * 58560 / ms / 1e6 / HBM_PEAK_GBS}
+    db6 = torch.stack([db.roll(k, 0) for k in range(6)], 1).contiguous()   # RING++: [n_db][6][61][120] = 351 360 B each
+    for nq in (1, 4):
+        q = db6[:nq].contiguous()
+        ms = ev_ms(lambda: ring.corr_sweep_fft(q, db6), reps=3, warm=1)
+        out[f"ringpp_q{nq}"] = {"pairs_per_s": nq * n_db / ms * 1e3, "ms": ms, "db_entries": n_db, "bytes_per_entry": 351360,
+                                "db_gbs": n_db * 351360 / ms / 1e6, "hbm_frac": n_db * 351360 / ms / 1e6 / HBM_PEAK_GBS}
+    del db6
+    # DiSCO (disco_ros/main.py:284-291): nearest 1024-d signature over the database, then ONE phase correlation
+    g = torch.Generator(device=device).manual_seed(3)
+    sig_db = torch.rand((n_db, 1024), generator=g, device=device)
+    spec_db = torch.view_as_complex(torch.randn((n_db, 1, 40, 120, 2), generator=g, device=device))
+    for nq in (1, 4):
+        qs = sig_db[:nq].contiguous() + 0.01
+
+        def disco_query():
+            i, _ = disco.signature_search(qs, sig_db)
+            return disco.phase_corr(spec_db[:nq], spec_db[i.long()])
+        ms = ev_ms(disco_query)
+        out[f"disco_q{nq}"] = {"queries_per_s": nq / ms * 1e3, "pairs_per_s": nq * n_db / ms * 1e3, "ms": ms, "db_entries": n_db,
+                               "bytes_per_entry": 4096, "db_gbs": n_db * 4096 / ms / 1e6,
+                               "note": "signature search over the whole database + phase_corr with the best entry"}
+    return out
+
+
+def pipeline_shard_leg(device, spec_pool, gicp_res):
+    """BASELINE configs[4], one GPU's share: RING++ database of 50 000 / 8 = 6 250 entries ([6][61][120] complex64,
+    2.2 GB) swept by one query, one elevation-map frame (move + 120k points + fuse + features + ray tracing, row N3), and
+    the GICP refinement rate of the configs[2] leg."""
+    from mr_slam_amd import elevation
+    n_db = 6250
+    idx = torch.arange(n_db, device=device) % spec_pool.shape[0]
+    db6 = torch.stack([spec_pool[idx].roll(k, 0) for k in range(6)], 1).contiguous()
+    q = db6[:1].contiguous()
+    ms = ev_ms(lambda: ring.corr_sweep_fft(q, db6), reps=3, warm=1)
+    out = {"ringpp_db_entries": n_db, "ringpp_db_bytes": n_db * 351360, "ringpp_sweep_ms": ms,
+           "ringpp_sweep_pairs_per_s": n_db / ms * 1e3, "ringpp_sweep_db_gbs": n_db * 351360 / ms / 1e6}
+    del db6
+    m = elevation.ElevationMap(200, 0.1)
+    rng = np.random.default_rng(0)
+    n = N_POINTS
+    x = rng.uniform(-9, 9, n).astype(np.float32); y = rng.uniform(-9, -1.2, n).astype(np.float32)
+    z = (0.1 * np.sin(x) - 0.6 + rng.normal(0, 0.02, n)).astype(np.float32)
+    T = np.eye(4, dtype=np.float32); T[2, 3] = 0.9
+    rv = np.diag([1e-4, 1e-4, 4e-4]).astype(np.float32)
+    cr = rng.integers(0, 256, n); inten = rng.uniform(0, 1, n).astype(np.float32)
+
+    def frame():
+        m.move(np.array([0.0, 0.0, 0.9], np.float32))
+        r = m.process_points(x, y, z, T, -2.0, 3.0, 0.02, 0.003, 0.01, [0, 0, 1.0], rv, np.eye(3), [0, 0, 1.0], np.zeros((3, 3)))
+        m.fuse(r["map_index"], cr, cr, cr, inten, r["z_ts"], r["var"])
+        m.mapvar_update(1e-4); m.map_feature(); m.raytracing()
+    for _ in range(2):
+        frame()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    T, conv, its = b.align()
+    for _ in range(5):
+        frame()
     torch.cuda.synchronize()
-    t_align = time.perf_counter() - t0
-    assert (its == iters).all()
-    return {"pairs": n_pairs, "iterations": iters, "points": N_POINTS,
-            "iters_per_s": n_pairs * iters / t_align, "align_s": t_align,
-            "nn_passes": b.nn_passes, "nn_pass_ms": 1e3 * t_align / (n_pairs * b.nn_passes),
-            "nn_search": "exact brute force over Morton-ordered LDS tiles with conservative bounding-box culling",
-            "covariance_s": t_cov, "covariance_clouds_per_s": 2 * n_pairs / t_cov, "k": 15,
-            "max_correspondence_distance": 5.0}
+    out["elevation_frame_ms"] = 1e3 * (time.perf_counter() - t0) / 5
+    out["elevation_frame"] = "200 x 200 map, 120k points, host arrays in and out (the libgpu.so calling convention)"
+    if gicp_res:
+        out["gicp_iters_per_s"] = gicp_res["iters_per_s"]; out["gicp_pairs_to_convergence_per_s"] = gicp_res["natural"]["pairs_per_s"]
+    return out
 
 
+def dropin_latency_leg(scan):
+    """One call at a time through the reference-named modules (host numpy in, host numpy out), as the ROS nodes make them."""
+    from mr_slam_amd.compat import gputransform, voxelocc, pygicp
+    soa = synth.to_soa(scan)
+    n = scan.shape[0]
+
+    def lat(fn, reps=10):
+        fn(); fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return 1e3 * (time.perf_counter() - t0) / reps
+
+    def cart():
+        t = voxelocc.GPUTransformer(soa, n, 1, 1, 120, 120, 1, 1); t.transform(); return t.retreive()
+
+    def polar():
+        t = gputransform.GPUTransformer(soa, n, 1, 1, 40, 120, 20, 1); t.transform(); return t.retreive()
+    out = {"voxelocc_120x120x1_ms": lat(cart), "gputransform_40x120x20_ms": lat(polar),
+           "generate_RING_ms": lat(lambda: ring.generate_RING(scan)), "points": n}
+    _, _, tir = ring.generate_RING(scan)
+    out["fast_corr_ms"] = lat(lambda: ring.fast_corr(tir, tir))
+    srcs, tgts = _gicp_pairs(1, 0)
+    src64, tgt64 = srcs[0].astype(np.float64), tgts[0].astype(np.float64)
+    out["pygicp_downsample_0.2_ms"] = lat(lambda: pygicp.downsample(src64, 0.2), reps=5)
+    s, t = pygicp.downsample(src64, 0.2), pygicp.downsample(tgt64, 0.2)
+
+    def reg():
+        g = pygicp.FastGICP(); g.set_input_target(t); g.set_input_source(s); g.set_max_correspondence_distance(5.0)
+        g.align(initial_guess=np.eye(4)); return g.get_fitness_score(1.0)
+    out["pygicp_align_downsampled_ms"] = lat(reg, reps=5)
+    out["pygicp_points"] = [int(s.shape[0]), int(t.shape[0])]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="scan pairs per rank per step")
-    ap.add_argument("--db", type=int, default=16384, help="database size for the sweep-rate leg (x 58 560 B)")
+    ap.add_argument("--batch", type=int, default=1024, help="scan pairs per launch")
+    ap.add_argument("--chunks", type=int, default=32, help="launches per step (resident shard = batch x chunks scans)")
     ap.add_argument("--gicp-pairs", type=int, default=256, help="120k-pt pairs per rank in the GICP leg (BASELINE configs[2]: 256; 0 = skip)")
     ap.add_argument("--gicp-iters", type=int, default=20)
+    ap.add_argument("--cpu-sample", type=int, default=256, help="scans in the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="only the headline step (+ GICP unless --gicp-pairs 0)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -186,53 +375,91 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device(device))
 
-    B = args.batch
-    (xyz, offs), scans = make_batch(B, rank, device)
+    B, CH = args.batch, args.chunks
+    t_setup = time.perf_counter()
+    chunks = make_shard(B, CH, rank, device)
     plan = ring.ring_plan(local_rank)
     img = torch.empty((B, 1, 120, 120), dtype=torch.float32, device=device)
-    # resident database of candidate descriptors (one candidate per new scan)
-    # database entries are Hermitian half spectra [61][120] complex64 (58 560 B) of the normalised sinograms
-    _, _, cand = ring.ring_descriptors(xyz, offs)
-    cand = ring.half_spectrum(cand).roll(1, 0).contiguous()
-    out_dist = torch.empty(B, dtype=torch.float32, device=device)
-    out_ang = torch.empty(B, dtype=torch.int32, device=device)
-    # N > 1: the all-gather of step i overlaps the kernels of step i+1 (async RCCL op on its own stream,
-    # double-buffered destination; the gathered descriptors only feed the database, not the next step)
-    # exchange format: fp16 replicas (29 280 B per descriptor; the owner keeps the exact fp32 entry) -- at >1 M
-    # descriptors/s/GPU the fp32 spectra would exceed what the xGMI links carry
-    gathered = [torch.empty((world * B, 61, 120, 2), dtype=torch.float16, device=device) for _ in range(2)] if dist_on else None
-    pending = {"work": None, "keep": None, "n": 0}
+    # the rank's exact database entries: Hermitian half spectra [61][120] complex64 (58 560 B) of the normalised
+    # sinograms of every resident scan, slot CH = the entries of the previous step's last launch
+    spec32 = torch.empty((CH + 1, B, 61, 120), dtype=torch.complex64, device=device)
+    for c, (xyz, offs) in enumerate(chunks):
+        _, _, nrm = ring.ring_descriptors(xyz, offs)
+        spec32[c] = ring.half_spectrum(nrm)
+    spec32[CH] = spec32[CH - 1]
+    g = torch.Generator(device=device).manual_seed(7 + rank)
+    NDB = world * B
+    cand_idx = torch.randint(0, NDB, (CH, B), generator=g, device=device, dtype=torch.int32)   # pre-selected candidate rows
+    out_dist = torch.empty((CH, B), dtype=torch.float32, device=device)
+    out_ang = torch.empty((CH, B), dtype=torch.int32, device=device)
+    sweep_best = torch.empty((CH, 2), dtype=torch.float32, device=device)
+    # N > 1: the replicated database of the previous launch's descriptors (fp16 replicas, 29 280 B each; the owner keeps
+    # the exact fp32 entry) -- at > 1 M descriptors/s/GPU fp32 spectra would exceed what the xGMI links carry
+    gathered = None
+    if dist_on:
+        gathered = [torch.empty((NDB, 61, 120, 2), dtype=torch.float16, device=device) for _ in range(2)]
+        for gbuf in gathered:
+            gbuf.copy_(torch.view_as_real(spec32[CH - 1]).to(torch.float16).repeat(world, 1, 1, 1))
+    pending = {"work": None, "keep": None}
+    rescorer = shard.OwnerRescorer(DIST_THRESHOLD, margin=2e-3, slots=64) if dist_on else None
+    setup_s = time.perf_counter() - t_setup
 
-    ev = {k: [] for k in ("bev", "radon", "corr")}
+    ev = {k: [] for k in ("bev", "radon", "corr", "sweep", "wait")}
 
     def step(record):
         def mark():
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             return e
-        e0 = mark() if record else None
-        bev.cart_bev(xyz, offs, 1, 1, 120, 120, 1, out=img.view(B, -1))
-        e1 = mark() if record else None
-        _, norm = plan.forward(img.view(B, 120, 120), raw=False, normalized=True)
-        e2 = mark() if record else None
-        # half spectrum of the new descriptors (kept: they are the next database entries; fp16 replica for the
-        # other ranks) + correlation with the candidates, one launch
-        spec, spec16, _, _ = ring.spectrum_corr_pairs(norm, cand, want_f16=dist_on, out=(out_dist, out_ang))
-        e3 = mark() if record else None
+        spec32[CH] = spec32[CH - 1]                    # last launch of the previous step = candidates of this step's first
+        for c, (xyz, offs) in enumerate(chunks):
+            e0 = mark() if record else None
+            bev.cart_bev(xyz, offs, 1, 1, 120, 120, 1, out=img.view(B, -1))
+            e1 = mark() if record else None
+            _, norm = plan.forward(img.view(B, 120, 120), raw=False, normalized=True)
+            e2 = mark() if record else None
+            if dist_on:
+                ew0 = mark() if record else None
+                if pending["work"] is not None:
+                    pending["work"].wait()             # the compute stream waits for the previous exchange (no host block)
+                ew1 = mark() if record else None
+                db = gathered[(c - 1) & 1]
+                # half spectrum of the new descriptors (kept: database entries; fp16 replica for the other ranks) +
+                # correlation with their candidates out of the replicated database, one launch
+                spec, spec16, _, _ = ring.spectrum_corr_pairs_db(norm, db, cand_idx[c], want_f16=True, out=(out_dist[c], out_ang[c]))
+            else:
+                db = spec32[c - 1]                     # c = 0: slot CH
+                spec, spec16, _, _ = ring.spectrum_corr_pairs_db(norm, db, cand_idx[c], out=(out_dist[c], out_ang[c]))
+            spec32[c] = spec
+            e3 = mark() if record else None
+            d, a = ring.corr_sweep_fft(spec[:1], db)   # one new query against the whole (replicated) database
+            sweep_best[c, 0], idx = torch.min(d[0], 0)
+            sweep_best[c, 1] = idx.float()
+            e4 = mark() if record else None
+            if dist_on:
+                pending["keep"] = spec16               # keep the source alive until the op completes
+                pending["work"] = dist.all_gather_into_tensor(gathered[c & 1], spec16, async_op=True)
+            if record:
+                ev["bev"].append((e0, e1)); ev["radon"].append((e1, e2)); ev["corr"].append((e2, e3)); ev["sweep"].append((e3, e4))
+                if dist_on:
+                    ev["wait"].append((ew0, ew1))
         if dist_on:
-            if pending["work"] is not None:
-                pending["work"].wait()
-            pending["keep"] = spec16                    # keep the source alive until the op completes
-            pending["work"] = dist.all_gather_into_tensor(gathered[pending["n"] & 1], spec16, async_op=True)
-            pending["n"] += 1
-        if record:
-            ev["bev"].append((e0, e1)); ev["radon"].append((e1, e2)); ev["corr"].append((e2, e3))
+            # exact re-scoring of the candidates whose replica score is within 2e-3 of the acceptance threshold: global row r
+            # of launch c's database = descriptor r % B of rank r // B, built in launch c - 1
+            slot = (torch.arange(CH, device=device) - 1) % (CH + 1)
+            flat_rows = (slot[:, None].to(torch.int64) * NDB + cand_idx.to(torch.int64)).reshape(-1)
+            e32 = spec32.view(-1, 61, 120)
+
+            def exact(qdesc, local_rows):
+                return ring.corr_pairs_fft(qdesc.contiguous(), e32[local_rows].contiguous())
+            d2, a2 = rescorer.rescore(out_dist.view(-1), out_ang.view(-1), flat_rows, spec32[:CH].reshape(-1, 61, 120),
+                                      lambda rows: (rows % NDB) // B, lambda rows: (rows // NDB) * B + rows % B, exact)
+            out_dist.view(-1).copy_(d2); out_ang.view(-1).copy_(a2)
 
     def fence():
         if dist_on:
             if pending["work"] is not None:
                 pending["work"].wait()
-                pending["work"] = None
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -249,28 +476,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kern_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
+    kern_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items() if v}
 
-    # database sweep leg (descriptors resident): 8 queries against a DB of args.db entries
-    sweep = None
-    if rank == 0:
-        nq = 4
-        db = cand[torch.arange(args.db, device=device) % B].contiguous()   # args.db * 58 560 B (> 256 MB L3 by default)
-        q = cand[:nq].contiguous()
-        for _ in range(2):
-            ring.corr_sweep_fft(q, db)
-        torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(5):
-            ring.corr_sweep_fft(q, db)
-        b.record()
-        torch.cuda.synchronize()
-        ms = a.elapsed_time(b) / 5
-        sweep = {"pairs_per_s": nq * args.db / ms * 1e3, "db": args.db, "queries": nq, "ms": ms,
-                 "bytes_per_pair": 58560, "algorithmic_gbs": nq * args.db * 58560 / ms / 1e6,
-                 "kernel": "k_ring_corr_fft (half-spectrum DB, in-register real FFT-120)"}
-
+    extra = {}
     gicp_res = None
     if args.gicp_pairs > 0:
         fence()
@@ -281,21 +489,33 @@ def main():
             gicp_res["iters_per_s"] = world * args.gicp_pairs * args.gicp_iters / float(t.item())
             gicp_res["pairs"] = world * args.gicp_pairs
 
+    topk_cmp = None
+    if dist_on:
+        # the two database designs of SURVEY.md 8(e) side by side: (a) replicate (all-gather the descriptors, every rank sweeps
+        # everything: what the step does) vs (b) keep the database sharded, all-gather the QUERIES, exchange top-k rows only
+        q_local = spec32[0, :4].contiguous()
+        fence()
+
+        def design_a():
+            full = shard.allgather_ragged(torch.view_as_real(spec32[0]).to(torch.float16))
+            d, a = ring.corr_sweep_fft(q_local, full)
+            return torch.topk(d, 4, dim=1, largest=False)
+
+        def design_b():
+            q_all = shard.allgather_ragged(torch.view_as_real(q_local).contiguous())
+            return shard.sharded_topk_sweep(torch.view_as_complex(q_all), spec32[0], ring.corr_sweep_fft, 4)
+        ms_a, ms_b = ev_ms(design_a, reps=3, warm=1), ev_ms(design_b, reps=3, warm=1)
+        topk_cmp = {"replicate_db_ms": ms_a, "sharded_topk_ms": ms_b, "queries_per_rank": 4, "db_rows_per_rank": B,
+                    "replicate_bytes_in_per_rank": (world - 1) * B * 29280, "sharded_bytes_in_per_rank": (world - 1) * 4 * (58560 + 4 * 16)}
+
     if rank == 0:
+        pmc = load_pmc()
         cells = 120 * 120
         bev_bytes = B * (12 * N_POINTS + 4 * cells)          # 12 B/point + 4 B/cell
         achieved = bev_bytes / (kern_ms["bev"] * 1e-3) / 1e9
-        # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected
-        # per MI355X_MICROARCH.md; counters cannot be read from inside this process)
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            traffic = pmc.get(f"k_cart_lds@grid{B * 1024}", {}).get("hbm_bytes")
-        except OSError:
-            pass
         line = {
             "metric": "loop-candidate pairs/sec (BEV+Radon+corr), 120k-pt scans",
-            "value": world * B * args.steps / elapsed,
+            "value": world * B * CH * args.steps / elapsed,
             "unit": "pairs/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -306,20 +526,51 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1] batched: 120k-pt synthetic lidar scans -> Cartesian BEV "
-                                   "120x120x1 -> Radon 120x120 -> normalise -> half spectrum -> FFT-domain rotation correlation vs 1 candidate",
-                       "pairs_per_rank_per_step": B, "points_per_scan": N_POINTS,
-                       "parallelism": f"scan-sharded x{world}" + (" + RCCL all-gather of fp16 descriptor replicas" if dist_on else "")},
+            "config": {"workload": "BASELINE configs[1] batched: 120k-pt synthetic lidar scans -> Cartesian BEV 120x120x1 -> Radon "
+                                   "120x120 -> normalise -> half spectrum -> FFT-domain rotation correlation vs 1 candidate of the "
+                                   "database (+ 1 query per launch swept over the database)",
+                       "pairs_per_rank_per_step": B * CH, "pairs_per_launch": B, "launches_per_step": CH,
+                       "resident_scan_bytes_per_rank": B * CH * 12 * N_POINTS, "points_per_scan": N_POINTS,
+                       "parallelism": f"scan-sharded x{world}" + (" + RCCL all-gather of fp16 descriptor replicas, candidates and "
+                                                                  "sweeps read the replicated database, owner re-scoring" if dist_on else "")},
+            "timed_region_s": elapsed,
+            "setup_s": setup_s,
             "kernel_ms": kern_ms,
             "roofline": {"kernel": "k_cart_lds (BEV scatter)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": bev_bytes,
-                         "traffic_source": "profiles/r01_pmc_traffic.json (PMC pass of this command)" if traffic else None},
-            "sweep": sweep,
+                         "traffic": pmc.get("k_cart_lds", {}).get("hbm_bytes"), "algorithmic_bytes_per_launch": bev_bytes,
+                         "traffic_source": "profiles/r02_pmc.json (rocprofv3 --pmc passes of tools/pmc_targets.py)" if pmc.get("k_cart_lds") else None},
             "gicp": gicp_res,
         }
+        if dist_on:
+            per_launch = (world - 1) * B * 29280
+            line["exchange"] = {"format": "fp16 half spectra, 29 280 B per descriptor", "allgather_bytes_in_per_rank_per_launch": per_launch,
+                                "allgather_bytes_in_per_rank_per_step": per_launch * CH,
+                                "inbound_gbs_needed_at_this_rate": per_launch * CH / (1e-3 * line["ms_per_step"]) / 1e9,
+                                "compute_stream_wait_ms_per_launch": kern_ms.get("wait"),
+                                "compute_stream_wait_ms_per_step": kern_ms.get("wait", 0.0) * CH,
+                                "rescore": rescorer.stats, "designs": topk_cmp}
+        if not args.no_extra_legs:
+            # polar BEV (the rasteriser north_star names), DiSCO layout 40 x 120 x 20, same scans
+            xyz0, offs0 = chunks[0]
+            pcells = 40 * 120 * 20
+            ms = ev_ms(lambda: bev.polar_bev(xyz0, offs0, 1, 1, 40, 120, 20))
+            pbytes = B * (12 * N_POINTS + 4 * pcells)
+            line["roofline_polar"] = {"kernel": "k_polar_lds (polar BEV scatter, 40x120x20)", "bound": "hbm", "achieved": pbytes / ms / 1e6,
+                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": pbytes / ms / 1e6 / HBM_PEAK_GBS, "ms": ms,
+                                      "traffic": pmc.get("k_polar_lds", {}).get("hbm_bytes"), "algorithmic_bytes_per_launch": pbytes}
+            samples = 1.47e6 * B                       # two-tap samples per launch (120 angles x 120 rays x ~102 steps)
+            r = pmc.get("k_radon2", {})
+            line["roofline_radon"] = {"kernel": "k_radon2 (two images per workgroup)", "bound": "valu+lds (not HBM: 115 KB per image)",
+                                      "ms": kern_ms["radon"], "samples_per_s": samples / (kern_ms["radon"] * 1e-3),
+                                      "valu_issue_frac": r.get("valu_issue_frac"), "lds_busy_frac": r.get("lds_busy_frac"),
+                                      "lds_bank_conflict_frac_of_lds": r.get("lds_bank_conflict_frac"),
+                                      "hbm_bytes": r.get("hbm_bytes"), "source": "profiles/r02_pmc.json" if r else None}
+            line["sweeps"] = sweep_legs(device, spec32[:CH].reshape(-1, 61, 120))
+            line["pipeline_shard"] = pipeline_shard_leg(device, spec32[:CH].reshape(-1, 61, 120), gicp_res)
+            line["dropin_latency"] = dropin_latency_leg(host_scans(chunks[0][0], 1)[0])
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(scans)
+            line["cpu_baseline"] = cpu_baseline(host_scans(chunks[0][0], min(args.cpu_sample, B)))
     else:
         line = None
     if dist_on:

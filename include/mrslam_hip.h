@@ -368,6 +368,13 @@ int mrs_ring_corr_fft_pairs(mrs_ctx* ctx, const float* d_a_spec, const float* d_
 int mrs_ring_spectrum_corr_pairs(mrs_ctx* ctx, const float* d_norm_sino, const float* d_cand_spec, int32_t n_pairs,
                                  int32_t n_angles, int32_t det, float* d_half_spec, void* d_half_spec_f16, float* d_dist,
                                  int32_t* d_angle, mrs_stream stream);
+/* Same launch with the candidates picked out of a database: candidate of pair i = row d_cand_index[i] of d_db_spec,
+ * a [n_db][61][120] array of complex64 half spectra (db_is_f16 = 0) or of their fp16 replicas (db_is_f16 = 1:
+ * IEEE binary16 pairs, the multi-GPU exchange format; arithmetic stays fp32).  This is the per-query step after a
+ * candidate pre-selection over the replicated database (RING_ros/main_RING.py:133-140 scores every candidate). */
+int mrs_ring_spectrum_corr_pairs_db(mrs_ctx* ctx, const float* d_norm_sino, const void* d_db_spec, int32_t db_is_f16,
+                                    const int32_t* d_cand_index, int32_t n_pairs, int32_t n_angles, int32_t det, float* d_half_spec,
+                                    void* d_half_spec_f16, float* d_dist, int32_t* d_angle, mrs_stream stream);
 
 /* Multi-channel forms (RING++, fast_corr_RINGplusplus, RING_ros/util.py:337-358): descriptors are
  * [channels][61][120] complex64 half spectra of the jointly normalised channels (mrs_normalize_groups over

@@ -257,7 +257,11 @@ __global__ __launch_bounds__(NSLOT* kSlotThreads) void k_ring_corr_fft(const flo
 // the LDS copy of that spectrum, its correlation with the candidate's.  Same arithmetic, op for op, as
 // k_ring_half_spectrum followed by the pairwise k_ring_corr_fft (bitwise identical results), one launch and one
 // round trip of the spectrum through HBM less.  grid = pairs, 128 lanes.
-__global__ __launch_bounds__(kSlotThreads) void k_ring_spec_corr_pairs(const float* __restrict__ x, const float2* __restrict__ cand,
+// CT = float2 (exact database entries) or __half2 (fp16 replicas received from other ranks); cand_idx (optional):
+// the candidate of pair i is row cand_idx[i] of `cand` (a pre-selected row of the replicated database) instead of row i.
+template <typename CT>
+__global__ __launch_bounds__(kSlotThreads) void k_ring_spec_corr_pairs(const float* __restrict__ x, const CT* __restrict__ cand,
+                                                                       const int* __restrict__ cand_idx,
                                                                        float2* __restrict__ out, __half2* __restrict__ out16,
                                                                        float denom, float* __restrict__ dist,
                                                                        int* __restrict__ angle)
@@ -288,9 +292,9 @@ __global__ __launch_bounds__(kSlotThreads) void k_ring_spec_corr_pairs(const flo
     }
     __syncthreads();
     float re[60], im[60];
-    const float2* b = cand + (size_t)pair * kHalf * kD + d;
+    const CT* b = cand + (size_t)(cand_idx ? cand_idx[pair] : pair) * kHalf * kD + d;
     corr_irfft120([&](int k, float& ar, float& ai, float& br, float& bi) {
-        const float2 bv = b[k * kD];
+        const float2 bv = load_spec(b + k * kD);
         const float2 av = qs[k * kD + d];
         ar = av.x; ai = av.y; br = bv.x; bi = bv.y;
     }, re, im);
@@ -322,6 +326,28 @@ __global__ __launch_bounds__(kSlotThreads) void k_ring_spec_corr_pairs(const flo
 }
 
 }  // namespace
+
+template <typename CT>
+static int spectrum_corr_pairs_launch(mrs_ctx* ctx, const float* d_norm_sino, const CT* cand, const int32_t* d_cand_index,
+                                      int32_t n_pairs, int32_t n_angles, int32_t det, float* d_half_spec, void* d_half_spec_f16,
+                                      float* d_dist, int32_t* d_angle, mrs_stream stream)
+{
+    MRS_REQUIRE(ctx && d_norm_sino && cand && d_dist && d_angle, "null pointer");
+    MRS_REQUIRE(n_pairs > 0, "n_pairs must be positive");
+    if (n_angles != kA || det != kD) {
+        mrs::set_error("ring_spectrum_corr_pairs is specialised for 120 x 120 (got %d x %d)", n_angles, det);
+        return MRS_ERR_UNSUPPORTED;
+    }
+    MRS_HIP_TRY(hipSetDevice(ctx->device));
+    const size_t lds = (size_t)kHalf * kD * sizeof(float2);
+    MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring_spec_corr_pairs<CT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+    hipLaunchKernelGGL(k_ring_spec_corr_pairs<CT>, dim3(n_pairs), dim3(kSlotThreads), lds, (hipStream_t)stream, d_norm_sino, cand,
+                       d_cand_index, reinterpret_cast<float2*>(d_half_spec), reinterpret_cast<__half2*>(d_half_spec_f16),
+                       (float)(0.15 * kA * kD), d_dist, d_angle);
+    MRS_HIP_TRY(hipGetLastError());
+    return MRS_OK;
+}
 
 extern "C" {
 
@@ -443,21 +469,19 @@ int mrs_ring_spectrum_corr_pairs(mrs_ctx* ctx, const float* d_norm_sino, const f
                                  int32_t n_angles, int32_t det, float* d_half_spec, void* d_half_spec_f16, float* d_dist,
                                  int32_t* d_angle, mrs_stream stream)
 {
-    MRS_REQUIRE(ctx && d_norm_sino && d_cand_spec && d_dist && d_angle, "null pointer");
-    MRS_REQUIRE(n_pairs > 0, "n_pairs must be positive");
-    if (n_angles != kA || det != kD) {
-        mrs::set_error("ring_spectrum_corr_pairs is specialised for 120 x 120 (got %d x %d)", n_angles, det);
-        return MRS_ERR_UNSUPPORTED;
-    }
-    MRS_HIP_TRY(hipSetDevice(ctx->device));
-    const size_t lds = (size_t)kHalf * kD * sizeof(float2);
-    MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring_spec_corr_pairs), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
-    hipLaunchKernelGGL(k_ring_spec_corr_pairs, dim3(n_pairs), dim3(kSlotThreads), lds, (hipStream_t)stream, d_norm_sino,
-                       reinterpret_cast<const float2*>(d_cand_spec), reinterpret_cast<float2*>(d_half_spec),
-                       reinterpret_cast<__half2*>(d_half_spec_f16), (float)(0.15 * kA * kD), d_dist, d_angle);
-    MRS_HIP_TRY(hipGetLastError());
-    return MRS_OK;
+    return spectrum_corr_pairs_launch<float2>(ctx, d_norm_sino, reinterpret_cast<const float2*>(d_cand_spec), nullptr, n_pairs, n_angles,
+                                              det, d_half_spec, d_half_spec_f16, d_dist, d_angle, stream);
+}
+
+int mrs_ring_spectrum_corr_pairs_db(mrs_ctx* ctx, const float* d_norm_sino, const void* d_db_spec, int32_t db_is_f16,
+                                    const int32_t* d_cand_index, int32_t n_pairs, int32_t n_angles, int32_t det, float* d_half_spec,
+                                    void* d_half_spec_f16, float* d_dist, int32_t* d_angle, mrs_stream stream)
+{
+    MRS_REQUIRE(d_cand_index, "null candidate index");
+    return db_is_f16 ? spectrum_corr_pairs_launch<__half2>(ctx, d_norm_sino, reinterpret_cast<const __half2*>(d_db_spec), d_cand_index,
+                                                          n_pairs, n_angles, det, d_half_spec, d_half_spec_f16, d_dist, d_angle, stream)
+                     : spectrum_corr_pairs_launch<float2>(ctx, d_norm_sino, reinterpret_cast<const float2*>(d_db_spec), d_cand_index,
+                                                          n_pairs, n_angles, det, d_half_spec, d_half_spec_f16, d_dist, d_angle, stream);
 }
 
 }  // extern "C"

@@ -339,6 +339,26 @@ def spectrum_corr_pairs(norm, cand_spec, want_f32=True, want_f16=False, out=None
     return (torch.view_as_complex(spec) if want_f32 else None), spec16, dist, ang
 
 
+def spectrum_corr_pairs_db(norm, db_spec, cand_index, want_f32=True, want_f16=False, out=None):
+    """spectrum_corr_pairs with the candidate of pair i = row cand_index[i] (int32 device tensor) of a database of half
+    spectra: complex64 [N,61,120] or the fp16 replica format [N,61,120,2] float16."""
+    d = _dev(norm)
+    x, db, idx = norm.contiguous(), db_spec.contiguous(), cand_index.contiguous()
+    P = x.shape[0]
+    assert x.shape[-2:] == (120, 120) and idx.dtype == torch.int32 and idx.numel() == P
+    f16 = db.dtype == torch.float16
+    assert (f16 and db.shape[1:] == (61, 120, 2)) or (db.dtype == torch.complex64 and db.shape[1:] == (61, 120))
+    spec = torch.empty((P, 61, 120, 2), dtype=torch.float32, device=x.device) if want_f32 else None
+    spec16 = torch.empty((P, 61, 120, 2), dtype=torch.float16, device=x.device) if want_f16 else None
+    dist, ang = out if out is not None else (torch.empty(P, dtype=torch.float32, device=x.device),
+                                             torch.empty(P, dtype=torch.int32, device=x.device))
+    _lib.check(_lib.load().mrs_ring_spectrum_corr_pairs_db(_lib.ctx(d), _lib.ptr(x), _lib.ptr(db if f16 else torch.view_as_real(db)),
+                                                           int(f16), _lib.ptr(idx), P, 120, 120,
+                                                           _lib.ptr(spec) if want_f32 else None, _lib.ptr(spec16) if want_f16 else None,
+                                                           _lib.ptr(dist), _lib.ptr(ang), _lib.current_stream(d)))
+    return (torch.view_as_complex(spec) if want_f32 else None), spec16, dist, ang
+
+
 def corr_sweep_fft(query_spec, db_spec, want_corr=False):
     """C1 sweep on half spectra: query_spec [Q,61,120] complex64, db_spec [N,61,120] complex64 or its fp16
     replica [N,61,120,2] float16 (device)."""

@@ -60,3 +60,126 @@ def sharded_sweep(queries, local_db, sweep_fn, group=None):
     d_all = allgather_ragged(d.t().contiguous(), group).t().contiguous()
     a_all = allgather_ragged(a.t().contiguous(), group).t().contiguous()
     return d_all, a_all
+
+
+def _world(group=None):
+    return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def _rank(group=None):
+    return dist.get_rank(group) if (dist.is_available() and dist.is_initialized()) else 0
+
+
+def sharded_topk_sweep(queries, local_db, sweep_fn, k, group=None):
+    """The low-traffic alternative to replicating the database: the database stays sharded, the
+    queries are the same on every rank (all-gather them first if they are not), every rank scores them against ITS rows
+    and only the k best (dist, angle, global row) per query travel.  Rows are numbered in rank order (rank r owns
+    [sum of the earlier shards, ...)).  Returns (dist [Q,k], angle [Q,k], row [Q,k]) sorted by ascending dist, identical
+    on every rank; ties resolve to the smaller global row, like a single-rank sweep followed by a stable sort."""
+    world, rank = _world(group), _rank(group)
+    Q = queries.shape[0]
+    dev = queries.device
+    n_local = torch.tensor([local_db.shape[0]], dtype=torch.int64, device=dev)
+    if world > 1:
+        counts = [torch.zeros_like(n_local) for _ in range(world)]
+        dist.all_gather(counts, n_local, group=group)
+        counts = [int(c.item()) for c in counts]
+    else:
+        counts = [int(n_local.item())]
+    base = sum(counts[:rank])
+    if local_db.shape[0]:
+        d, a = sweep_fn(queries, local_db)
+    else:
+        d = torch.zeros((Q, 0), dtype=torch.float32, device=dev); a = torch.zeros((Q, 0), dtype=torch.int32, device=dev)
+    kk = min(k, d.shape[1])
+    row = torch.arange(d.shape[1], device=dev, dtype=torch.int64)[None].expand(Q, -1) + base
+    if kk:
+        order = torch.argsort(d, dim=1, stable=True)[:, :kk]
+        d, a, row = torch.gather(d, 1, order), torch.gather(a, 1, order), torch.gather(row, 1, order)
+    # fixed-size exchange: k slots per rank, unused slots carry +inf
+    pd = torch.full((Q, k), float("inf"), dtype=torch.float32, device=dev); pd[:, :kk] = d[:, :kk]
+    pa = torch.zeros((Q, k), dtype=torch.int32, device=dev); pa[:, :kk] = a[:, :kk]
+    pr = torch.full((Q, k), -1, dtype=torch.int64, device=dev); pr[:, :kk] = row[:, :kk]
+    if world > 1:
+        gd = torch.empty((world * Q, k), dtype=torch.float32, device=dev)    # concatenation along dim 0 (gloo and RCCL alike)
+        ga = torch.empty((world * Q, k), dtype=torch.int32, device=dev)
+        gr = torch.empty((world * Q, k), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(gd, pd.contiguous(), group=group)
+        dist.all_gather_into_tensor(ga, pa.contiguous(), group=group)
+        dist.all_gather_into_tensor(gr, pr.contiguous(), group=group)
+        pd = gd.view(world, Q, k).permute(1, 0, 2).reshape(Q, world * k)
+        pa = ga.view(world, Q, k).permute(1, 0, 2).reshape(Q, world * k)
+        pr = gr.view(world, Q, k).permute(1, 0, 2).reshape(Q, world * k)
+    # rank-major concatenation = ascending global row among equal distances -> the stable sort keeps that order
+    order = torch.argsort(pd, dim=1, stable=True)[:, :k]
+    return torch.gather(pd, 1, order), torch.gather(pa, 1, order), torch.gather(pr, 1, order)
+
+
+class OwnerRescorer:
+    """Exact re-scoring of loop candidates whose replica score is too close to the acceptance threshold to trust.
+
+    Non-owner ranks hold fp16 replicas of a descriptor (the exchange format); the owner keeps the exact fp32 entry.  A
+    replica score differs from the exact one by < 2e-3 (tests/test_ring_gpu.py::test_fp16_replica_format), while the
+    reference accepts a loop on a hard threshold (RING_ros/main_RING.py:137 `dist < cfg.dist_threshold`, config.py:17).
+    So every (query, candidate) whose replica distance lies within `margin` of the threshold is sent to the candidate's
+    owner, scored there against the exact entry, and the decision is taken on that number.
+
+    Collectives have static shapes (at most `slots` requests per rank and call, padded), so every rank issues the same
+    sequence whatever its data: one all-gather of the requests (row index + the query's fp32 descriptor), one
+    all-reduce of the answers."""
+
+    def __init__(self, threshold, margin=2e-3, slots=64, group=None):
+        self.threshold, self.margin, self.slots, self.group = float(threshold), float(margin), int(slots), group
+        self.stats = {"calls": 0, "requested": 0, "dropped": 0, "flipped": 0}
+
+    def ambiguous(self, dist_replica):
+        return torch.nonzero((dist_replica - self.threshold).abs() < self.margin).reshape(-1)
+
+    def rescore(self, dist_replica, angle_replica, cand_row, query_desc, owner_of_row, local_row_of, exact_pair_fn):
+        """dist_replica/angle_replica/cand_row: [P] results against replicas and the candidates' GLOBAL rows;
+        query_desc: [P, ...] the queries' exact descriptors (device); owner_of_row(rows)->rank tensor and
+        local_row_of(rows)->owner-local index tensor map global rows; exact_pair_fn(query_desc [m,...], local_rows [m]) ->
+        (dist [m], angle [m]) scores against the caller's OWN exact entries.  Returns (dist, angle) with the ambiguous
+        entries replaced by the owners' exact values."""
+        world, rank = _world(self.group), _rank(self.group)
+        dev = dist_replica.device
+        S = self.slots
+        amb = self.ambiguous(dist_replica)
+        self.stats["calls"] += 1
+        self.stats["requested"] += int(amb.numel())
+        if amb.numel() > S:                                  # bounded: the closest to the threshold first
+            keep = torch.argsort((dist_replica[amb] - self.threshold).abs())[:S]
+            self.stats["dropped"] += int(amb.numel()) - S
+            amb = amb[keep]
+        m = int(amb.numel())
+        rows = torch.full((S,), -1, dtype=torch.int64, device=dev)
+        rows[:m] = cand_row[amb].to(torch.int64)
+        q = torch.zeros((S,) + tuple(query_desc.shape[1:]), dtype=query_desc.dtype, device=dev)
+        q[:m] = query_desc[amb]
+        if world > 1:
+            all_rows = torch.empty((world * S,), dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(all_rows, rows, group=self.group)
+            qr = torch.view_as_real(q) if q.is_complex() else q
+            all_q = torch.empty((world * S,) + tuple(qr.shape[1:]), dtype=qr.dtype, device=dev)
+            dist.all_gather_into_tensor(all_q, qr.contiguous(), group=self.group)
+            if q.is_complex():
+                all_q = torch.view_as_complex(all_q)
+        else:
+            all_rows, all_q = rows, q
+        ans_d = torch.zeros((world * S,), dtype=torch.float32, device=dev)
+        ans_a = torch.zeros((world * S,), dtype=torch.int32, device=dev)
+        valid = all_rows >= 0
+        mine = torch.nonzero(valid & (owner_of_row(all_rows.clamp(min=0)) == rank)).reshape(-1)
+        if mine.numel():
+            d, a = exact_pair_fn(all_q[mine], local_row_of(all_rows[mine]))
+            ans_d[mine] = d.to(torch.float32); ans_a[mine] = a.to(torch.int32)
+        if world > 1:                                        # exactly one rank fills each slot
+            dist.all_reduce(ans_d, group=self.group)
+            dist.all_reduce(ans_a, group=self.group)
+        out_d, out_a = dist_replica.clone(), angle_replica.clone()
+        if m:
+            new_d = ans_d[rank * S: rank * S + m]
+            self.stats["flipped"] += int(((new_d < self.threshold) != (dist_replica[amb] < self.threshold)).sum())
+            out_d[amb] = new_d
+            out_a[amb] = ans_a[rank * S: rank * S + m]
+        return out_d, out_a

@@ -52,6 +52,30 @@ def _worker(rank, world, port, out_dir):
     d_full, a_full = sweep(torch.from_numpy(q), torch.from_numpy(db))
     assert torch.equal(d_sh, d_full) and torch.equal(a_sh, a_full)
     assert int(a_full[0, 3]) == -9 and int(torch.argmin(d_full[1])) == 1
+    # top-k only exchange over the sharded database == single-rank sweep + stable sort
+    dk, ak, rk = shard.sharded_topk_sweep(torch.from_numpy(q), local, sweep, 3)
+    order = torch.argsort(d_full, dim=1, stable=True)[:, :3]
+    assert torch.equal(dk, torch.gather(d_full, 1, order)) and torch.equal(ak, torch.gather(a_full, 1, order))
+    assert torch.equal(rk, order)
+    dk9, _, rk9 = shard.sharded_topk_sweep(torch.from_numpy(q), local, sweep, 9)     # k larger than the database
+    assert torch.isinf(dk9[:, n_db:]).all() and (rk9[:, n_db:] == -1).all() and torch.equal(rk9[:, :n_db], torch.argsort(d_full, dim=1, stable=True))
+    # owner re-scoring: replicas are a lossy copy; results within the margin of the threshold are recomputed by the
+    # row's owner on its exact entry.  Stand-in scores: exact = |q - entry|, replica = exact + a known error.
+    exact_db = torch.arange(10, dtype=torch.float32)                 # rows 0..4 owned by rank 0, 5..9 by rank 1
+    own = exact_db[5 * rank: 5 * rank + 5]
+    qv = torch.tensor([2.3005, 7.5, 6.3, 0.1], dtype=torch.float32) + rank   # different queries per rank
+    cand_row = torch.tensor([2, 8, 6, 9])
+    exact = (qv - exact_db[cand_row]).abs()
+    err = torch.tensor([1.5e-3, -1.0e-3, 0.0, 1e-3])
+    replica = exact + err
+    thr = float(exact[0]) + 1e-3                                      # entry 0: replica above, exact below the threshold
+    rs = shard.OwnerRescorer(thr, margin=2e-3, slots=3)
+    got_d, got_a = rs.rescore(replica, torch.zeros(4, dtype=torch.int32), cand_row, qv[:, None],
+                              lambda rows: rows // 5, lambda rows: rows % 5,
+                              lambda qq, lr: ((qq[:, 0] - own[lr]).abs(), torch.full((qq.shape[0],), 7, dtype=torch.int32)))
+    amb = (replica - thr).abs() < 2e-3
+    assert amb[0] and torch.equal(got_d[amb], exact[amb]) and torch.equal(got_d[~amb], replica[~amb])
+    assert (got_a[amb] == 7).all() and rs.stats["flipped"] >= 1 and rs.stats["dropped"] == 0
     # empty shard on one rank
     e = shard.allgather_ragged(torch.zeros((0 if rank else 2, 3)))
     assert e.shape == (2, 3)

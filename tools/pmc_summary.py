@@ -1,0 +1,56 @@
+"""Condenses the rocprofv3 --pmc passes over tools/pmc_targets.py (gpurun_out/<tag>/pmc_<group>/...) into
+profiles/<tag>_pmc.json + .md.  HBM bytes: FETCH_SIZE / WRITE_SIZE in KB, FETCH_SIZE doubled on gfx950 (64 B counted per
+128-B request) as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes.  VALU issue fraction = SQ_INSTS_VALU x 4
+cycles / (256 CUs x 4 SIMDs x active cycles per XCD); LDS busy = SQ_LDS_IDX_ACTIVE / (256 CUs x active cycles per XCD);
+active cycles per XCD = GRBM_GUI_ACTIVE / 8."""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", tag)
+KEYS = {"k_cart_lds": "k_cart_lds", "k_polar_lds": "k_polar_lds", "k_radon2": "k_radon2", "k_ring_spec_corr_pairs": "k_ring_spec_corr_pairs",
+        "k_ring_corr_fft": "k_ring_corr_fft", "k_linearize": "k_linearize", "k_nn_scan": "k_nn_scan", "k_knn_cov": "k_knn_cov"}
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        m = re.search(r"(k_[a-z_0-9]+)", r["Kernel_Name"])
+        if not m or m.group(1) not in KEYS:
+            continue
+        k = m.group(1)
+        if k == "k_ring_corr_fft":
+            k += "@grid%s" % r["Grid_Size"]
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {}
+for k, c in sorted(acc.items()):
+    mean = {n: sum(v) / len(v) for n, v in c.items()}
+    e = {"launches": max(len(v) for v in c.values()), "counters": mean}
+    if "FETCH_SIZE" in mean or "WRITE_SIZE" in mean:
+        e["hbm_read_bytes"] = 2 * mean.get("FETCH_SIZE", 0.0) * 1024
+        e["hbm_write_bytes"] = mean.get("WRITE_SIZE", 0.0) * 1024
+        e["hbm_bytes"] = e["hbm_read_bytes"] + e["hbm_write_bytes"]
+    if "GRBM_GUI_ACTIVE" in mean:
+        cyc = mean["GRBM_GUI_ACTIVE"] / 8.0
+        e["active_cycles_per_xcd"] = cyc
+        if "SQ_INSTS_VALU" in mean:
+            e["valu_issue_frac"] = mean["SQ_INSTS_VALU"] * 4.0 / (256 * 4 * cyc)
+        if "SQ_LDS_IDX_ACTIVE" in mean:
+            e["lds_busy_frac"] = mean["SQ_LDS_IDX_ACTIVE"] / (256 * cyc)
+        if "SQ_LDS_BANK_CONFLICT" in mean and mean.get("SQ_LDS_IDX_ACTIVE"):
+            e["lds_bank_conflict_frac"] = mean["SQ_LDS_BANK_CONFLICT"] / mean["SQ_LDS_IDX_ACTIVE"]
+    out[k] = e
+os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
+json.dump(out, open(os.path.join(root, "profiles", f"{tag}_pmc.json"), "w"), indent=1)
+with open(os.path.join(root, "profiles", f"{tag}_pmc.md"), "w") as o:
+    o.write(f"# rocprofv3 --pmc summary `{tag}` (tools/pmc_targets.py, 1 x MI355X, separate passes per counter group, no tracing)\n\n")
+    o.write("| kernel | launches | HBM read MB | HBM write MB | VALU issue | LDS busy | LDS conflict share |\n|---|---|---|---|---|---|---|\n")
+    for k, e in out.items():
+        f = lambda v, s=1.0, p="{:.2f}": p.format(v * s) if v is not None else "-"
+        o.write(f"| `{k}` | {e['launches']} | {f(e.get('hbm_read_bytes'), 1e-6)} | {f(e.get('hbm_write_bytes'), 1e-6)} | "
+                f"{f(e.get('valu_issue_frac'))} | {f(e.get('lds_busy_frac'))} | {f(e.get('lds_bank_conflict_frac'))} |\n")
+print(open(os.path.join(root, "profiles", f"{tag}_pmc.md")).read())

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Collects the round's profiles on the GPU box (run through gpurun from the repo root):
+#   kernel-trace stats of the default bench run, then one --pmc pass per counter group over tools/pmc_targets.py.
+# PMC passes carry no tracing flags (gpurun refuses --pmc together with trace domains).
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs > $OUT/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $R/tools/pmc_targets.py > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $R/tools/pmc_targets.py > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $OUT/pmc_valu -- python $R/tools/pmc_targets.py > $OUT/pmc_valu.log 2>&1
+rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc_lds -- python $R/tools/pmc_targets.py > $OUT/pmc_lds.log 2>&1
+ls $OUT; tail -2 $OUT/*.log
