@@ -14,7 +14,7 @@ def _run(extra_env=None):
     env = dict(os.environ)
     env.update(extra_env or {})
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "32",
-                        "--db", "512", "--gicp-pairs", "2", "--gicp-iters", "3"], capture_output=True, text=True, env=env, timeout=600)
+                        "--chunks", "3", "--cpu-sample", "8", "--gicp-pairs", "2", "--gicp-iters", "6"], capture_output=True, text=True, env=env, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     return json.loads(lines[-1])          # the JSON is the LAST line of stdout
@@ -28,12 +28,17 @@ def test_bench_line_contract():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["unit"] == "pairs/s"
     assert "workload" in d["config"] and "model" not in d["config"]
-    assert abs(d["value"] - 32 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    assert abs(d["value"] - 32 * 3 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]       # batch x chunks x steps / time
+    assert d["config"]["pairs_per_rank_per_step"] == 96 and d["config"]["launches_per_step"] == 3
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
-    assert d["gicp"]["iterations"] == 3 and d["gicp"]["iters_per_s"] > 0 and d["sweep"]["pairs_per_s"] > 0
+    assert d["gicp"]["iterations"] == 6 and d["gicp"]["iters_per_s"] > 0 and d["gicp"]["nn_passes"] == 6
+    assert d["gicp"]["cold"]["iters_per_s"] > 0 and d["gicp"]["natural"]["converged"] == 2
+    for leg in ("roofline_polar", "roofline_radon", "sweeps", "pipeline_shard", "dropin_latency"):
+        assert leg in d, leg
+    assert d["roofline_polar"]["bound"] == "hbm" and d["sweeps"]["ring_q1"]["pairs_per_s"] > 0 and d["sweeps"]["disco_q4"]["queries_per_s"] > 0
 
 
 def test_bench_collective_path_on_one_gpu():
@@ -41,3 +46,6 @@ def test_bench_collective_path_on_one_gpu():
     ranks) with world size 1."""
     d = _run({"MRS_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"})
     assert d["n_gpus"] == 1 and d["value"] > 0 and "all-gather" in d["config"]["parallelism"]
+    x = d["exchange"]
+    assert x["allgather_bytes_in_per_rank_per_launch"] == 0 and x["compute_stream_wait_ms_per_launch"] >= 0      # world size 1: nothing inbound
+    assert x["rescore"]["calls"] == 4 and x["rescore"]["dropped"] >= 0 and x["designs"]["sharded_topk_ms"] > 0
