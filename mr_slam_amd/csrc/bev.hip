@@ -18,6 +18,8 @@
 //     from the host libm, through a host-built table of change points);
 //   * the bit-for-bit `retreive()` layouts (order-dependent x/y payloads, enough_large > 1,
 //     num_height > 1) go through deterministic multi-pass kernels on global scratch.
+#include <hipcub/hipcub.hpp>
+
 #include <climits>
 #include <cmath>
 
@@ -594,6 +596,62 @@ __global__ void k_feat_max(const float* __restrict__ pts, const int64_t* __restr
     }
 }
 
+// A5 with num_height > 1.  The reference keeps ONE running maximum per (column, channel) while it writes the value into
+// the point's own height layer (kernel.cu:151-158: max_h is indexed without the layer), so what a layer's cell holds
+// depends on the ORDER of the column's points: it is the last point of that layer that raised the column's running
+// maximum.  Sequential reading (threads in gid order = what the host build of the reference executes): stable sort of
+// the points by (scan, column), then one thread walks each column's points in input order with the running maxima in
+// registers.  Values <= 0 never pass `max_h < value` (max_h starts at 0).
+constexpr int kFeatMax = 16;
+
+__global__ void k_feat_keys(const float* __restrict__ pts, const int64_t* __restrict__ offs, CartP p,
+                            unsigned long long* __restrict__ keys, int* __restrict__ vals)
+{
+    const int b = blockIdx.y;
+    const ScanView v = scan_view(pts, offs, b, p.F);
+    const int64_t o = offs[b];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < v.n; i += gridDim.x * blockDim.x) {
+        int col = 0;
+        const int lin = cart_lin(p, v.px[i], v.py[i], v.pz[i], col);
+        keys[o + i] = lin < 0 ? ~0ull : (((unsigned long long)b << 32) | (unsigned)col);
+        vals[o + i] = i;
+    }
+}
+
+template <bool COMPACT>
+__global__ void k_feat_columns(const float* __restrict__ pts, const int64_t* __restrict__ offs, CartP p,
+                               const unsigned long long* __restrict__ keys, const int* __restrict__ perm, size_t total,
+                               float* __restrict__ out)
+{
+    const size_t cols = (size_t)p.NX * p.NY;
+    const size_t cells = cols * p.H;
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < total; j += (size_t)gridDim.x * blockDim.x) {
+        const unsigned long long k = keys[j];
+        if (k == ~0ull || (j > 0 && keys[j - 1] == k)) continue;      // not the head of a column's run
+        const int b = (int)(k >> 32);
+        const ScanView v = scan_view(pts, offs, b, p.F);
+        float* dst = out + (size_t)b * cells * (COMPACT ? p.F - 3 : p.F);
+        float m[kFeatMax];
+#pragma unroll
+        for (int c = 0; c < kFeatMax; ++c) m[c] = 0.0f;
+        for (size_t e = j; e < total && keys[e] == k; ++e) {
+            const int i = perm[e];
+            int col;
+            const int lin = cart_lin(p, v.px[i], v.py[i], v.pz[i], col);
+#pragma unroll
+            for (int c = 0; c < kFeatMax; ++c) {
+                if (c >= p.F) break;
+                const float f = v.px[i + (size_t)c * v.n];
+                if (m[c] < f) {
+                    m[c] = f;
+                    if (COMPACT) { if (c >= 3) dst[(size_t)(c - 3) * cells + lin] = f; }
+                    else dst[(size_t)lin * p.F + c] = f;
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -872,15 +930,44 @@ int mrs_bev_feat_batch(mrs_ctx* ctx, const float* d_pts, const int64_t* d_offset
     CartP p;
     st = make_cart(cfg, true, p);
     if (st != MRS_OK) return st;
-    if (p.H != 1) {
-        mrs::set_error("feature BEV: num_height > 1 is racy/undefined in the reference; only 1 is supported");
-        return MRS_ERR_UNSUPPORTED;
-    }
     if (layout == MRS_BEV_OUT_COMPACT && p.F <= 3) {
         mrs::set_error("feature BEV COMPACT layout needs featsize > 3");
         return MRS_ERR_ARG;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (p.H != 1) {   // order-dependent semantics: sorted columns, one thread per column (see k_feat_columns)
+        MRS_REQUIRE(p.F <= kFeatMax, "feature BEV with num_height > 1 supports at most 16 channels");
+        MRS_REQUIRE(batch <= mrs::kMaxGridY, "at most 65535 scans per call (split the batch)");
+        const size_t cellsH = (size_t)p.NX * p.NY * p.H;
+        const size_t totH = (size_t)batch * cellsH * (layout == MRS_BEV_OUT_COMPACT ? p.F - 3 : p.F);
+        MRS_HIP_TRY(hipMemsetAsync(d_out, 0, totH * sizeof(float), s));
+        int64_t total = 0;
+        MRS_HIP_TRY(hipMemcpyAsync(&total, d_offsets + batch, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        MRS_HIP_TRY(hipStreamSynchronize(s));
+        if (total == 0) return MRS_OK;
+        MRS_REQUIRE(total < (1ll << 31), "more than 2^31 points in one call");
+        mrs::Scratch k_in, k_out, v_in, v_out, tmp;
+        if ((st = k_in.alloc((size_t)total * 8, s)) != MRS_OK) return st;
+        if ((st = k_out.alloc((size_t)total * 8, s)) != MRS_OK) return st;
+        if ((st = v_in.alloc((size_t)total * 4, s)) != MRS_OK) return st;
+        if ((st = v_out.alloc((size_t)total * 4, s)) != MRS_OK) return st;
+        hipLaunchKernelGGL(k_feat_keys, dim3(512, batch), dim3(256), 0, s, d_pts, d_offsets, p, k_in.as<unsigned long long>(), v_in.as<int>());
+        size_t bytes = 0;
+        MRS_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k_in.as<unsigned long long>(), k_out.as<unsigned long long>(),
+                                                       v_in.as<int>(), v_out.as<int>(), (int)total, 0, 64, s));
+        if ((st = tmp.alloc(bytes, s)) != MRS_OK) return st;
+        MRS_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes, k_in.as<unsigned long long>(), k_out.as<unsigned long long>(),
+                                                       v_in.as<int>(), v_out.as<int>(), (int)total, 0, 64, s));
+        const int fb = blocks_for((size_t)total, 256, 4096);
+        if (layout == MRS_BEV_OUT_COMPACT)
+            hipLaunchKernelGGL(k_feat_columns<true>, dim3(fb), dim3(256), 0, s, d_pts, d_offsets, p, k_out.as<unsigned long long>(),
+                               v_out.as<int>(), (size_t)total, d_out);
+        else
+            hipLaunchKernelGGL(k_feat_columns<false>, dim3(fb), dim3(256), 0, s, d_pts, d_offsets, p, k_out.as<unsigned long long>(),
+                               v_out.as<int>(), (size_t)total, d_out);
+        MRS_HIP_TRY(hipGetLastError());
+        return MRS_OK;
+    }
     const size_t cells = (size_t)p.NX * p.NY;
     const size_t tot = (size_t)batch * cells * (layout == MRS_BEV_OUT_COMPACT ? p.F - 3 : p.F);
     // positive floats order like ints: accumulate straight into the output buffer

@@ -317,3 +317,25 @@ def test_compact_maps_drop_special_values_like_the_oracle(dev, oracle):
         np.testing.assert_array_equal(cart[b].reshape(-1), oracle.bev_cart(soa, 1, 1, 120, 120, 1).reshape(-1, 3)[:, 2])
         np.testing.assert_array_equal(pol[b].reshape(-1), oracle.bev_polar(soa, 1, 1, 40, 120, 20).reshape(-1, 3)[:, 2])
         np.testing.assert_array_equal(pol1[b].reshape(-1), oracle.bev_polar(soa, 1, 1, 120, 120, 1).reshape(-1, 3)[:, 2])
+
+
+def test_feat_bev_height_layers_follow_the_reference_order_semantics(dev, oracle):
+    """num_height > 1: kernel.cu:151-158 keeps ONE running maximum per column while writing into the point's own layer, so
+    the cell of a layer keeps the last point of that layer that raised its column's maximum.  (The reference's manager
+    allocates a single layer for that kernel -- manager.cu:31-32 -- so its own run overflows; the restatement applies the
+    kernel statement sequentially on a full-size map.)  HIP (sorted columns, one thread per column) == restatement,
+    REFERENCE and COMPACT layouts, ragged batch."""
+    from mr_slam_amd import bev
+    from mr_slam_amd._lib import OUT_REFERENCE
+    rng = np.random.default_rng(31)
+    for (NX, NY, H, F) in ((40, 30, 4, 9), (120, 120, 3, 6)):
+        planes = [rng.uniform(-1.1, 1.1, size=(F, n)).astype(np.float32) for n in (30000, 1, 12345)]
+        for p in planes:
+            p[np.abs(p) == 1.0] = 0.5
+        pts, offs = bev.pack_scans([p.reshape(-1) for p in planes], dev, planes=F)
+        ref = bev.feat_bev(pts, offs, F, 1, 1, NX, NY, H, layout=OUT_REFERENCE).cpu().numpy()
+        comp = bev.feat_bev(pts, offs, F, 1, 1, NX, NY, H).cpu().numpy()
+        for b, p in enumerate(planes):
+            want = oracle.bev_feat(p.reshape(-1), F, 1, 1, NX, NY, H)
+            np.testing.assert_array_equal(ref[b], want)
+            np.testing.assert_array_equal(comp[b].reshape(F - 3, -1), want.reshape(-1, F)[:, 3:].T)

@@ -209,3 +209,15 @@ def test_feat_oracle_matches_reference_golden_and_build(oracle, golden_dir):
         pts[np.abs(pts) == 1.0] = 0.5
         np.testing.assert_array_equal(oracle.ref_bev_feat(pts.reshape(-1), F, 1, 1, 120, 120, 1),
                                       oracle.bev_feat(pts.reshape(-1), F, 1, 1, 120, 120, 1))
+    # num_height > 1 is NOT compared with the reference build: its manager allocates a one-layer device map
+    # (manager.cu:31-32: d_feat_size = num_x * num_y * featsize floats) while the kernel indexes all layers
+    # (kernel.cu:155) -- a buffer overflow (the host build crashes).  The restatement gives the kernel's statement its
+    # sequential reading on a full-size map; layer 0 of a single-layer-tall cloud is the one place both are defined.
+    F = 6
+    pts = rng.uniform(-1.1, 1.1, size=(F, 20_000)).astype(np.float32)
+    pts[np.abs(pts) == 1.0] = 0.5
+    pts[2] = -np.abs(pts[2]) * 0.9 - 0.05                       # every z in layer 0 of H = 2 (z < 0)
+    got = oracle.bev_feat(pts.reshape(-1), F, 1, 1, 60, 60, 2).reshape(2, 3600, F)
+    one = oracle.ref_bev_feat(pts.reshape(-1), F, 1, 2, 60, 60, 1).reshape(3600, F)   # same columns, one layer, via the reference
+    np.testing.assert_array_equal(got[0], one)
+    assert not got[1].any()
