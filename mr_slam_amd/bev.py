@@ -94,10 +94,11 @@ def cart_bev(xyz, offsets, max_length, max_height, num_x, num_y, num_height,
 
 def feat_bev(pts, offsets, featsize, max_length, max_height, num_x, num_y, num_height=1,
              layout=OUT_COMPACT, out=None):
-    """A5.  COMPACT: [B, F-3, NX, NY] planar (channels 3..F-1);  REFERENCE: [B, NX*NY*H*F]."""
+    """A5.  COMPACT: [B, F-3, NX, NY] planar (channels 3..F-1; [B, F-3, H, NX, NY] when num_height > 1);
+    REFERENCE: [B, NX*NY*H*F]."""
     cfg = _cfg(max_length, max_height, num_x, num_y, num_height, featsize)
     cells = num_x * num_y * num_height
     if layout == OUT_COMPACT:
         o = _batch("mrs_bev_feat_batch", pts, offsets, cfg, layout, cells * (featsize - 3), out)
-        return o.view(-1, featsize - 3, num_x, num_y)
+        return o.view(-1, featsize - 3, num_x, num_y) if num_height == 1 else o.view(-1, featsize - 3, num_height, num_x, num_y)
     return _batch("mrs_bev_feat_batch", pts, offsets, cfg, layout, cells * featsize, out)
