@@ -178,7 +178,20 @@ def test_solve_translation(dev):
     p = O.radon_parallel(shifted, ANG, 120, 1.0)[None]
     x, y, err, sh = ring.solve_translation(q, p, 0.3, want_shifts=True)
     wx, wy, werr, wsh = K.solve_translation(q, p, 0.3)
-    assert (sh == wsh).mean() > 0.97            # integer row shifts (ties aside)
+    # integer row shifts: equal, or -- where the two FFT implementations pick different maxima -- the float64 circular
+    # correlation of that row has the same value at both positions to fp32 precision (a genuine tie)
+    for i in np.flatnonzero(sh != wsh):
+        c = np.abs(np.fft.ifft(np.fft.fft(q[0, i].astype(np.float64)) * np.conj(np.fft.fft(p[0, i].astype(np.float64)))))
+        c = np.fft.fftshift(c)
+        a, b = c[int(60 - sh[i])], c[int(60 - wsh[i])]
+        assert abs(a - b) <= 2e-6 * c.max(), (i, sh[i], wsh[i], a, b)
+    assert (sh == wsh).mean() > 0.9
+    # the 120 x 2 least-squares solve, unconditionally: on the GPU's own shifts against a float64 pseudo-inverse
+    ang = np.linspace(0, 2 * np.pi, 120).astype(np.float32).astype(np.float64) + 0.3
+    Amat = np.stack([np.cos(ang), np.sin(ang)], 1)
+    sol = np.linalg.pinv(Amat) @ sh.astype(np.float64)
+    res = np.linalg.norm(Amat @ sol - sh)
+    assert abs(x[0] - sol[0]) < 1e-3 and abs(y[0] - sol[1]) < 1e-3 and abs(err - res) < 1e-2 * max(res, 1.0)
     if (sh == wsh).all():
         assert abs(x[0] - wx.item()) < 1e-3 and abs(y[0] - wy.item()) < 1e-3 and abs(err - werr.item()) < 1e-2
 
