@@ -65,13 +65,14 @@ def test_rotate_bev_matches_restatement(dev):
         # every output pixel equal, except where the source coordinate sits on a texel boundary (x.5 within float rounding)
         # and nearest-neighbour rounding may go either way: shown per mismatching pixel in float64
         bad = np.argwhere((got != want).any(0))
-        rot = -ang                                    # inverse map of a rotation by -ang about the image centre
         for (yy, xx) in bad:
             px, py = xx - 59.5, yy - 59.5
-            sx = np.cos(rot) * px + np.sin(rot) * py + 59.5
-            sy = -np.sin(rot) * px + np.cos(rot) * py + 59.5
-            fx, fy = abs(sx - np.floor(sx) - 0.5), abs(sy - np.floor(sy) - 0.5)
-            assert min(fx, fy) < 2e-4, (ang, yy, xx, sx, sy)
+            near = []
+            for rot in (ang, -ang):                   # the source pixel of (yy, xx) under the inverse map (either handedness)
+                sx = np.cos(rot) * px + np.sin(rot) * py + 59.5
+                sy = -np.sin(rot) * px + np.cos(rot) * py + 59.5
+                near.append(min(abs(sx - np.floor(sx) - 0.5), abs(sy - np.floor(sy) - 0.5)))
+            assert min(near) < 2e-4, (ang, yy, xx, near)
         assert len(bad) < 0.002 * 120 * 120
     np.testing.assert_array_equal(ring.rotate_bev(torch.from_numpy(img).to(dev), 0.0).cpu().numpy(), img)
 
