@@ -13,6 +13,75 @@ void set_error(const char* fmt, ...)
     va_end(ap);
 }
 
+// ---- scratch allocator (see common.hpp) -------------------------------------------------------------------------
+namespace {
+struct ScratchBlock {
+    void* p;
+    size_t cap;
+    int device;
+    hipStream_t last_stream;
+    hipEvent_t ev;       // recorded on last_stream at release
+    bool busy;
+};
+std::mutex g_scratch_mu;
+std::vector<ScratchBlock> g_scratch;   // a few dozen blocks at most: linear search
+}  // namespace
+
+void* scratch_acquire(size_t bytes, hipStream_t stream)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    const size_t want = (bytes + 255) & ~(size_t)255;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        int best = -1;
+        for (int i = 0; i < (int)g_scratch.size(); ++i) {
+            ScratchBlock& b = g_scratch[i];
+            if (b.busy || b.device != dev || b.cap < want || b.cap > 4 * want + (1 << 20)) continue;
+            // same stream: stream order protects the previous user's work; other stream: only once that work is done
+            if (b.last_stream != stream && hipEventQuery(b.ev) != hipSuccess) continue;
+            if (best < 0 || b.cap < g_scratch[best].cap) best = i;
+        }
+        if (best >= 0) {
+            g_scratch[best].busy = true;
+            return g_scratch[best].p;
+        }
+    }
+    ScratchBlock nb{nullptr, want, dev, stream, nullptr, true};
+    if (hipMalloc(&nb.p, want) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&nb.ev, hipEventDisableTiming) != hipSuccess) { (void)hipFree(nb.p); return nullptr; }
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    g_scratch.push_back(nb);
+    return nb.p;
+}
+
+void scratch_release(void* p, hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    for (ScratchBlock& b : g_scratch)
+        if (b.p == p) {
+            b.last_stream = stream;
+            (void)hipEventRecord(b.ev, stream);
+            b.busy = false;
+            break;
+        }
+    // keep the cache bounded: beyond 8 GiB of idle blocks, give finished ones back
+    size_t idle = 0;
+    for (const ScratchBlock& b : g_scratch) idle += b.busy ? 0 : b.cap;
+    if (idle > ((size_t)8 << 30)) {
+        for (size_t i = 0; i < g_scratch.size();) {
+            ScratchBlock& b = g_scratch[i];
+            if (!b.busy && b.p != p && hipEventQuery(b.ev) == hipSuccess) {
+                (void)hipFree(b.p);
+                (void)hipEventDestroy(b.ev);
+                g_scratch.erase(g_scratch.begin() + i);
+            } else {
+                ++i;
+            }
+        }
+    }
+}
+
 }  // namespace mrs
 
 extern "C" {

@@ -36,16 +36,28 @@ void set_error(const char* fmt, ...);
         }                                                          \
     } while (0)
 
-// Stream-ordered scratch buffer (hipMallocAsync): re-entrant, no hidden global state.
+// Scratch buffer of one call, handed out by a small caching allocator of this library (capi.hip): blocks are
+// hipMalloc'ed once and recycled.  A released block carries an event recorded on the stream that used it; it is handed
+// out again to the SAME stream at once (stream order makes that safe) and to another stream only after the event has
+// completed.  Not hipMallocAsync: with a second process active on the same GPU, small stream-ordered-pool allocations
+// were observed to come back overlapping (the memset of one scratch buffer zeroed its neighbour: 6-7 of 30 runs of the
+// adapter test under a GPU-holding parent process; 0 of 40 with plain allocations), silently corrupting results.
+void* scratch_acquire(size_t bytes, hipStream_t stream);
+void scratch_release(void* p, hipStream_t stream);
+
 struct Scratch {
     void* p = nullptr;
     hipStream_t s = nullptr;
     ~Scratch() {
-        if (p) (void)hipFreeAsync(p, s);
+        if (p) scratch_release(p, s);
     }
     int alloc(size_t bytes, hipStream_t stream) {
         s = stream;
-        MRS_HIP_TRY(hipMallocAsync(&p, bytes ? bytes : 16, stream));
+        p = scratch_acquire(bytes ? bytes : 16, stream);
+        if (!p) {
+            set_error("scratch allocation of %zu bytes failed: %s", bytes, hipGetErrorString(hipGetLastError()));
+            return MRS_ERR_HIP;
+        }
         return MRS_OK;
     }
     template <class T>

@@ -1941,7 +1941,9 @@ int mrs_gicp_batch_fitness(mrs_gicp_batch* h, const double* h_poses, double max_
     if (st != MRS_OK) return st;
     st = part.alloc((size_t)h->n_pairs * h->max_blocks * 2 * sizeof(double), s);
     if (st != MRS_OK) return st;
-    MRS_HIP_TRY(hipMemcpyAsync(poses.p, h_poses, (size_t)h->n_pairs * 16 * sizeof(double), hipMemcpyHostToDevice, s));
+    // pageable host memory: a blocking copy (hipMemcpyAsync from a caller's stack array may be deferred past the launch)
+    MRS_HIP_TRY(hipStreamSynchronize(s));
+    MRS_HIP_TRY(hipMemcpy(poses.p, h_poses, (size_t)h->n_pairs * 16 * sizeof(double), hipMemcpyHostToDevice));
     MRS_HIP_TRY(hipMemsetAsync(part.p, 0, (size_t)h->n_pairs * h->max_blocks * 2 * sizeof(double), s));
     hipLaunchKernelGGL(k_fitness, dim3(h->max_blocks, h->n_pairs), dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0],
                        h->d_pts[1], h->d_offs[1], h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], poses.as<double>(), max_range,

@@ -112,6 +112,10 @@ int main()
         const bool ok = !rejected && std::fabs(finalResult(0, 3) - tx) < tol_t && std::fabs(finalResult(1, 3) - ty) < tol_t &&
                         std::fabs(std::atan2(finalResult(1, 0), finalResult(0, 0)) - yaw) < tol_r &&
                         std::fabs(gpu_fit - host_fit) < 1e-6 + 1e-4 * host_fit && unused_result->points.size() == queryKeyframe->points.size();
+        if (!ok)
+            std::printf("  FAILED %s: rejected=%d dtx=%.2e dty=%.2e dyaw=%.2e |gpu-host|=%.3e aligned=%zu\n", method, (int)rejected,
+                        std::fabs(finalResult(0, 3) - tx), std::fabs(finalResult(1, 3) - ty),
+                        std::fabs(std::atan2(finalResult(1, 0), finalResult(0, 0)) - yaw), std::fabs(gpu_fit - host_fit), unused_result->points.size());
         all_ok = all_ok && ok;
     }
     return all_ok ? 0 : 1;
