@@ -381,12 +381,19 @@ def main():
     plan = ring.ring_plan(local_rank)
     img = torch.empty((B, 1, 120, 120), dtype=torch.float32, device=device)
     # the rank's exact database entries: Hermitian half spectra [61][120] complex64 (58 560 B) of the normalised
-    # sinograms of every resident scan, slot CH = the entries of the previous step's last launch
-    spec32 = torch.empty((CH + 1, B, 61, 120), dtype=torch.complex64, device=device)
+    # sinograms of every resident scan; slots CH, CH + 1 = the entries of the previous step's last two launches.
+    # The database a launch reads is the one built TWO launches earlier (DEPTH): its exchange then has two launches of
+    # kernels to hide behind.
+    DEPTH = 2
+    assert CH >= DEPTH
+    spec32 = torch.empty((CH + DEPTH, B, 61, 120), dtype=torch.complex64, device=device)
     for c, (xyz, offs) in enumerate(chunks):
         _, _, nrm = ring.ring_descriptors(xyz, offs)
         spec32[c] = ring.half_spectrum(nrm)
-    spec32[CH] = spec32[CH - 1]
+    spec32[CH:] = spec32[CH - DEPTH:CH]
+
+    def db_slot(c):
+        return c - DEPTH if c >= DEPTH else CH + c
     g = torch.Generator(device=device).manual_seed(7 + rank)
     NDB = world * B
     cand_idx = torch.randint(0, NDB, (CH, B), generator=g, device=device, dtype=torch.int32)   # pre-selected candidate rows
@@ -397,10 +404,11 @@ def main():
     # the exact fp32 entry) -- at > 1 M descriptors/s/GPU fp32 spectra would exceed what the xGMI links carry
     gathered = None
     if dist_on:
-        gathered = [torch.empty((NDB, 61, 120, 2), dtype=torch.float16, device=device) for _ in range(2)]
+        gathered = [torch.empty((NDB, 61, 120, 2), dtype=torch.float16, device=device) for _ in range(DEPTH + 1)]
         for gbuf in gathered:
             gbuf.copy_(torch.view_as_real(spec32[CH - 1]).to(torch.float16).repeat(world, 1, 1, 1))
-    pending = {"work": None, "keep": None}
+    pending = []                                       # (work, source tensor) of the exchanges still in flight, oldest first
+    launch_no = [0]
     rescorer = shard.OwnerRescorer(DIST_THRESHOLD, margin=2e-3, slots=64) if dist_on else None
     setup_s = time.perf_counter() - t_setup
 
@@ -411,8 +419,9 @@ def main():
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             return e
-        spec32[CH] = spec32[CH - 1]                    # last launch of the previous step = candidates of this step's first
+        spec32[CH:] = spec32[CH - DEPTH:CH]            # last launches of the previous step = databases of this step's first
         for c, (xyz, offs) in enumerate(chunks):
+            g = launch_no[0]; launch_no[0] += 1
             e0 = mark() if record else None
             bev.cart_bev(xyz, offs, 1, 1, 120, 120, 1, out=img.view(B, -1))
             e1 = mark() if record else None
@@ -420,15 +429,15 @@ def main():
             e2 = mark() if record else None
             if dist_on:
                 ew0 = mark() if record else None
-                if pending["work"] is not None:
-                    pending["work"].wait()             # the compute stream waits for the previous exchange (no host block)
+                while len(pending) >= DEPTH:           # the compute stream waits for the exchange of launch g - DEPTH
+                    pending.pop(0)[0].wait()           # (stream-side wait, the host does not block)
                 ew1 = mark() if record else None
-                db = gathered[(c - 1) & 1]
+                db = gathered[(g - DEPTH) % (DEPTH + 1)]
                 # half spectrum of the new descriptors (kept: database entries; fp16 replica for the other ranks) +
                 # correlation with their candidates out of the replicated database, one launch
                 spec, spec16, _, _ = ring.spectrum_corr_pairs_db(norm, db, cand_idx[c], want_f16=True, out=(out_dist[c], out_ang[c]))
             else:
-                db = spec32[c - 1]                     # c = 0: slot CH
+                db = spec32[db_slot(c)]
                 spec, spec16, _, _ = ring.spectrum_corr_pairs_db(norm, db, cand_idx[c], out=(out_dist[c], out_ang[c]))
             spec32[c] = spec
             e3 = mark() if record else None
@@ -437,16 +446,15 @@ def main():
             sweep_best[c, 1] = idx.float()
             e4 = mark() if record else None
             if dist_on:
-                pending["keep"] = spec16               # keep the source alive until the op completes
-                pending["work"] = dist.all_gather_into_tensor(gathered[c & 1], spec16, async_op=True)
+                pending.append((dist.all_gather_into_tensor(gathered[g % (DEPTH + 1)], spec16, async_op=True), spec16))
             if record:
                 ev["bev"].append((e0, e1)); ev["radon"].append((e1, e2)); ev["corr"].append((e2, e3)); ev["sweep"].append((e3, e4))
                 if dist_on:
                     ev["wait"].append((ew0, ew1))
         if dist_on:
             # exact re-scoring of the candidates whose replica score is within 2e-3 of the acceptance threshold: global row r
-            # of launch c's database = descriptor r % B of rank r // B, built in launch c - 1
-            slot = (torch.arange(CH, device=device) - 1) % (CH + 1)
+            # of launch c's database = descriptor r % B of rank r // B, built in launch c - DEPTH
+            slot = torch.tensor([db_slot(c) for c in range(CH)], device=device)
             flat_rows = (slot[:, None].to(torch.int64) * NDB + cand_idx.to(torch.int64)).reshape(-1)
             e32 = spec32.view(-1, 61, 120)
 
@@ -458,8 +466,8 @@ def main():
 
     def fence():
         if dist_on:
-            if pending["work"] is not None:
-                pending["work"].wait()
+            while pending:
+                pending.pop(0)[0].wait()
             dist.barrier()
         torch.cuda.synchronize()
 
