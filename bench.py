@@ -358,6 +358,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=256, help="scans in the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="only the headline step (+ GICP unless --gicp-pairs 0)")
+    ap.add_argument("--verify-exchange", action="store_true", help="N > 1: re-derive the last launch's replica scores from the exact remote entries")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -365,6 +366,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1 or os.environ.get("MRS_BENCH_FORCE_DIST") == "1"   # the env var exercises the RCCL path on 1 GPU
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
+    # test hook: MRS_BENCH_BACKEND=gloo MRS_BENCH_SHARE_GPU=1 runs the N > 1 control flow with several ranks on ONE GPU
+    # (RCCL refuses two ranks per device; gloo stages the collectives through the host) -- correctness only, not a measurement
+    backend = os.environ.get("MRS_BENCH_BACKEND", "nccl")
+    if os.environ.get("MRS_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     if dist_on:
@@ -373,7 +379,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend)
 
     B, CH = args.batch, args.chunks
     t_setup = time.perf_counter()
@@ -497,6 +506,19 @@ def main():
             gicp_res["iters_per_s"] = world * args.gicp_pairs * args.gicp_iters / float(t.item())
             gicp_res["pairs"] = world * args.gicp_pairs
 
+    verify = None
+    if dist_on and args.verify_exchange:
+        # the last launch scored its new descriptors against fp16 replicas of the descriptors every rank built DEPTH
+        # launches earlier: gather those exact fp32 entries and score the same (query, candidate row) pairs against them
+        fence()
+        c = CH - 1
+        exact_db = shard.allgather_ragged(torch.view_as_real(spec32[db_slot(c)]).contiguous())
+        exact_db = torch.view_as_complex(exact_db.contiguous())
+        d_ex, a_ex = ring.corr_pairs_fft(spec32[c].contiguous(), exact_db[cand_idx[c].long()].contiguous())
+        err = (d_ex - out_dist[c]).abs()
+        verify = {"checked": int(err.numel()), "max_abs_dist_error": float(err.max()),
+                  "angle_mismatches": int((a_ex != out_ang[c]).sum()), "remote_candidates": int((cand_idx[c] // B != rank).sum())}
+
     topk_cmp = None
     if dist_on:
         # the two database designs of SURVEY.md 8(e) side by side: (a) replicate (all-gather the descriptors, every rank sweeps
@@ -557,7 +579,7 @@ def main():
                                 "inbound_gbs_needed_at_this_rate": per_launch * CH / (1e-3 * line["ms_per_step"]) / 1e9,
                                 "compute_stream_wait_ms_per_launch": kern_ms.get("wait"),
                                 "compute_stream_wait_ms_per_step": kern_ms.get("wait", 0.0) * CH,
-                                "rescore": rescorer.stats, "designs": topk_cmp}
+                                "rescore": rescorer.stats, "designs": topk_cmp, "verify": verify}
         if not args.no_extra_legs:
             # polar BEV (the rasteriser north_star names), DiSCO layout 40 x 120 x 20, same scans
             xyz0, offs0 = chunks[0]

@@ -49,3 +49,26 @@ def test_bench_collective_path_on_one_gpu():
     x = d["exchange"]
     assert x["allgather_bytes_in_per_rank_per_launch"] == 0 and x["compute_stream_wait_ms_per_launch"] >= 0      # world size 1: nothing inbound
     assert x["rescore"]["calls"] == 4 and x["rescore"]["dropped"] >= 0 and x["designs"]["sharded_topk_ms"] > 0
+
+
+def test_bench_two_ranks_share_one_gpu_over_gloo():
+    """The N = 2 control flow on real kernels: two ranks on ONE GPU (RCCL refuses that, so the collectives run over gloo,
+    staged through the host): replicated database, candidates by index out of the other rank's rows, owner re-scoring,
+    the top-k design, max-over-ranks timing, one JSON line from rank 0.  Correctness of the exchange is checked inside:
+    with --verify-exchange every rank recomputes a sample of its replica scores against the exact remote entries."""
+    env = dict(os.environ)
+    env.update({"MRS_BENCH_BACKEND": "gloo", "MRS_BENCH_SHARE_GPU": "1"})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "32",
+           "--chunks", "3", "--gicp-pairs", "2", "--gicp-iters", "4", "--no-extra-legs", "--verify-exchange"]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["pairs_per_rank_per_step"] == 96
+    x = d["exchange"]
+    assert x["allgather_bytes_in_per_rank_per_launch"] == 32 * 29280 and x["rescore"]["calls"] == 3
+    v = x["verify"]
+    assert v["checked"] == 32 and v["remote_candidates"] > 0 and v["max_abs_dist_error"] < 2e-3
+    assert v["angle_mismatches"] <= 3          # fp16 replicas may move the peak of a flat correlation (unrelated scans)
+    assert d["gicp"]["pairs"] == 4
