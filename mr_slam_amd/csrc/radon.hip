@@ -34,7 +34,7 @@ struct mrs_radon_plan {
 
 namespace {
 
-constexpr int kRadonWG = 960;  // 15 waves; 120x120 rays = 15 rays per lane exactly
+constexpr int kRadonWG = 1024; // 16 waves = 4 per SIMD; 120x120 rays = 14 full rounds + one of 64 rays
 constexpr int kPad = 2;
 
 // The geometry of a ray does not depend on the image: it is evaluated once, on the host, when the
