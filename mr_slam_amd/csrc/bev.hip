@@ -983,43 +983,42 @@ int mrs_bev_feat_batch(mrs_ctx* ctx, const float* d_pts, const int64_t* d_offset
 }
 
 // ---- host-buffer forms (reference calling convention) -------------------------------------
+// One scan per call, host arrays in and out: what a rospy callback does.  Latency matters here, so the device buffers come
+// from the library's scratch cache and every caller thread keeps one non-blocking stream for the life of the thread
+// (callbacks of different subscriptions run on different threads and therefore overlap on the GPU).
+static hipStream_t thread_stream()
+{
+    static thread_local hipStream_t s = nullptr;
+    if (!s && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
+    return s;
+}
+
 static int bev_host(mrs_ctx* ctx, const float* h_in, int32_t n, int planes, const mrs_bev_cfg* cfg,
                     float* h_out, size_t out_floats, int which)
 {
     MRS_REQUIRE(ctx && cfg && h_in && h_out, "null pointer");
     MRS_REQUIRE(n >= 0, "n must be >= 0");
     MRS_HIP_TRY(hipSetDevice(ctx->device));
-    hipStream_t s;
-    MRS_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    int st = MRS_OK;
-    float* d_in = nullptr; float* d_out = nullptr; int64_t* d_off = nullptr;
+    hipStream_t s = thread_stream();
+    if (!s) { mrs::set_error("could not create the caller thread's stream"); return MRS_ERR_HIP; }
+    mrs::Scratch in, out, off;
+    int st;
+    if ((st = in.alloc((size_t)(n ? n : 1) * planes * sizeof(float), s)) != MRS_OK) return st;
+    if ((st = out.alloc(out_floats * sizeof(float), s)) != MRS_OK) return st;
+    if ((st = off.alloc(2 * sizeof(int64_t), s)) != MRS_OK) return st;
     const int64_t offs[2] = {0, n};
-    do {
-        if (hipMalloc(&d_in, (size_t)(n ? n : 1) * planes * sizeof(float)) != hipSuccess ||
-            hipMalloc(&d_out, out_floats * sizeof(float)) != hipSuccess ||
-            hipMalloc(&d_off, sizeof(offs)) != hipSuccess) {
-            mrs::set_error("hipMalloc failed in host-buffer BEV"); st = MRS_ERR_HIP; break;
-        }
-        if (hipMemcpyAsync(d_in, h_in, (size_t)n * planes * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess ||
-            hipMemcpyAsync(d_off, offs, sizeof(offs), hipMemcpyHostToDevice, s) != hipSuccess) {
-            mrs::set_error("H2D copy failed"); st = MRS_ERR_HIP; break;
-        }
-        if (which == 0) st = mrs_bev_polar_batch(ctx, d_in, d_off, 1, cfg, MRS_BEV_OUT_REFERENCE, d_out, s);
-        else if (which == 1) st = mrs_bev_cart_batch(ctx, d_in, d_off, 1, cfg, MRS_BEV_OUT_REFERENCE, d_out, s);
-        else st = mrs_bev_feat_batch(ctx, d_in, d_off, 1, cfg, MRS_BEV_OUT_REFERENCE, d_out, s);
-        if (st != MRS_OK) break;
-        if (hipMemcpyAsync(h_out, d_out, out_floats * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess ||
-            hipStreamSynchronize(s) != hipSuccess) {
-            mrs::set_error("D2H copy / synchronise failed: %s", hipGetErrorString(hipGetLastError()));
-            st = MRS_ERR_HIP;
-        }
-    } while (0);
-    (void)hipStreamSynchronize(s);
-    if (d_in) (void)hipFree(d_in);
-    if (d_out) (void)hipFree(d_out);
-    if (d_off) (void)hipFree(d_off);
-    (void)hipStreamDestroy(s);
-    return st;
+    MRS_HIP_TRY(hipMemcpyAsync(in.p, h_in, (size_t)n * planes * sizeof(float), hipMemcpyHostToDevice, s));
+    MRS_HIP_TRY(hipMemcpyAsync(off.p, offs, sizeof(offs), hipMemcpyHostToDevice, s));
+    if (which == 0) st = mrs_bev_polar_batch(ctx, in.as<float>(), off.as<int64_t>(), 1, cfg, MRS_BEV_OUT_REFERENCE, out.as<float>(), s);
+    else if (which == 1) st = mrs_bev_cart_batch(ctx, in.as<float>(), off.as<int64_t>(), 1, cfg, MRS_BEV_OUT_REFERENCE, out.as<float>(), s);
+    else st = mrs_bev_feat_batch(ctx, in.as<float>(), off.as<int64_t>(), 1, cfg, MRS_BEV_OUT_REFERENCE, out.as<float>(), s);
+    if (st != MRS_OK) { (void)hipStreamSynchronize(s); return st; }
+    if (hipMemcpyAsync(h_out, out.p, out_floats * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
+        mrs::set_error("D2H copy / synchronise failed: %s", hipGetErrorString(hipGetLastError()));
+        return MRS_ERR_HIP;
+    }
+    return MRS_OK;
 }
 
 int mrs_bev_polar_host(mrs_ctx* ctx, const float* h_xyz, int32_t n, const mrs_bev_cfg* cfg, float* h_out)

@@ -1471,6 +1471,8 @@ struct mrs_gicp_batch {
     float4* d_tlo[2] = {nullptr, nullptr};     // tile bounding boxes
     float4* d_thi[2] = {nullptr, nullptr};
     int max_tiles[2] = {0, 0};                 // tiles of the largest cloud
+    int64_t cap_points[2] = {0, 0};            // capacity of d_pts / d_cov (points), d_tlo / d_thi (cap_tiles): buffers are kept
+    int cap_tiles[2] = {0, 0};                 // across setInput* calls and only re-allocated when a cloud outgrows them
     bool cov_valid[2] = {false, false};
     LmState* d_state = nullptr;
     double* d_partial = nullptr;
@@ -1504,6 +1506,7 @@ void free_cloud(mrs_gicp_batch* h, int w)
     h->d_offs[w] = nullptr; h->d_pts[w] = nullptr; h->d_cov[w] = nullptr;
     h->d_tile_base[w] = nullptr; h->d_tlo[w] = nullptr; h->d_thi[w] = nullptr; h->d_bbox[w] = nullptr;
     h->cov_valid[w] = false;
+    h->cap_points[w] = 0; h->cap_tiles[w] = 0;
 }
 
 int blocks_for_points(int n) { return (n + kNNThreads * kPts - 1) / (kNNThreads * kPts); }
@@ -1616,7 +1619,6 @@ int mrs_gicp_batch_set_clouds(mrs_gicp_batch* h, int32_t which, const float* d_p
     }
     MRS_HIP_TRY(hipSetDevice(h->ctx->device));
     hipStream_t s = (hipStream_t)stream;
-    free_cloud(h, which);
     const int64_t total = h_offsets[h->n_pairs];
     MRS_REQUIRE(total < (1ll << 31), "more than 2^31 points in one batch");
     MRS_REQUIRE(h->n_pairs < (1 << 21), "too many pairs for the 64-bit sort key");
@@ -1633,21 +1635,30 @@ int mrs_gicp_batch_set_clouds(mrs_gicp_batch* h, int32_t which, const float* d_p
         longest = std::max(longest, n);
     }
     h->max_tiles[which] = longest_tiles;
-    MRS_HIP_TRY(hipMalloc(&h->d_offs[which], (h->n_pairs + 1) * sizeof(int64_t)));
-    MRS_HIP_TRY(hipMalloc(&h->d_pts[which], (size_t)total * sizeof(float4)));
-    MRS_HIP_TRY(hipMalloc(&h->d_cov[which], (size_t)total * 6 * sizeof(double)));
-    MRS_HIP_TRY(hipMalloc(&h->d_tile_base[which], h->n_pairs * sizeof(int)));
-    MRS_HIP_TRY(hipMalloc(&h->d_tlo[which], (size_t)tiles * sizeof(float4)));
-    MRS_HIP_TRY(hipMalloc(&h->d_thi[which], (size_t)tiles * sizeof(float4)));
-    if (which == 0) {
-        if (h->d_corr) (void)hipFree(h->d_corr);
-        h->d_corr = nullptr;
-        MRS_HIP_TRY(hipMalloc(&h->d_corr, (size_t)total * sizeof(int)));
-        if (h->d_seed) (void)hipFree(h->d_seed);
-        h->d_seed = nullptr;
-        MRS_HIP_TRY(hipMalloc(&h->d_seed, (size_t)total * sizeof(int)));
-        h->n_seed = (size_t)total;
+    h->cov_valid[which] = false;
+    // a registration object is fed a new cloud per loop candidate (ICPCheck, global_manager.cpp:2018-2019): keep the device
+    // buffers and only grow them (each hipFree synchronises the device, each hipMalloc costs tens of microseconds)
+    if (total > h->cap_points[which] || tiles > h->cap_tiles[which] || !h->d_offs[which]) {
+        free_cloud(h, which);
+        const int64_t cap = total + total / 8;
+        const int capt = tiles + tiles / 8 + 1;
+        MRS_HIP_TRY(hipMalloc(&h->d_offs[which], (h->n_pairs + 1) * sizeof(int64_t)));
+        MRS_HIP_TRY(hipMalloc(&h->d_pts[which], (size_t)cap * sizeof(float4)));
+        MRS_HIP_TRY(hipMalloc(&h->d_cov[which], (size_t)cap * 6 * sizeof(double)));
+        MRS_HIP_TRY(hipMalloc(&h->d_tile_base[which], h->n_pairs * sizeof(int)));
+        MRS_HIP_TRY(hipMalloc(&h->d_tlo[which], (size_t)capt * sizeof(float4)));
+        MRS_HIP_TRY(hipMalloc(&h->d_thi[which], (size_t)capt * sizeof(float4)));
+        MRS_HIP_TRY(hipMalloc(&h->d_bbox[which], (size_t)h->n_pairs * 6 * sizeof(int)));
+        h->cap_points[which] = cap; h->cap_tiles[which] = capt;
+        if (which == 0) {
+            if (h->d_corr) (void)hipFree(h->d_corr);
+            if (h->d_seed) (void)hipFree(h->d_seed);
+            h->d_corr = nullptr; h->d_seed = nullptr;
+            MRS_HIP_TRY(hipMalloc(&h->d_corr, (size_t)cap * sizeof(int)));
+            MRS_HIP_TRY(hipMalloc(&h->d_seed, (size_t)cap * sizeof(int)));
+        }
     }
+    if (which == 0) h->n_seed = (size_t)total;
     if (h->d_seed) MRS_HIP_TRY(hipMemsetAsync(h->d_seed, 0xff, h->n_seed * sizeof(int), s));  // -1: no warm start across clouds
     MRS_HIP_TRY(hipMemcpyAsync(h->d_offs[which], h_offsets, (h->n_pairs + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
     MRS_HIP_TRY(hipMemcpyAsync(h->d_tile_base[which], tile_base.data(), h->n_pairs * sizeof(int), hipMemcpyHostToDevice, s));
@@ -1655,7 +1666,6 @@ int mrs_gicp_batch_set_clouds(mrs_gicp_batch* h, int32_t which, const float* d_p
     // Morton order: per-cloud bounding box -> 64-bit keys (cloud id | Morton code) -> stable radix sort
     mrs::Scratch keys_in, keys_out, vals_in, vals_out, tmp;
     int st;
-    MRS_HIP_TRY(hipMalloc(&h->d_bbox[which], (size_t)h->n_pairs * 6 * sizeof(int)));
     int* const bbox_p = h->d_bbox[which];
     if ((st = keys_in.alloc((size_t)total * 8, s)) != MRS_OK) return st;
     if ((st = keys_out.alloc((size_t)total * 8, s)) != MRS_OK) return st;
@@ -1673,14 +1683,16 @@ int mrs_gicp_batch_set_clouds(mrs_gicp_batch* h, int32_t which, const float* d_p
                        bbox_p);
     hipLaunchKernelGGL(k_morton_keys, pg, dim3(256), 0, s, d_points, stride_floats, h->d_offs[which], bbox_p,
                        keys_in.as<unsigned long long>(), vals_in.as<int>());
+    int key_bits = 42;                       // 42-bit Morton code + the bits of the cloud id: fewer radix passes than 64
+    while ((1ll << (key_bits - 42)) < h->n_pairs) ++key_bits;
     size_t tmp_bytes = 0;
     MRS_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in.as<unsigned long long>(),
                                                    keys_out.as<unsigned long long>(), vals_in.as<int>(), vals_out.as<int>(),
-                                                   (int)total, 0, 64, s));
+                                                   (int)total, 0, key_bits, s));
     if ((st = tmp.alloc(tmp_bytes, s)) != MRS_OK) return st;
     MRS_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, keys_in.as<unsigned long long>(),
                                                    keys_out.as<unsigned long long>(), vals_in.as<int>(), vals_out.as<int>(),
-                                                   (int)total, 0, 64, s));
+                                                   (int)total, 0, key_bits, s));
     hipLaunchKernelGGL(k_gather_sorted, pg, dim3(256), 0, s, d_points, stride_floats, h->d_offs[which], vals_out.as<int>(),
                        h->d_pts[which]);
     hipLaunchKernelGGL(k_tile_boxes, dim3(longest_tiles, h->n_pairs), dim3(256), 0, s, h->d_pts[which], h->d_offs[which],
