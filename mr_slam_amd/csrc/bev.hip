@@ -357,9 +357,10 @@ __global__ __launch_bounds__(kWG) void k_polar_lds(const float* __restrict__ xyz
     // eps away from a bin edge (fp32 fast path == the reference's double path there); everything else
     // (rare) re-evaluates exactly through polar_lin().
     const float fR = (float)p.R, hmax = (float)(2 * p.H + 16);
+    const float hi_ring = 1.0f - p.eps_ring, hi_sector = 1.0f - p.eps_sector, hi_height = 1.0f - p.eps_height;
     auto put = [&](float x, float y, float z) {
+        // quotients g >= 0 on the fast path: bin = (int)g (truncation == floor), distance to a bin edge from v_fract
         const float gr = __builtin_amdgcn_sqrtf(__builtin_fmaf(x, x, y * y)) * p.inv_ring;
-        const float fr = floorf(gr);
         const float ax = fabsf(x), ay = fabsf(y);
         const bool steep = ay > ax;
         const float t = (steep ? ax : ay) * __builtin_amdgcn_rcpf(steep ? ay : ax);
@@ -369,20 +370,21 @@ __global__ __launch_bounds__(kWG) void k_polar_lds(const float* __restrict__ xyz
         const float base = xn ? 180.0f : (yn ? 360.0f : 0.0f);
         const float theta = (xn != yn) ? base - a : base + a;
         const float gs = theta * p.inv_sector;
-        const float fs = floorf(gs);
         const float sh = z + p.mh;
         float gh = sh * p.inv_height;
-        float fh = floorf(gh);
         // height edge (ground returns sit right on the z = 0 bin edge after the reference's z > 0 crop): the
         // reference quotient is a plain fp32 division -> redo just that, IEEE-rounded, instead of leaving the fast path
-        if (0.5f - fabsf((gh - fh) - 0.5f) < p.eps_height) {
-            gh = sh / p.gap_height;
-            fh = floorf(gh);
+        {
+            const float fh0 = __builtin_amdgcn_fractf(gh);
+            if (!(fh0 >= p.eps_height) | !(fh0 <= hi_height)) gh = sh / p.gap_height;
         }
-        const float er = gr >= fR + 1.0f ? 1.0f : 0.5f - fabsf((gr - fr) - 0.5f);
-        const float es = 0.5f - fabsf((gs - fs) - 0.5f);
-        const bool fast = (bool)((int)(x * y * z != 0.0f) & (int)(fminf(er - p.eps_ring, es - p.eps_sector) >= 0.0f) &
-                                 (int)(gr < 5.0e8f) & (int)(fabsf(gh) < hmax));
+        const float frr = __builtin_amdgcn_fractf(gr), frs = __builtin_amdgcn_fractf(gs);
+        // every comparison is false for NaN; gr >= R + 1 clamps to the last ring whatever its fraction
+        const bool ring_ok = (gr >= fR + 1.0f) | ((frr >= p.eps_ring) & (frr <= hi_ring));
+        const bool sect_ok = (frs >= p.eps_sector) & (frs <= hi_sector);
+        const bool fast = (bool)((int)(x * y * z != 0.0f) & (int)ring_ok & (int)sect_ok & (int)(gr < 5.0e8f) & (int)(gh >= 0.0f) &
+                                 (int)(gh < hmax));
+        const float fr = gr, fs = gs, fh = gh;   // (int) of these below
         int lin;
         if (fast) {
             const int kr = gr >= fR ? p.R - 1 : (int)fr;
