@@ -51,3 +51,39 @@ def test_adapter_is_stable_next_to_another_gpu_process():
         if r.returncode != 0:
             bad.append((i, r.stdout[-300:] + r.stderr[-300:]))
     assert not bad, bad
+
+
+# ---- libgpu.so: the elevation_mapping boundary (row N3) ----------------------------------------------------------------
+ELEV_SO = os.path.join(ROOT, "bindings", "elevation", "_built", "libgpu.so")
+ELEV_OUT = os.path.join(ROOT, "tests", "cpp", "build", "elev_test")
+
+
+def _compile_elev():
+    lib_dir = os.path.join(ROOT, "mr_slam_amd")
+    if not os.path.exists(os.path.join(lib_dir, "libmrslam_hip.so")) or not os.path.exists(ELEV_SO):
+        import __graft_entry__
+        __graft_entry__.build()
+    os.makedirs(os.path.dirname(ELEV_OUT), exist_ok=True)
+    so_dir = os.path.dirname(ELEV_SO)
+    cmd = ["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "elev_main.cpp"),
+           "-o", ELEV_OUT, "-L" + so_dir, "-lgpu", "-L" + lib_dir, "-lmrslam_hip", "-Wl,-rpath," + so_dir, "-Wl,-rpath," + lib_dir]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_libgpu_shim_exports_the_symbols_the_mapping_node_links():
+    """The ten C++-linkage functions of the reference's libgpu.so, with its exact parameter lists (incl. Eigen::Matrix
+    template arguments): same mangled names as cuda/gpu_process.cu:938-1312 compiled by nvcc."""
+    _compile_elev()
+    out = subprocess.run(["nm", "-D", "--defined-only", ELEV_SO], capture_output=True, text=True).stdout
+    for sym in ("_Z21Init_GPU_elevationmapifff", "_Z4MovePffiS_PiS_", "_Z13Map_closeloopPffif", "_Z10Raytracingi",
+                "_Z4FuseiiPiS_S_S_PfS0_S0_", "_Z11Map_featureiPfS_PiS0_S0_S_S_S_S_", "_Z11Map_optmovePfffiS_", "_Z13Mapvar_updateif",
+                "_Z14Process_pointsPiPfS0_S0_S0_S0_S0_S0_N5Eigen6MatrixIfLi4ELi4ELi0ELi4ELi4EEEiddfffNS2_IfLi1ELi3ELi1ELi1ELi3EEENS2_IfLi3ELi3ELi0ELi3ELi3EEES5_S4_S5_"):
+        assert sym in out, sym
+
+
+@pytest.mark.gpu
+def test_libgpu_shim_equals_the_c_abi():
+    _compile_elev()
+    r = subprocess.run([ELEV_OUT], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "libgpu.so == C ABI: yes" in r.stdout, r.stdout + r.stderr
