@@ -988,10 +988,14 @@ int mrs_bev_feat_batch(mrs_ctx* ctx, const float* d_pts, const int64_t* d_offset
 // One scan per call, host arrays in and out: what a rospy callback does.  Latency matters here, so the device buffers come
 // from the library's scratch cache and every caller thread keeps one non-blocking stream for the life of the thread
 // (callbacks of different subscriptions run on different threads and therefore overlap on the GPU).
-static hipStream_t thread_stream()
+static hipStream_t thread_stream(int device)   // the calling thread's stream on `device` (current device already set)
 {
-    static thread_local hipStream_t s = nullptr;
-    if (!s && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
+    static thread_local std::map<int, hipStream_t> streams;
+    auto it = streams.find(device);
+    if (it != streams.end()) return it->second;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    streams[device] = s;
     return s;
 }
 
@@ -1001,7 +1005,7 @@ static int bev_host(mrs_ctx* ctx, const float* h_in, int32_t n, int planes, cons
     MRS_REQUIRE(ctx && cfg && h_in && h_out, "null pointer");
     MRS_REQUIRE(n >= 0, "n must be >= 0");
     MRS_HIP_TRY(hipSetDevice(ctx->device));
-    hipStream_t s = thread_stream();
+    hipStream_t s = thread_stream(ctx->device);
     if (!s) { mrs::set_error("could not create the caller thread's stream"); return MRS_ERR_HIP; }
     mrs::Scratch in, out, off;
     int st;
