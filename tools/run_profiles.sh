@@ -8,8 +8,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_valu $OUT/pmc_lds
-# order matters: the plain bench run and the kernel trace come first -- after the --pmc passes the device stays in the
-# profiling power state for the rest of the session (small latency-bound kernels then take about twice as long)
+# the plain bench run and the kernel trace come first, the counter passes last
 (cd $R && python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $R/tools/pmc_targets.py > $OUT/pmc_fetch.log 2>&1
