@@ -408,7 +408,8 @@ def main():
     cand_idx = torch.randint(0, NDB, (CH, B), generator=g, device=device, dtype=torch.int32)   # pre-selected candidate rows
     out_dist = torch.empty((CH, B), dtype=torch.float32, device=device)
     out_ang = torch.empty((CH, B), dtype=torch.int32, device=device)
-    sweep_best = torch.empty((CH, 2), dtype=torch.float32, device=device)
+    sweep_val = torch.empty(CH, dtype=torch.float32, device=device)    # best distance / database row of the per-launch sweep
+    sweep_row = torch.empty(CH, dtype=torch.int64, device=device)
     # N > 1: the replicated database of the previous launch's descriptors (fp16 replicas, 29 280 B each; the owner keeps
     # the exact fp32 entry) -- at > 1 M descriptors/s/GPU fp32 spectra would exceed what the xGMI links carry
     gathered = None
@@ -444,15 +445,14 @@ def main():
                 db = gathered[(g - DEPTH) % (DEPTH + 1)]
                 # half spectrum of the new descriptors (kept: database entries; fp16 replica for the other ranks) +
                 # correlation with their candidates out of the replicated database, one launch
-                spec, spec16, _, _ = ring.spectrum_corr_pairs_db(norm, db, cand_idx[c], want_f16=True, out=(out_dist[c], out_ang[c]))
+                spec, spec16, _, _ = ring.spectrum_corr_pairs_db(norm, db, cand_idx[c], want_f16=True, out=(out_dist[c], out_ang[c]),
+                                                                 spec_out=spec32[c])
             else:
                 db = spec32[db_slot(c)]
-                spec, spec16, _, _ = ring.spectrum_corr_pairs_db(norm, db, cand_idx[c], out=(out_dist[c], out_ang[c]))
-            spec32[c] = spec
+                spec, spec16, _, _ = ring.spectrum_corr_pairs_db(norm, db, cand_idx[c], out=(out_dist[c], out_ang[c]), spec_out=spec32[c])
             e3 = mark() if record else None
             d, a = ring.corr_sweep_fft(spec[:1], db)   # one new query against the whole (replicated) database
-            sweep_best[c, 0], idx = torch.min(d[0], 0)
-            sweep_best[c, 1] = idx.float()
+            torch.min(d, 1, out=(sweep_val[c:c + 1], sweep_row[c:c + 1]))
             e4 = mark() if record else None
             if dist_on:
                 pending.append((dist.all_gather_into_tensor(gathered[g % (DEPTH + 1)], spec16, async_op=True), spec16))

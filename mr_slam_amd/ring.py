@@ -339,16 +339,21 @@ def spectrum_corr_pairs(norm, cand_spec, want_f32=True, want_f16=False, out=None
     return (torch.view_as_complex(spec) if want_f32 else None), spec16, dist, ang
 
 
-def spectrum_corr_pairs_db(norm, db_spec, cand_index, want_f32=True, want_f16=False, out=None):
+def spectrum_corr_pairs_db(norm, db_spec, cand_index, want_f32=True, want_f16=False, out=None, spec_out=None):
     """spectrum_corr_pairs with the candidate of pair i = row cand_index[i] (int32 device tensor) of a database of half
-    spectra: complex64 [N,61,120] or the fp16 replica format [N,61,120,2] float16."""
+    spectra: complex64 [N,61,120] or the fp16 replica format [N,61,120,2] float16.  spec_out (optional): complex64
+    [P,61,120] tensor that receives the new half spectra (e.g. the database slot they belong to)."""
     d = _dev(norm)
     x, db, idx = norm.contiguous(), db_spec.contiguous(), cand_index.contiguous()
     P = x.shape[0]
     assert x.shape[-2:] == (120, 120) and idx.dtype == torch.int32 and idx.numel() == P
     f16 = db.dtype == torch.float16
     assert (f16 and db.shape[1:] == (61, 120, 2)) or (db.dtype == torch.complex64 and db.shape[1:] == (61, 120))
-    spec = torch.empty((P, 61, 120, 2), dtype=torch.float32, device=x.device) if want_f32 else None
+    if spec_out is not None:
+        assert spec_out.dtype == torch.complex64 and spec_out.shape == (P, 61, 120) and spec_out.is_contiguous()
+        spec, want_f32 = torch.view_as_real(spec_out), True
+    else:
+        spec = torch.empty((P, 61, 120, 2), dtype=torch.float32, device=x.device) if want_f32 else None
     spec16 = torch.empty((P, 61, 120, 2), dtype=torch.float16, device=x.device) if want_f16 else None
     dist, ang = out if out is not None else (torch.empty(P, dtype=torch.float32, device=x.device),
                                              torch.empty(P, dtype=torch.int32, device=x.device))
