@@ -11,13 +11,23 @@ import os
 import re
 import sys
 
+
+def newest(paths):
+    """gpurun merges every call's files into gpurun_out/: keep the most recent run of each directory"""
+    by_dir = {}
+    for f in paths:
+        d = os.path.dirname(f)
+        if d not in by_dir or os.path.getmtime(f) > os.path.getmtime(by_dir[d]):
+            by_dir[d] = f
+    return sorted(by_dir.values())
+
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
 KEYS = {"k_cart_lds": "k_cart_lds", "k_polar_lds": "k_polar_lds", "k_radon2": "k_radon2", "k_ring_spec_corr_pairs": "k_ring_spec_corr_pairs",
         "k_ring_corr_fft": "k_ring_corr_fft", "k_linearize": "k_linearize", "k_nn_scan": "k_nn_scan", "k_knn_cov": "k_knn_cov"}
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
+for f in newest(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))):
     for r in csv.DictReader(open(f)):
         m = re.search(r"(k_[a-z_0-9]+)", r["Kernel_Name"])
         if not m or m.group(1) not in KEYS:

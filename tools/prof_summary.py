@@ -10,6 +10,16 @@ import os
 import re
 import sys
 
+
+def newest(paths):
+    """gpurun merges every call's files into gpurun_out/: keep the most recent run of each directory"""
+    by_dir = {}
+    for f in paths:
+        d = os.path.dirname(f)
+        if d not in by_dir or os.path.getmtime(f) > os.path.getmtime(by_dir[d]):
+            by_dir[d] = f
+    return sorted(by_dir.values())
+
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
@@ -23,7 +33,7 @@ def short(name):
 
 
 rows = []
-for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
+for f in newest(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))):
     for r in csv.DictReader(open(f)):
         rows.append((short(r["Name"]), int(r["Calls"]), float(r["TotalDurationNs"]), float(r["AverageNs"]),
                      float(r["MinNs"]), float(r["MaxNs"]), float(r["Percentage"])))
@@ -35,7 +45,7 @@ with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as o:
 
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 for sub in ("pmc_fetch", "pmc_write"):
-    for f in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
+    for f in newest(glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))):
         for r in csv.DictReader(open(f)):
             if "k_" in r["Kernel_Name"]:
                 pmc[(short(r["Kernel_Name"]), int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
