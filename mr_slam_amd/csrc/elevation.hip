@@ -10,8 +10,8 @@
 //     result, O(N log N);
 //   * the racy `map_lowest` update of G_pointsprocess is given its sequential-in-input-order reading with
 //     the same bucketing (see oracle/elev_oracle.cpp header);
-//   * state lives in a handle instead of __device__ globals, no cudaMalloc/cudaFree per call beyond the
-//     stream-ordered scratch, every call returns a status.
+//   * state lives in a handle instead of __device__ globals, per-call buffers come from the library's scratch cache
+//     (capi.hip) instead of cudaMalloc/cudaFree per call, every call returns a status.
 #include <hipcub/hipcub.hpp>
 
 #include <cmath>

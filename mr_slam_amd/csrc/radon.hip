@@ -12,8 +12,9 @@
 // every workgroup streams from L2.  Samples are aligned exactly to texel centres along the ray's
 // dominant axis (integer stepping, always towards increasing index), 2-tap fp32 interpolation along
 // the minor axis: 7 VALU + one ds_read2_b32 per sample, the two taps accumulated by one packed FMA.
-// HBM traffic is 4*H*W in + 4*A*D out per image; the kernel is bound by VALU issue (83 % busy) and the
-// LDS array (79 % busy, 42 % of it bank conflicts: adjacent rays are 1-1.41 texels apart), not by HBM.
+// HBM traffic is 4*H*W in + 4*A*D out per image; the kernels are bound by VALU issue and the LDS array, not by HBM.
+// Batches run two images per workgroup (k_radon2 / march2 below: the two images share the per-sample index chain;
+// VALU issue 76 %, LDS array 65 % busy of which 41 % bank conflicts: adjacent rays are 1-1.41 texels apart).
 // Numerics are shared with oracle/radon_oracle.c op for op (cos/sin evaluated on the host in
 // double when the plan is built), so HIP == oracle bit for bit.
 #include <algorithm>
