@@ -596,6 +596,15 @@ def main():
                                       "valu_issue_frac": r.get("valu_issue_frac"), "lds_busy_frac": r.get("lds_busy_frac"),
                                       "lds_bank_conflict_frac_of_lds": r.get("lds_bank_conflict_frac"),
                                       "hbm_bytes": r.get("hbm_bytes"), "source": "profiles/r02_pmc.json" if r else None}
+            # the same box's device-to-device copy rate next to the nominal peak (a copy moves 2 bytes per byte copied)
+            src_buf = chunks[0][0]
+            dst_buf = torch.empty_like(src_buf)
+            ms = ev_ms(lambda: dst_buf.copy_(src_buf), reps=5, warm=2)
+            copy_gbs = 2 * src_buf.numel() * 4 / ms / 1e6
+            del dst_buf
+            line["roofline"]["measured_copy_gbs"] = copy_gbs
+            line["roofline"]["frac_of_measured_copy"] = achieved / copy_gbs
+            line["roofline_polar"]["frac_of_measured_copy"] = line["roofline_polar"]["achieved"] / copy_gbs
             line["sweeps"] = sweep_legs(device, spec32[:CH].reshape(-1, 61, 120))
             line["pipeline_shard"] = pipeline_shard_leg(device, spec32[:CH].reshape(-1, 61, 120), gicp_res)
             line["dropin_latency"] = dropin_latency_leg(host_scans(chunks[0][0], 1)[0])
