@@ -371,8 +371,9 @@ int mrs_ring_spectrum_corr_pairs(mrs_ctx* ctx, const float* d_norm_sino, const f
 /* Same launch with the candidates picked out of a database: candidate of pair i = row d_cand_index[i] of d_db_spec,
  * a [n_db][61][120] array of complex64 half spectra (db_is_f16 = 0) or of their fp16 replicas (db_is_f16 = 1:
  * IEEE binary16 pairs, the multi-GPU exchange format; arithmetic stays fp32).  This is the per-query step after a
- * candidate pre-selection over the replicated database (RING_ros/main_RING.py:133-140 scores every candidate). */
-int mrs_ring_spectrum_corr_pairs_db(mrs_ctx* ctx, const float* d_norm_sino, const void* d_db_spec, int32_t db_is_f16,
+ * candidate pre-selection over the replicated database (RING_ros/main_RING.py:133-140 scores every candidate).
+ * An index outside [0, n_db) means "no candidate": dist = +inf, angle = 0 (the new spectrum is still written). */
+int mrs_ring_spectrum_corr_pairs_db(mrs_ctx* ctx, const float* d_norm_sino, const void* d_db_spec, int32_t db_is_f16, int32_t n_db,
                                     const int32_t* d_cand_index, int32_t n_pairs, int32_t n_angles, int32_t det, float* d_half_spec,
                                     void* d_half_spec_f16, float* d_dist, int32_t* d_angle, mrs_stream stream);
 

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(NSLOT* kSlotThreads) void k_ring_corr_fft(const flo
 // the candidate of pair i is row cand_idx[i] of `cand` (a pre-selected row of the replicated database) instead of row i.
 template <typename CT>
 __global__ __launch_bounds__(kSlotThreads) void k_ring_spec_corr_pairs(const float* __restrict__ x, const CT* __restrict__ cand,
-                                                                       const int* __restrict__ cand_idx,
+                                                                       const int* __restrict__ cand_idx, int n_db,
                                                                        float2* __restrict__ out, __half2* __restrict__ out16,
                                                                        float denom, float* __restrict__ dist,
                                                                        int* __restrict__ angle)
@@ -292,7 +292,12 @@ __global__ __launch_bounds__(kSlotThreads) void k_ring_spec_corr_pairs(const flo
     }
     __syncthreads();
     float re[60], im[60];
-    const CT* b = cand + (size_t)(cand_idx ? cand_idx[pair] : pair) * kHalf * kD + d;
+    const int row = cand_idx ? cand_idx[pair] : pair;
+    if (cand_idx && (row < 0 || row >= n_db)) {   // no such database row: the new spectrum is still written, the score says "no match"
+        if (t == 0) { dist[pair] = INFINITY; angle[pair] = 0; }
+        return;
+    }
+    const CT* b = cand + (size_t)row * kHalf * kD + d;
     corr_irfft120([&](int k, float& ar, float& ai, float& br, float& bi) {
         const float2 bv = load_spec(b + k * kD);
         const float2 av = qs[k * kD + d];
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(kSlotThreads) void k_ring_spec_corr_pairs(const flo
 
 template <typename CT>
 static int spectrum_corr_pairs_launch(mrs_ctx* ctx, const float* d_norm_sino, const CT* cand, const int32_t* d_cand_index,
-                                      int32_t n_pairs, int32_t n_angles, int32_t det, float* d_half_spec, void* d_half_spec_f16,
+                                      int32_t n_db, int32_t n_pairs, int32_t n_angles, int32_t det, float* d_half_spec, void* d_half_spec_f16,
                                       float* d_dist, int32_t* d_angle, mrs_stream stream)
 {
     MRS_REQUIRE(ctx && d_norm_sino && cand && d_dist && d_angle, "null pointer");
@@ -343,7 +348,7 @@ static int spectrum_corr_pairs_launch(mrs_ctx* ctx, const float* d_norm_sino, co
     MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring_spec_corr_pairs<CT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
     hipLaunchKernelGGL(k_ring_spec_corr_pairs<CT>, dim3(n_pairs), dim3(kSlotThreads), lds, (hipStream_t)stream, d_norm_sino, cand,
-                       d_cand_index, reinterpret_cast<float2*>(d_half_spec), reinterpret_cast<__half2*>(d_half_spec_f16),
+                       d_cand_index, n_db, reinterpret_cast<float2*>(d_half_spec), reinterpret_cast<__half2*>(d_half_spec_f16),
                        (float)(0.15 * kA * kD), d_dist, d_angle);
     MRS_HIP_TRY(hipGetLastError());
     return MRS_OK;
@@ -469,19 +474,20 @@ int mrs_ring_spectrum_corr_pairs(mrs_ctx* ctx, const float* d_norm_sino, const f
                                  int32_t n_angles, int32_t det, float* d_half_spec, void* d_half_spec_f16, float* d_dist,
                                  int32_t* d_angle, mrs_stream stream)
 {
-    return spectrum_corr_pairs_launch<float2>(ctx, d_norm_sino, reinterpret_cast<const float2*>(d_cand_spec), nullptr, n_pairs, n_angles,
+    return spectrum_corr_pairs_launch<float2>(ctx, d_norm_sino, reinterpret_cast<const float2*>(d_cand_spec), nullptr, n_pairs, n_pairs, n_angles,
                                               det, d_half_spec, d_half_spec_f16, d_dist, d_angle, stream);
 }
 
-int mrs_ring_spectrum_corr_pairs_db(mrs_ctx* ctx, const float* d_norm_sino, const void* d_db_spec, int32_t db_is_f16,
+int mrs_ring_spectrum_corr_pairs_db(mrs_ctx* ctx, const float* d_norm_sino, const void* d_db_spec, int32_t db_is_f16, int32_t n_db,
                                     const int32_t* d_cand_index, int32_t n_pairs, int32_t n_angles, int32_t det, float* d_half_spec,
                                     void* d_half_spec_f16, float* d_dist, int32_t* d_angle, mrs_stream stream)
 {
     MRS_REQUIRE(d_cand_index, "null candidate index");
+    MRS_REQUIRE(n_db > 0, "n_db must be positive");
     return db_is_f16 ? spectrum_corr_pairs_launch<__half2>(ctx, d_norm_sino, reinterpret_cast<const __half2*>(d_db_spec), d_cand_index,
-                                                          n_pairs, n_angles, det, d_half_spec, d_half_spec_f16, d_dist, d_angle, stream)
+                                                          n_db, n_pairs, n_angles, det, d_half_spec, d_half_spec_f16, d_dist, d_angle, stream)
                      : spectrum_corr_pairs_launch<float2>(ctx, d_norm_sino, reinterpret_cast<const float2*>(d_db_spec), d_cand_index,
-                                                          n_pairs, n_angles, det, d_half_spec, d_half_spec_f16, d_dist, d_angle, stream);
+                                                          n_db, n_pairs, n_angles, det, d_half_spec, d_half_spec_f16, d_dist, d_angle, stream);
 }
 
 }  // extern "C"

@@ -358,7 +358,7 @@ def spectrum_corr_pairs_db(norm, db_spec, cand_index, want_f32=True, want_f16=Fa
     dist, ang = out if out is not None else (torch.empty(P, dtype=torch.float32, device=x.device),
                                              torch.empty(P, dtype=torch.int32, device=x.device))
     _lib.check(_lib.load().mrs_ring_spectrum_corr_pairs_db(_lib.ctx(d), _lib.ptr(x), _lib.ptr(db if f16 else torch.view_as_real(db)),
-                                                           int(f16), _lib.ptr(idx), P, 120, 120,
+                                                           int(f16), int(db.shape[0]), _lib.ptr(idx), P, 120, 120,
                                                            _lib.ptr(spec) if want_f32 else None, _lib.ptr(spec16) if want_f16 else None,
                                                            _lib.ptr(dist), _lib.ptr(ang), _lib.current_stream(d)))
     return (torch.view_as_complex(spec) if want_f32 else None), spec16, dist, ang

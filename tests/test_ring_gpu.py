@@ -432,3 +432,27 @@ def test_two_images_per_workgroup_equal_one_image_per_workgroup(dev, oracle):
         assert torch.equal(singles[i][0][0], s7[i]) and torch.equal(singles[i][1][0], n7[i])
     s6, n6 = plan.forward(t[:6], raw=True, normalized=True)
     assert torch.equal(s6, s7[:6]) and torch.equal(n6, n7[:6])
+
+
+def test_spectrum_corr_pairs_db_indexes_the_database_and_flags_missing_rows(dev):
+    """Candidates picked by row out of a database (exact entries or fp16 replicas) == the pairwise kernel on the gathered
+    rows, bit for bit (fp32 DB) / within the replica bound (fp16 DB); an index outside the database reports no match."""
+    import torch
+    from mr_slam_amd import ring
+    rng = np.random.default_rng(11)
+    imgs = torch.from_numpy((rng.random((40, 120, 120)) * (rng.random((40, 120, 120)) < 0.3)).astype(np.float32)).to(dev)
+    _, norm = ring.ring_plan(0).forward(imgs, raw=False, normalized=True)
+    db = ring.half_spectrum(norm[:32])
+    q = norm[32:]
+    idx = torch.tensor([5, 31, 0, 17, 17, 2, 99, -1], dtype=torch.int32, device=dev)
+    slot = torch.zeros((8, 61, 120), dtype=torch.complex64, device=dev)
+    spec, _, d, a = ring.spectrum_corr_pairs_db(q, db, idx, spec_out=slot)
+    assert spec.data_ptr() == slot.data_ptr() and torch.equal(slot, ring.half_spectrum(q))
+    ok = torch.tensor([True] * 6 + [False] * 2, device=dev)
+    wd, wa = ring.corr_pairs_fft(ring.half_spectrum(q)[ok], db[idx[ok].long()])
+    assert torch.equal(d[ok], wd) and torch.equal(a[ok], wa)
+    assert torch.isinf(d[~ok]).all() and (a[~ok] == 0).all()
+    db16 = torch.view_as_real(db).to(torch.float16)
+    _, s16, d16, a16 = ring.spectrum_corr_pairs_db(q, db16, idx, want_f16=True)
+    assert (d16[ok] - wd).abs().max() < 2e-3 and torch.isinf(d16[~ok]).all()
+    assert torch.equal(s16, torch.view_as_real(ring.half_spectrum(q)).to(torch.float16))
