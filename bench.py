@@ -560,6 +560,7 @@ def main():
                                    "120x120 -> normalise -> half spectrum -> FFT-domain rotation correlation vs 1 candidate of the "
                                    "database (+ 1 query per launch swept over the database)",
                        "pairs_per_rank_per_step": B * CH, "pairs_per_launch": B, "launches_per_step": CH,
+                       "database_rows_swept_per_launch": NDB,      # grows with the world size: the replicated database is world x B rows
                        "resident_scan_bytes_per_rank": B * CH * 12 * N_POINTS, "points_per_scan": N_POINTS,
                        "parallelism": f"scan-sharded x{world}" + (" + RCCL all-gather of fp16 descriptor replicas, candidates and "
                                                                   "sweeps read the replicated database, owner re-scoring" if dist_on else "")},
