@@ -16,6 +16,7 @@
 // ([C][61][120]) run the same code in a channel loop; fp16 replicas of the database are accepted as well.
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 
 #include <hip/hip_fp16.h>
 
@@ -29,79 +30,106 @@ constexpr int kD = 120;        // detectors
 constexpr int kHalf = 61;      // kA / 2 + 1
 constexpr int kSlotThreads = 128;
 
-// Z[k] = E + i O for one k, from P[k] = (ar, ai) and P[60-k] = (br, bi):
-// E = P[k] + conj(P[60-k]),  O = (P[k] - conj(P[60-k])) * exp(+2 pi i k / 120)
-template <int K>
-__device__ __forceinline__ void irfft_pre(float ar, float ai, float br, float bi, float& zr, float& zi)
+constexpr int kLdsStride = 128;  // LDS row stride of a staged half spectrum: columns 120..127 are zero, so the 8 lanes past the
+                                 // last detector of a 128-lane slot multiply by zero instead of being masked value by value
+
+// A complex value is one v2f (re, im) in an aligned VGPR pair (csrc/fft_codelets.hpp): every line below is one packed
+// fp32 instruction (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32, swizzles and signs in the operand modifiers).
+__device__ __forceinline__ v2f cmul_conj(v2f a, v2f b)   // a * conj(b) = (ar br + ai bi, ai br - ar bi)
 {
-    const float er = ar + br, ei = ai - bi;
-    const float dr = ar - br, di = ai + bi;
-    const float orr = dr * kCos120[K] - di * kSin120[K];
-    const float oi = dr * kSin120[K] + di * kCos120[K];
-    zr = er - oi;
-    zi = ei + orr;
+    const v2f t = a.yx * b.yy * (v2f){1.0f, -1.0f};
+    return __builtin_elementwise_fma(a, b.xx, t);
+}
+
+__device__ __forceinline__ v2f twiddle120(int K, v2f d)   // d * exp(+2 pi i K / 120); K is a constant after unrolling
+{
+    const v2f t = d.yx * (v2f){-kSin120[K], kSin120[K]};
+    return __builtin_elementwise_fma(d, (v2f){kCos120[K], kCos120[K]}, t);
+}
+
+// Pre-processing of the half-length inverse real transform for the pair (J, 60 - J) from P[J] = u and P[60-J] = w:
+// Z[k] = E + i O with E = P[k] + conj(P[60-k]), O = (P[k] - conj(P[60-k])) exp(+2 pi i k / 120); the partner needs no
+// arithmetic of its own: E' = conj(E), O' = conj(O)  =>  Z[60-J] = (Er + Oi, Or - Ei).
+__device__ __forceinline__ void irfft_pre_pair(int J, v2f u, v2f w, v2f& zj, v2f& zp)
+{
+    const v2f e = __builtin_elementwise_fma(w, (v2f){1.0f, -1.0f}, u);
+    const v2f d = __builtin_elementwise_fma(w, (v2f){-1.0f, 1.0f}, u);
+    const v2f o = twiddle120(J, d);
+    zj = __builtin_elementwise_fma(o.yx, (v2f){-1.0f, 1.0f}, e);
+    zp = __builtin_elementwise_fma(e, (v2f){1.0f, -1.0f}, o.yx);
 }
 
 // Conjugate product of two half spectra streamed straight into the pre-processed FFT input, then the
-// 60-point inverse codelet: on return x[2m] = re[m], x[2m+1] = im[m] with
-// x[n] = sum_{k=0}^{119} P_full[k] exp(+2 pi i k n / 120), P = a * conj(b).
-// load(k, ar, ai, br, bi) fetches a[k] and b[k] of this lane's column.
-template <class Load>
-__device__ __forceinline__ void corr_irfft120(Load load, float (&re)[60], float (&im)[60])
+// 60-point inverse codelet: on return the 120 real samples are x[m] = (sample 2m, sample 2m + 1) of
+// s[n] = sum_{k=0}^{119} P_full[k] exp(+2 pi i k n / 120), P = a * conj(b).
+// la(k) / lb(k) fetch a[k] and b[k] (k = 0..60) of this lane's column.  The a values (LDS or L2) of the NEXT group of
+// frequency pairs are requested before the arithmetic of the current group: left to itself the scheduler places every read
+// right in front of its use and the wave sits out the full latency 30 times per column.
+constexpr int kPairsPerGroup = 5;   // 6 groups cover the pairs (J, 60 - J), J = 0..29; J = 30 rides with the last group
+template <class LoadA, class LoadB>
+__device__ __forceinline__ void corr_irfft120(LoadA la, LoadB lb, v2f (&x)[60])
 {
-    auto prod = [&](int k, float& pr, float& pi) {
-        float ar, ai, br, bi;
-        load(k, ar, ai, br, bi);
-        pr = ar * br + ai * bi;   // a * conj(b)
-        pi = ai * br - ar * bi;
+    constexpr int G = kPairsPerGroup, NG = 30 / kPairsPerGroup;
+    v2f abuf[2][2 * G + 1];
+    auto request = [&](int g, v2f (&dst)[2 * G + 1]) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            dst[2 * j] = la(g * G + j);
+            dst[2 * j + 1] = la(60 - (g * G + j));
+        }
+        if (g == NG - 1) dst[2 * G] = la(30);
     };
-    {
-        float p0r, p0i, p60r, p60i;
-        prod(0, p0r, p0i);
-        prod(60, p60r, p60i);
-        irfft_pre<0>(p0r, p0i, p60r, p60i, re[0], im[0]);
+    request(0, abuf[0]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) request(g + 1, abuf[(g + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const v2f(&a)[2 * G + 1] = abuf[g & 1];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int J = g * G + j;
+            v2f zj, zp;
+            irfft_pre_pair(J, cmul_conj(a[2 * j], lb(J)), cmul_conj(a[2 * j + 1], lb(60 - J)), zj, zp);
+            x[J] = zj;
+            if (J != 0) x[60 - J] = zp;
+        }
+        if (g == NG - 1) {
+            const v2f pm = cmul_conj(a[2 * G], lb(30));
+            v2f unused;
+            irfft_pre_pair(30, pm, pm, x[30], unused);
+        }
     }
-#define MRS_IRFFT_PAIR(J)                                                   \
-    {                                                                       \
-        float ur, ui, wr, wi;                                               \
-        prod(J, ur, ui);                                                    \
-        prod(60 - J, wr, wi);                                               \
-        irfft_pre<J>(ur, ui, wr, wi, re[J], im[J]);                         \
-        irfft_pre<60 - J>(wr, wi, ur, ui, re[60 - J], im[60 - J]);          \
-    }
-    MRS_IRFFT_PAIR(1) MRS_IRFFT_PAIR(2) MRS_IRFFT_PAIR(3) MRS_IRFFT_PAIR(4) MRS_IRFFT_PAIR(5) MRS_IRFFT_PAIR(6)
-    MRS_IRFFT_PAIR(7) MRS_IRFFT_PAIR(8) MRS_IRFFT_PAIR(9) MRS_IRFFT_PAIR(10) MRS_IRFFT_PAIR(11) MRS_IRFFT_PAIR(12)
-    MRS_IRFFT_PAIR(13) MRS_IRFFT_PAIR(14) MRS_IRFFT_PAIR(15) MRS_IRFFT_PAIR(16) MRS_IRFFT_PAIR(17) MRS_IRFFT_PAIR(18)
-    MRS_IRFFT_PAIR(19) MRS_IRFFT_PAIR(20) MRS_IRFFT_PAIR(21) MRS_IRFFT_PAIR(22) MRS_IRFFT_PAIR(23) MRS_IRFFT_PAIR(24)
-    MRS_IRFFT_PAIR(25) MRS_IRFFT_PAIR(26) MRS_IRFFT_PAIR(27) MRS_IRFFT_PAIR(28) MRS_IRFFT_PAIR(29)
-#undef MRS_IRFFT_PAIR
-    {
-        float pr, pi;
-        prod(30, pr, pi);
-        irfft_pre<30>(pr, pi, pr, pi, re[30], im[30]);
-    }
-    cfft60_inv(re, im);
+    cfft60_inv(x);
 }
 
-// real x (x[2m] = re[m], x[2m+1] = im[m]) -> X[0..60] = sum_n x[n] exp(-2 pi i k n / 120), handed to
-// store(k, xr, xi) one frequency at a time (keeps the register footprint at the codelet's)
-template <class Store>
-__device__ __forceinline__ void rfft120(float (&re)[60], float (&im)[60], Store store)
+// real samples (x[m] = (sample 2m, sample 2m + 1)) -> TWICE the spectrum, 2 X[k] = 2 sum_n s[n] exp(-2 pi i k n / 120),
+// k = 0..60, handed to store(k, value) (the caller folds the exact factor 0.5 into its own scale).
+// Z = FFT60(x); S = Z[k] + conj(Z[60-k]), T = (Z[k] - conj(Z[60-k])) exp(-2 pi i k / 120), 2 X[k] = S - i T; the partner
+// frequency shares all of it: S' = conj(S), T' = conj(T)  =>  2 X[60-k] = (Sr - Ti, -Si - Tr).
+__device__ __forceinline__ void rfft_post_pair(int K, v2f zk, v2f zp, v2f& xk, v2f& xp)
 {
-    cfft60_fwd(re, im);
+    const v2f sum = __builtin_elementwise_fma(zp, (v2f){1.0f, -1.0f}, zk);
+    const v2f d = __builtin_elementwise_fma(zp, (v2f){-1.0f, 1.0f}, zk);
+    const v2f tt = d.yx * (v2f){kSin120[K], -kSin120[K]};
+    const v2f t = __builtin_elementwise_fma(d, (v2f){kCos120[K], kCos120[K]}, tt);      // d * (cos - i sin)
+    xk = __builtin_elementwise_fma(t.yx, (v2f){1.0f, -1.0f}, sum);
+    xp = __builtin_elementwise_fma(sum, (v2f){1.0f, -1.0f}, -t.yx);
+}
+
+template <class Store>
+__device__ __forceinline__ void rfft120(v2f (&x)[60], Store store)
+{
+    cfft60_fwd(x);
 #pragma unroll
-    for (int k = 0; k <= 60; ++k) {
-        const int k0 = k % 60, k1 = (60 - k) % 60;
-        const float ar = re[k0], ai = im[k0];
-        const float br = re[k1], bi = -im[k1];                     // conj(Z[60-k])
-        const float sr = ar + br, si = ai + bi;
-        const float dr = ar - br, di = ai - bi;
-        // X = 0.5 * S - 0.5 i * exp(-i theta_k) * D,   exp(-i theta) = cos - i sin
-        const float tr = dr * kCos120[k] + di * kSin120[k];
-        const float ti = di * kCos120[k] - dr * kSin120[k];
-        store(k, 0.5f * (sr + ti), 0.5f * (si - tr));
+    for (int K = 0; K <= 30; ++K) {
+        v2f xk, xp;
+        rfft_post_pair(K, x[K], x[(60 - K) % 60], xk, xp);
+        store(K, xk);
+        if (K != 30) store(60 - K, xp);
     }
 }
+
+constexpr float kOrtho120 = 0.09128709291752769f;   // 1 / sqrt(120)
 
 // R2: half spectrum (ortho) of normalised sinograms.  grid = images, 128 lanes (120 columns).
 // out16 (optional): the same values rounded to nearest-even fp16 = the exchange / replica format (29 280 B)
@@ -110,44 +138,50 @@ __global__ __launch_bounds__(kSlotThreads) void k_ring_half_spectrum(const float
 {
     const int d = min((int)threadIdx.x, kD - 1);
     const float* src = x + (size_t)blockIdx.x * kA * kD + d;
-    float re[60], im[60];
+    v2f s[60];
 #pragma unroll
-    for (int m = 0; m < 60; ++m) {
-        re[m] = src[(2 * m) * kD];
-        im[m] = src[(2 * m + 1) * kD];
-    }
+    for (int m = 0; m < 60; ++m) s[m] = (v2f){src[(2 * m) * kD], src[(2 * m + 1) * kD]};
     const bool live = threadIdx.x < kD;
-    const float sc = 0.09128709291752769f;  // 1/sqrt(120)
     const size_t o = (size_t)blockIdx.x * kHalf * kD + d;
-    rfft120(re, im, [&](int k, float xr, float xi) {
+    rfft120(s, [&](int k, v2f twice) {
         if (!live) return;
-        const float2 v = make_float2(xr * sc, xi * sc);
-        if (out) out[o + k * kD] = v;
+        const v2f v = twice * (v2f){0.5f * kOrtho120, 0.5f * kOrtho120};
+        if (out) out[o + k * kD] = make_float2(v.x, v.y);
         if (out16) out16[o + k * kD] = __floats2half2_rn(v.x, v.y);
     });
 }
 
-// Sum over the 64 lanes of a wave of |x[n]|, n = 0..119, where x[2m] = re[m], x[2m+1] = im[m]
-// (reduce-scatter: 6 halving steps).  On return lane L holds the totals of n = 2L (w0) and 2L+1 (w1).
-__device__ __forceinline__ void wave_abs_reduce_scatter(const float (&re)[60], const float (&im)[60], bool live,
-                                                        float& w0, float& w1)
+// Sum over the 64 lanes of a wave of |s[n]|, n = 0..119, s[2m] = x[m].x, s[2m+1] = x[m].y (reduce-scatter: 6 halving
+// steps).  On return lane L holds the totals of n = 2L (w0) and 2L+1 (w1).  Lanes that must not contribute hold zeros.
+// Steps 0 and 1 (96 of the 126 exchanges) are v_permlane32_swap / v_permlane16_swap: the two values a lane would select
+// between are swapped across the wave halves / row pairs in place, so a halving step is one swap + one add.
+__device__ __forceinline__ float swap32_abs_add(float a, float b)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return fabsf(__uint_as_float(r[0])) + fabsf(__uint_as_float(r[1]));   // low half: |a[L]| + |a[L+32]|, high half: |b[L-32]| + |b[L]|
+}
+__device__ __forceinline__ float swap16_add(float a, float b)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);                  // even rows: a + a[L^16], odd rows: b[L^16] + b
+}
+
+__device__ __forceinline__ void wave_abs_reduce_scatter(const v2f (&x)[60], float& w0, float& w1)
 {
     const int lane = threadIdx.x & 63;
     float w[64];
-    {
-        const bool hi = (lane & 32) != 0;   // step 0: indices [0,64) stay in the low half-wave, [64,128) in the high
+    // step 0: indices [0,64) stay in the low half-wave, [64,128) in the high one (120..127 do not exist: zero)
 #pragma unroll
-        for (int i = 0; i < 64; ++i) {
-            const float lo_v = live ? fabsf((i & 1) ? im[i >> 1] : re[i >> 1]) : 0.0f;
-            const int j = 64 + i;
-            const float hi_v = (j < 120 && live) ? fabsf((j & 1) ? im[(j >> 1) % 60] : re[(j >> 1) % 60]) : 0.0f;
-            const float send = hi ? lo_v : hi_v;
-            const float mine = hi ? hi_v : lo_v;
-            w[i] = mine + __shfl_xor(send, 32, 64);
-        }
+    for (int i = 0; i < 64; ++i) {
+        const int j = 64 + i;
+        const float lo_v = (i & 1) ? x[i >> 1].y : x[i >> 1].x;
+        const float hi_v = j < 120 ? ((j & 1) ? x[j >> 1].y : x[j >> 1].x) : 0.0f;
+        w[i] = swap32_abs_add(lo_v, hi_v);
     }
 #pragma unroll
-    for (int step = 1; step < 6; ++step) {
+    for (int i = 0; i < 32; ++i) w[i] = swap16_add(w[i], w[32 + i]);
+#pragma unroll
+    for (int step = 2; step < 6; ++step) {
         const int keep = 64 >> step;
         const int mask = 32 >> step;
         const bool hi = (lane & mask) != 0;
@@ -176,12 +210,12 @@ __device__ __forceinline__ float2 load_spec(const __half2* p) { return __half22f
 // Descriptors with C channels are [C][61][120]: |corr| is summed over channels and detectors
 // (fast_corr_RINGplusplus, RING_ros/util.py:337-358; C = 1: fast_corr, util.py:362-374).
 // PAIRWISE: candidate = query index (one per block row); MULTI: runtime channel count (else C = 1, no loop).
-template <int NSLOT, bool QLDS, bool PAIRWISE, bool MULTI, typename DBT>
+template <int NSLOT, bool QLDS, bool PAIRWISE, bool MULTI, typename DBT, bool PRELOAD = false>
 __global__ __launch_bounds__(NSLOT* kSlotThreads) void k_ring_corr_fft(const float2* __restrict__ Q, const DBT* __restrict__ DB,
                                                                        FftCorrP p, float* __restrict__ dist,
                                                                        int* __restrict__ angle, float* __restrict__ corr_out)
 {
-    extern __shared__ __attribute__((aligned(16))) float2 qs[];  // [61][120] query half spectrum (QLDS)
+    extern __shared__ __attribute__((aligned(16))) v2f qs[];  // [61][128] query half spectrum, columns 120..127 zero (QLDS)
     __shared__ float xbuf[NSLOT][128];
     const int q = blockIdx.y;
     const int slot = threadIdx.x / kSlotThreads;
@@ -193,7 +227,12 @@ __global__ __launch_bounds__(NSLOT* kSlotThreads) void k_ring_corr_fft(const flo
     const size_t entry = (size_t)C * kHalf * kD;
     const float2* qsrc = Q + (size_t)q * entry;
     if (QLDS) {
-        for (int i = threadIdx.x; i < kHalf * kD; i += NSLOT * kSlotThreads) qs[i] = qsrc[i];
+        for (int i = threadIdx.x; i < kHalf * kLdsStride; i += NSLOT * kSlotThreads) {
+            const int k = i / kLdsStride, col = i % kLdsStride;
+            v2f v = {0.0f, 0.0f};
+            if (col < kD) { const float2 g = qsrc[k * kD + col]; v = (v2f){g.x, g.y}; }
+            qs[i] = v;
+        }
         __syncthreads();
     }
     const int ncand = PAIRWISE ? 1 : p.ndb;
@@ -201,31 +240,37 @@ __global__ __launch_bounds__(NSLOT* kSlotThreads) void k_ring_corr_fft(const flo
     const int rounds = (ncand + stride - 1) / stride;
     for (int r = 0; r < rounds; ++r) {
         const int cand = (r * gridDim.x + blockIdx.x) * NSLOT + slot;
-        const bool live = cand < ncand;
+        const bool live = cand < ncand;      // uniform over the slot's two waves
         float v[2] = {0.0f, 0.0f};
-        for (int c = 0; c < C; ++c) {
-            float re[60], im[60];
-            if (live) {
+        if (live) {
+            for (int c = 0; c < C; ++c) {
+                v2f x[60];
                 const DBT* b = DB + (size_t)(PAIRWISE ? q : cand) * entry + (size_t)c * kHalf * kD + d;
                 const float2* a = qsrc + (size_t)c * kHalf * kD + d;
-                corr_irfft120([&](int k, float& ar, float& ai, float& br, float& bi) {
-                    const float2 bv = load_spec(b + k * kD);
-                    const float2 av = QLDS ? qs[k * kD + d] : a[k * kD];
-                    ar = av.x; ai = av.y; br = bv.x; bi = bv.y;
-                }, re, im);
-            } else {
+                auto la = [&](int k) {
+                    if (QLDS) return qs[k * kLdsStride + t];
+                    const float2 g = a[k * kD];       // lanes past the last detector: zero query -> zero correlation
+                    return live_col ? (v2f){g.x, g.y} : (v2f){0.0f, 0.0f};
+                };
+                if (PRELOAD) {
+                    DBT raw[kHalf];                   // the whole column of the candidate in flight before the first use
 #pragma unroll
-                for (int m = 0; m < 60; ++m) { re[m] = 0.0f; im[m] = 0.0f; }
+                    for (int k = 0; k < kHalf; ++k) raw[k] = b[k * kD];
+                    __builtin_amdgcn_sched_barrier(0);
+                    corr_irfft120(la, [&](int k) { const float2 g = load_spec(&raw[k]); return (v2f){g.x, g.y}; }, x);
+                } else {
+                    corr_irfft120(la, [&](int k) { const float2 g = load_spec(b + k * kD); return (v2f){g.x, g.y}; }, x);
+                }
+                float w0, w1;
+                wave_abs_reduce_scatter(x, w0, w1);
+                v[0] += w0;
+                v[1] += w1;
             }
-            float w0, w1;
-            wave_abs_reduce_scatter(re, im, live && live_col, w0, w1);
-            v[0] += w0;
-            v[1] += w1;
         }
         if (wave_in_slot == 1) { xbuf[slot][2 * lane] = v[0]; xbuf[slot][2 * lane + 1] = v[1]; }
         __syncthreads();
         if (wave_in_slot == 0 && live) {
-            const float sc = 0.09128709291752769f;  // ifft ortho factor 1/sqrt(120)
+            const float sc = kOrtho120;  // ifft ortho factor
             const float s0 = (v[0] + xbuf[slot][2 * lane]) * sc, s1 = (v[1] + xbuf[slot][2 * lane + 1]) * sc;
             // fftshift: shifted index m = (n + 60) % 120; first maximum in m order (util.py:367-371)
             const int n0 = 2 * lane, n1 = 2 * lane + 1;
@@ -252,6 +297,86 @@ __global__ __launch_bounds__(NSLOT* kSlotThreads) void k_ring_corr_fft(const flo
     }
 }
 
+// The single-channel database sweep with the candidate of the NEXT round already in flight while this round's
+// correlation runs (software pipeline in registers: 61 x 8 B per lane, or 61 x 4 B for fp16 replicas).  Same arithmetic and
+// epilogue as k_ring_corr_fft<NSLOT, true, false, false>; one query per blockIdx.y.
+template <int NSLOT, typename DBT, int WAVES>
+__global__ __launch_bounds__(NSLOT* kSlotThreads) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_ring_sweep_pipe(
+    const float2* __restrict__ Q, const DBT* __restrict__ DB, FftCorrP p, float* __restrict__ dist, int* __restrict__ angle,
+    float* __restrict__ corr_out)
+{
+    extern __shared__ __attribute__((aligned(16))) v2f qs[];  // [61][128] query half spectrum, columns 120..127 zero
+    __shared__ float xbuf[NSLOT][128];
+    const int q = blockIdx.y;
+    const int slot = threadIdx.x / kSlotThreads;
+    const int t = threadIdx.x % kSlotThreads;
+    const int wave_in_slot = t >> 6, lane = t & 63;
+    const int d = min(t, kD - 1);
+    const size_t entry = (size_t)kHalf * kD;
+    const float2* qsrc = Q + (size_t)q * entry;
+    const int ncand = p.ndb;
+    const int stride = gridDim.x * NSLOT;
+    const int rounds = (ncand + stride - 1) / stride;
+    int cand = blockIdx.x * NSLOT + slot;
+    DBT nxt[kHalf];
+    auto fetch = [&](int c) {
+        const DBT* b = DB + (size_t)c * entry + d;
+#pragma unroll
+        for (int k = 0; k < kHalf; ++k) nxt[k] = b[k * kD];
+    };
+    if (cand < ncand) fetch(cand);           // in flight while the query is staged
+    for (int i = threadIdx.x; i < kHalf * kLdsStride; i += NSLOT * kSlotThreads) {
+        const int k = i / kLdsStride, col = i % kLdsStride;
+        v2f v = {0.0f, 0.0f};
+        if (col < kD) { const float2 g = qsrc[k * kD + col]; v = (v2f){g.x, g.y}; }
+        qs[i] = v;
+    }
+    __syncthreads();
+    for (int r = 0; r < rounds; ++r) {
+        const bool live = cand < ncand;      // uniform over the slot's two waves
+        DBT cur[kHalf];
+#pragma unroll
+        for (int k = 0; k < kHalf; ++k) cur[k] = nxt[k];
+        const int next = cand + stride;
+        if (next < ncand) fetch(next);
+        __builtin_amdgcn_sched_barrier(0);
+        float v0 = 0.0f, v1 = 0.0f;
+        if (live) {
+            v2f x[60];
+            corr_irfft120([&](int k) { return qs[k * kLdsStride + t]; },
+                          [&](int k) { const float2 g = load_spec(&cur[k]); return (v2f){g.x, g.y}; }, x);
+            wave_abs_reduce_scatter(x, v0, v1);
+        }
+        if (wave_in_slot == 1) { xbuf[slot][2 * lane] = v0; xbuf[slot][2 * lane + 1] = v1; }
+        __syncthreads();
+        if (wave_in_slot == 0 && live) {
+            const float sc = kOrtho120;
+            const float s0 = (v0 + xbuf[slot][2 * lane]) * sc, s1 = (v1 + xbuf[slot][2 * lane + 1]) * sc;
+            const int n0 = 2 * lane, n1 = 2 * lane + 1;
+            const int m0 = n0 < 60 ? n0 + 60 : n0 - 60, m1 = n1 < 60 ? n1 + 60 : n1 - 60;
+            const size_t o = (size_t)q * p.ndb + cand;
+            float best = -1.0f;
+            int bm = 1 << 30;
+            if (lane < 60) {
+                if (corr_out) { corr_out[o * kA + m0] = s0; corr_out[o * kA + m1] = s1; }
+                best = s0; bm = m0;
+                if (s1 > best || (s1 == best && m1 < bm)) { best = s1; bm = m1; }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                const float ob = __shfl_xor(best, off, 64);
+                const int om = __shfl_xor(bm, off, 64);
+                if (ob > best || (ob == best && om < bm)) { best = ob; bm = om; }
+            }
+            if (lane == 0) {
+                dist[o] = 1.0f - best / p.denom;
+                angle[o] = kA / 2 - bm;
+            }
+        }
+        __syncthreads();  // xbuf reuse
+        cand = next;
+    }
+}
+
 // New-descriptor path of a loop check in ONE launch (row R2 + C1 for pairs): half spectrum of the freshly
 // normalised sinogram (written out: it becomes a database entry / travels to the other ranks) and, straight from
 // the LDS copy of that spectrum, its correlation with the candidate's.  Same arithmetic, op for op, as
@@ -260,55 +385,56 @@ __global__ __launch_bounds__(NSLOT* kSlotThreads) void k_ring_corr_fft(const flo
 // CT = float2 (exact database entries) or __half2 (fp16 replicas received from other ranks); cand_idx (optional):
 // the candidate of pair i is row cand_idx[i] of `cand` (a pre-selected row of the replicated database) instead of row i.
 template <typename CT>
-__global__ __launch_bounds__(kSlotThreads) void k_ring_spec_corr_pairs(const float* __restrict__ x, const CT* __restrict__ cand,
+__global__ __launch_bounds__(kSlotThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_ring_spec_corr_pairs(const float* __restrict__ x, const CT* __restrict__ cand,
                                                                        const int* __restrict__ cand_idx, int n_db,
                                                                        float2* __restrict__ out, __half2* __restrict__ out16,
                                                                        float denom, float* __restrict__ dist,
                                                                        int* __restrict__ angle)
 {
-    extern __shared__ __attribute__((aligned(16))) float2 qs[];  // [61][120]
+    extern __shared__ __attribute__((aligned(16))) v2f qs[];  // [61][128], columns 120..127 zero
     __shared__ float xbuf[128];
     const int pair = blockIdx.x;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int d = min(t, kD - 1);
     const bool live_col = t < kD;
+    // the candidate's column is requested first: it arrives while the forward transform of the new sinogram runs (the
+    // workgroup's LDS footprint allows one wave per SIMD anyway, so the 61 - 122 extra registers cost no occupancy)
+    const int row = cand_idx ? cand_idx[pair] : pair;
+    const bool no_row = cand_idx && (row < 0 || row >= n_db);
+    CT raw[kHalf];
+    {
+        const CT* b = cand + (size_t)(no_row ? 0 : row) * kHalf * kD + d;
+#pragma unroll
+        for (int k = 0; k < kHalf; ++k) raw[k] = b[k * kD];
+    }
     {
         const float* src = x + (size_t)pair * kA * kD + d;
-        float re[60], im[60];
+        v2f s[60];
 #pragma unroll
-        for (int m = 0; m < 60; ++m) {
-            re[m] = src[(2 * m) * kD];
-            im[m] = src[(2 * m + 1) * kD];
-        }
-        const float sc = 0.09128709291752769f;  // 1/sqrt(120)
+        for (int m = 0; m < 60; ++m) s[m] = (v2f){src[(2 * m) * kD], src[(2 * m + 1) * kD]};
         const size_t o = (size_t)pair * kHalf * kD + d;
-        rfft120(re, im, [&](int k, float xr, float xi) {
+        rfft120(s, [&](int k, v2f twice) {
+            const v2f v = twice * (v2f){0.5f * kOrtho120, 0.5f * kOrtho120};
+            qs[k * kLdsStride + t] = live_col ? v : (v2f){0.0f, 0.0f};
             if (!live_col) return;
-            const float2 v = make_float2(xr * sc, xi * sc);
-            qs[k * kD + d] = v;
-            if (out) out[o + k * kD] = v;
+            if (out) out[o + k * kD] = make_float2(v.x, v.y);
             if (out16) out16[o + k * kD] = __floats2half2_rn(v.x, v.y);
         });
     }
     __syncthreads();
-    float re[60], im[60];
-    const int row = cand_idx ? cand_idx[pair] : pair;
-    if (cand_idx && (row < 0 || row >= n_db)) {   // no such database row: the new spectrum is still written, the score says "no match"
+    if (no_row) {   // no such database row: the new spectrum is still written, the score says "no match"
         if (t == 0) { dist[pair] = INFINITY; angle[pair] = 0; }
         return;
     }
-    const CT* b = cand + (size_t)row * kHalf * kD + d;
-    corr_irfft120([&](int k, float& ar, float& ai, float& br, float& bi) {
-        const float2 bv = load_spec(b + k * kD);
-        const float2 av = qs[k * kD + d];
-        ar = av.x; ai = av.y; br = bv.x; bi = bv.y;
-    }, re, im);
+    v2f c[60];
+    corr_irfft120([&](int k) { return qs[k * kLdsStride + t]; },
+                  [&](int k) { const float2 g = load_spec(&raw[k]); return (v2f){g.x, g.y}; }, c);
     float v0, v1;
-    wave_abs_reduce_scatter(re, im, live_col, v0, v1);
+    wave_abs_reduce_scatter(c, v0, v1);
     if (wave == 1) { xbuf[2 * lane] = v0; xbuf[2 * lane + 1] = v1; }
     __syncthreads();
     if (wave == 0) {
-        const float sc = 0.09128709291752769f;
+        const float sc = kOrtho120;
         const float s0 = (v0 + xbuf[2 * lane]) * sc, s1 = (v1 + xbuf[2 * lane + 1]) * sc;
         const int n0 = 2 * lane, n1 = 2 * lane + 1;
         const int m0 = n0 < 60 ? n0 + 60 : n0 - 60, m1 = n1 < 60 ? n1 + 60 : n1 - 60;
@@ -344,7 +470,7 @@ static int spectrum_corr_pairs_launch(mrs_ctx* ctx, const float* d_norm_sino, co
         return MRS_ERR_UNSUPPORTED;
     }
     MRS_HIP_TRY(hipSetDevice(ctx->device));
-    const size_t lds = (size_t)kHalf * kD * sizeof(float2);
+    const size_t lds = (size_t)kHalf * kLdsStride * sizeof(v2f);
     MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring_spec_corr_pairs<CT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
     hipLaunchKernelGGL(k_ring_spec_corr_pairs<CT>, dim3(n_pairs), dim3(kSlotThreads), lds, (hipStream_t)stream, d_norm_sino, cand,
@@ -424,10 +550,24 @@ static int corr_fft_launch(mrs_ctx* ctx, const float* d_q, int32_t n_q, const vo
             if (blocks > need) blocks = need;
             if (blocks < 1) blocks = 1;
             if (channels == 1) {
-                const size_t lds = (size_t)kHalf * kD * sizeof(float2);
-                auto kern = k_ring_corr_fft<NSLOT, true, false, false, DBT>;
-                MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(kern, dim3(blocks, nq), dim3(NSLOT * kSlotThreads), lds, s, qq, dd, p, dist_c, angle_c, corr_c);
+                const size_t lds = (size_t)kHalf * kLdsStride * sizeof(v2f);
+                // the candidate's whole column is requested before the arithmetic starts (PRELOAD); fp16 replicas (half the
+                // registers per value) swept by one or two queries (the HBM-side regime): the NEXT round's candidate is already
+                // in flight during this round's arithmetic
+                bool launched = false;
+                if constexpr (std::is_same<DBT, __half2>::value) {
+                    if (n_q <= 2) {
+                        auto kern = k_ring_sweep_pipe<NSLOT, DBT, 2>;
+                        MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                        hipLaunchKernelGGL(kern, dim3(blocks, nq), dim3(NSLOT * kSlotThreads), lds, s, qq, dd, p, dist_c, angle_c, corr_c);
+                        launched = true;
+                    }
+                }
+                if (!launched) {
+                    auto kern = k_ring_corr_fft<NSLOT, true, false, false, DBT, true>;
+                    MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL(kern, dim3(blocks, nq), dim3(NSLOT * kSlotThreads), lds, s, qq, dd, p, dist_c, angle_c, corr_c);
+                }
             } else {
                 hipLaunchKernelGGL((k_ring_corr_fft<NSLOT, false, false, true, DBT>), dim3(blocks, nq), dim3(NSLOT * kSlotThreads), 0, s, qq, dd, p,
                                    dist_c, angle_c, corr_c);
