@@ -377,6 +377,87 @@ __global__ __launch_bounds__(NSLOT* kSlotThreads) __attribute__((amdgpu_waves_pe
     }
 }
 
+// RING++ database sweep, channel-outer: one channel of the query is staged in LDS at a time (the six channels together,
+// 375 KB, do not fit) and swept over all of the workgroup's candidates before the next channel replaces it, so that the inner
+// loop is the single-channel kernel's (query from LDS, candidate column requested up front, two waves per SIMD).  The
+// per-candidate |corr| sums of every lane wait in LDS between channels: MAXR rounds x NSLOT x 128 lanes x 2 floats.
+// grid = (queries, chunks): workgroups that follow each other sweep the SAME candidates for different queries and share them
+// through L2.  Channel sums are added in channel order per lane, like the channel-inner loop of k_ring_corr_fft (same bits).
+template <int NSLOT, int MAXR, typename DBT>
+__global__ __launch_bounds__(NSLOT* kSlotThreads) void k_ring_sweep_mc(const float2* __restrict__ Q, const DBT* __restrict__ DB, FftCorrP p,
+                                                                       float* __restrict__ dist, int* __restrict__ angle,
+                                                                       float* __restrict__ corr_out)
+{
+    extern __shared__ __attribute__((aligned(16))) v2f qs[];  // [61][128] one query channel, then acc[MAXR][NSLOT][128]
+    v2f* acc = qs + kHalf * kLdsStride;
+    const int q = blockIdx.x, chunk = blockIdx.y, nchunks = gridDim.y;
+    const int slot = threadIdx.x / kSlotThreads;
+    const int t = threadIdx.x % kSlotThreads;
+    const int lane = t & 63;
+    const int d = min(t, kD - 1);
+    const int C = p.channels;
+    const size_t plane = (size_t)kHalf * kD, entry = (size_t)C * plane;
+    const float2* qsrc = Q + (size_t)q * entry;
+    const int ncand = p.ndb;
+    const int rounds = (ncand + nchunks * NSLOT - 1) / (nchunks * NSLOT);   // <= MAXR (launcher)
+    for (int r = 0; r < rounds; ++r) acc[(r * NSLOT + slot) * kSlotThreads + t] = (v2f){0.0f, 0.0f};
+    for (int c = 0; c < C; ++c) {
+        __syncthreads();   // the previous channel has been read by every wave
+        for (int i = threadIdx.x; i < kHalf * kLdsStride; i += NSLOT * kSlotThreads) {
+            const int k = i / kLdsStride, col = i % kLdsStride;
+            v2f v = {0.0f, 0.0f};
+            if (col < kD) { const float2 g = qsrc[c * plane + k * kD + col]; v = (v2f){g.x, g.y}; }
+            qs[i] = v;
+        }
+        __syncthreads();
+        for (int r = 0; r < rounds; ++r) {
+            const int cand = (r * nchunks + chunk) * NSLOT + slot;
+            if (cand >= ncand) continue;   // uniform over the slot's two waves; no barrier inside this loop
+            const DBT* b = DB + (size_t)cand * entry + c * plane + d;
+            DBT raw[kHalf];
+#pragma unroll
+            for (int k = 0; k < kHalf; ++k) raw[k] = b[k * kD];
+            __builtin_amdgcn_sched_barrier(0);
+            v2f x[60];
+            corr_irfft120([&](int k) { return qs[k * kLdsStride + t]; },
+                          [&](int k) { const float2 g = load_spec(&raw[k]); return (v2f){g.x, g.y}; }, x);
+            float w0, w1;
+            wave_abs_reduce_scatter(x, w0, w1);
+            v2f* a = &acc[(r * NSLOT + slot) * kSlotThreads + t];
+            const v2f old = *a;
+            *a = (v2f){old.x + w0, old.y + w1};
+        }
+    }
+    __syncthreads();
+    if (t >= 64) return;   // the first wave of each slot adds the second wave's sums and picks the maximum
+    for (int r = 0; r < rounds; ++r) {
+        const int cand = (r * nchunks + chunk) * NSLOT + slot;
+        if (cand >= ncand) continue;
+        const v2f lo = acc[(r * NSLOT + slot) * kSlotThreads + lane], hi = acc[(r * NSLOT + slot) * kSlotThreads + 64 + lane];
+        const float sc = kOrtho120;
+        const float s0 = (lo.x + hi.x) * sc, s1 = (lo.y + hi.y) * sc;
+        const int n0 = 2 * lane, n1 = 2 * lane + 1;
+        const int m0 = n0 < 60 ? n0 + 60 : n0 - 60, m1 = n1 < 60 ? n1 + 60 : n1 - 60;
+        const size_t o = (size_t)q * p.ndb + cand;
+        float best = -1.0f;
+        int bm = 1 << 30;
+        if (lane < 60) {
+            if (corr_out) { corr_out[o * kA + m0] = s0; corr_out[o * kA + m1] = s1; }
+            best = s0; bm = m0;
+            if (s1 > best || (s1 == best && m1 < bm)) { best = s1; bm = m1; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ob = __shfl_xor(best, off, 64);
+            const int om = __shfl_xor(bm, off, 64);
+            if (ob > best || (ob == best && om < bm)) { best = ob; bm = om; }
+        }
+        if (lane == 0) {
+            dist[o] = 1.0f - best / p.denom;
+            angle[o] = kA / 2 - bm;
+        }
+    }
+}
+
 // New-descriptor path of a loop check in ONE launch (row R2 + C1 for pairs): half spectrum of the freshly
 // normalised sinogram (written out: it becomes a database entry / travels to the other ranks) and, straight from
 // the LDS copy of that spectrum, its correlation with the candidate's.  Same arithmetic, op for op, as
@@ -569,8 +650,22 @@ static int corr_fft_launch(mrs_ctx* ctx, const float* d_q, int32_t n_q, const vo
                     hipLaunchKernelGGL(kern, dim3(blocks, nq), dim3(NSLOT * kSlotThreads), lds, s, qq, dd, p, dist_c, angle_c, corr_c);
                 }
             } else {
-                hipLaunchKernelGGL((k_ring_corr_fft<NSLOT, false, false, true, DBT>), dim3(blocks, nq), dim3(NSLOT * kSlotThreads), 0, s, qq, dd, p,
-                                   dist_c, angle_c, corr_c);
+                constexpr int MAXR = 8;
+                // chunks = a whole number of "waves" of resident workgroups (two per CU, shared by the queries of the launch), the
+                // smallest that keeps the rounds per workgroup within MAXR: 10 000 entries, one query -> 1024 chunks x 5 rounds
+                // (625 chunks x 8 rounds would run 512 + 113 workgroups: the second wave almost empty)
+                const int resident = std::max(1, 2 * (ctx->num_cu > 0 ? ctx->num_cu : 256) / nq);
+                const int waves = (n_db + NSLOT * MAXR * resident - 1) / (NSLOT * MAXR * resident);
+                const int chunks = std::max(1, std::min(waves * resident, (n_db + NSLOT - 1) / NSLOT));
+                const size_t lds = (size_t)(kHalf * kLdsStride + MAXR * NSLOT * kSlotThreads) * sizeof(v2f);
+                if (chunks <= mrs::kMaxGridY) {
+                    auto kern = k_ring_sweep_mc<NSLOT, MAXR, DBT>;
+                    MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL(kern, dim3(nq, chunks), dim3(NSLOT * kSlotThreads), lds, s, qq, dd, p, dist_c, angle_c, corr_c);
+                } else {   // more than 65535 x 16 candidates in one call: the channel-inner kernel has no such limit
+                    hipLaunchKernelGGL((k_ring_corr_fft<NSLOT, false, false, true, DBT>), dim3(blocks, nq), dim3(NSLOT * kSlotThreads), 0, s, qq, dd,
+                                       p, dist_c, angle_c, corr_c);
+                }
             }
         }
     }
