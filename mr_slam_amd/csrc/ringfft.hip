@@ -10,10 +10,10 @@
 // across lanes), forms the conjugate product, and runs a 120-point real inverse transform entirely in
 // registers (half-length trick + generated straight-line complex FFT-60, csrc/fft_codelets.hpp).
 // The 120 |corr| values per lane are summed across the 120 lanes with a wave reduce-scatter.
-// ~0.3 MFLOP and 58.56 KB per pair: with one query the sweep is near both the HBM and the VALU limit
-// (64 M pairs/s = 3.8 TB/s); with several queries per launch the database is fetched once (L2 shares it
-// between the query rows) and the in-register FFT (VALU) binds at ~90-100 M pairs/s.  RING++ descriptors
-// ([C][61][120]) run the same code in a channel loop; fp16 replicas of the database are accepted as well.
+// 58.56 KB and ~1 400 packed / scalar VALU instructions per 120-lane column pass: with one query the sweep runs at the
+// device's copy rate (81 M pairs/s = 4.8 TB/s, profiles/r02_*); with several queries per launch the database is fetched once
+// (L2 shares it between the query rows) and the in-register FFT (VALU) binds at 115-135 M pairs/s.  RING++ descriptors
+// ([C][61][120]) are swept channel-outer (k_ring_sweep_mc); fp16 replicas of the database are accepted as well.
 #include <algorithm>
 #include <cmath>
 #include <type_traits>
