@@ -456,3 +456,40 @@ def test_spectrum_corr_pairs_db_indexes_the_database_and_flags_missing_rows(dev)
     _, s16, d16, a16 = ring.spectrum_corr_pairs_db(q, db16, idx, want_f16=True)
     assert (d16[ok] - wd).abs().max() < 2e-3 and torch.isinf(d16[~ok]).all()
     assert torch.equal(s16, torch.view_as_real(ring.half_spectrum(q)).to(torch.float16))
+
+
+def test_multi_round_sweeps_equal_the_pairwise_kernel_bit_for_bit(dev):
+    """Databases large enough that every sweep kernel runs several (ragged) rounds per workgroup: the one-query and
+    several-query RING sweeps, the fp16-replica sweep with the next candidate prefetched (1-2 queries) and without (3), and
+    the channel-outer RING++ sweep must all give exactly what the one-candidate-per-workgroup pairwise kernel gives."""
+    import torch
+    from mr_slam_amd import ring
+    g = torch.Generator(device=dev).manual_seed(5)
+    n_db = 2 * 2 * 256 * 2 + 77                      # > 2 rounds of 2 x (2 workgroups per CU) x 256 CUs, ragged tail
+    sino = torch.rand((n_db, 120, 120), device=dev, generator=g) * (torch.rand((n_db, 120, 120), device=dev, generator=g) < 0.3)
+    sdb, sdb16 = ring.half_spectrum_f16(ring.normalize(sino[:, None])[:, 0])
+    sq = sdb[[3, n_db - 1, 1000]].contiguous()
+    pick = torch.tensor([0, 1, 511, 512, 1023, 1024, 1500, 2047, 2048, n_db - 2, n_db - 1], device=dev)
+    for nq in (1, 3):
+        d, a = ring.corr_sweep_fft(sq[:nq], sdb)
+        for qi in range(nq):
+            wd, wa = ring.corr_pairs_fft(sq[qi:qi + 1].expand(len(pick), -1, -1).contiguous(), sdb[pick].contiguous())
+            assert torch.equal(d[qi, pick], wd) and torch.equal(a[qi, pick], wa)
+        assert int(torch.argmin(d[0])) == 3 and int(a[0, 3]) == 0      # the query is entry 3 itself
+    d16_1, a16_1 = ring.corr_sweep_fft(sq[:1], sdb16)              # prefetching kernel
+    d16_3, a16_3 = ring.corr_sweep_fft(sq, sdb16)                  # plain kernel
+    assert torch.equal(d16_1[0], d16_3[0]) and torch.equal(a16_1[0], a16_3[0])
+    assert float((d16_3 - ring.corr_sweep_fft(sq, sdb)[0]).abs().max()) < 2e-3
+    # RING++: 6 channels, > 1 round of 8 candidates per slot
+    C, n_pp = 6, 2 * 256 * 2 * 8 + 333
+    spp = sdb.new_empty((n_pp, C, 61, 120))
+    idx = torch.randint(0, n_db, (n_pp, C), device=dev, generator=g)
+    spp.copy_(sdb[idx.reshape(-1)].reshape(n_pp, C, 61, 120))       # channel planes drawn from the RING entries
+    qpp = spp[[5, n_pp - 1]].contiguous()
+    pick = torch.tensor([0, 5, 15, 16, 4095, 4096, 8191, 8192, n_pp - 1], device=dev)
+    for nq in (1, 2):
+        d, a = ring.corr_sweep_fft(qpp[:nq], spp)
+        for qi in range(nq):
+            wd, wa = ring.corr_pairs_fft(qpp[qi:qi + 1].expand(len(pick), -1, -1, -1).contiguous(), spp[pick].contiguous())
+            assert torch.equal(d[qi, pick], wd) and torch.equal(a[qi, pick], wa)
+    assert int(torch.argmin(d[0])) == 5 and int(torch.argmin(d[1])) == n_pp - 1
