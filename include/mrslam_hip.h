@@ -458,9 +458,9 @@ int mrs_elev_create(mrs_ctx* ctx, int32_t length, float resolution, float mahala
 int mrs_elev_destroy(mrs_elev_map* m);
 /* Move(current_Position[3], resolution, length, Central_coordinate[2], Start_indice[2], alignedPositionShift[2]) */
 int mrs_elev_move(mrs_elev_map* m, const float* h_position3, float* h_central2, int32_t* h_start2, float* h_aligned_shift2);
-/* Process_points(map_index, point_x/y/z (rejected -> -1), point_var, point_x/y/z_ts, transform, point_num, thresholds,
+/* Process_points(map_index, point_x/y/z (read only: the reference never copies its device copy back), point_var, point_x/y/z_ts, transform, point_num, thresholds,
  * sensor model, sensorJacobian, rotationVariance, C_SB_transpose, P_mul_C_BM_transpose, B_r_BS_skew) */
-int mrs_elev_process_points(mrs_elev_map* m, int32_t n, float* h_x, float* h_y, float* h_z, const float* h_transform16,
+int mrs_elev_process_points(mrs_elev_map* m, int32_t n, const float* h_x, const float* h_y, const float* h_z, const float* h_transform16,
                             double relative_lower_threshold, double relative_upper_threshold, float min_r, float beam_a,
                             float beam_c, const float* h_sensorJacobian3, const float* h_rotationVariance9,
                             const float* h_C_SB_transpose9, const float* h_P_mul_C_BM_transpose3, const float* h_B_r_BS_skew9,

@@ -454,7 +454,7 @@ int mrs_elev_move(mrs_elev_map* m, const float* h_position3, float* h_central2, 
 }
 
 // Process_points (:1076-1137): host arrays in / out like the reference
-int mrs_elev_process_points(mrs_elev_map* m, int32_t n, float* h_x, float* h_y, float* h_z, const float* h_transform16,
+int mrs_elev_process_points(mrs_elev_map* m, int32_t n, const float* h_x, const float* h_y, const float* h_z, const float* h_transform16,
                             double lower, double upper, float min_r, float beam_a, float beam_c, const float* h_sensorJacobian3,
                             const float* h_rotationVariance9, const float* h_C_SB_transpose9, const float* h_P_mul_C_BM_transpose3,
                             const float* h_B_r_BS_skew9, int32_t* h_map_index, float* h_var, float* h_x_ts, float* h_y_ts, float* h_z_ts)
@@ -483,9 +483,6 @@ int mrs_elev_process_points(mrs_elev_map* m, int32_t n, float* h_x, float* h_y, 
     if (st != MRS_OK) return st;
     hipLaunchKernelGGL(k_elev_lowest, dim3(nb(n)), dim3(256), 0, s, keys.as<unsigned>(), perm.as<int>(), n, dzt, dv, m->lowest);
     MRS_HIP_TRY(hipGetLastError());
-    MRS_HIP_TRY(hipMemcpyAsync(h_x, dx, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    MRS_HIP_TRY(hipMemcpyAsync(h_y, dy, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    MRS_HIP_TRY(hipMemcpyAsync(h_z, dz, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     MRS_HIP_TRY(hipMemcpyAsync(h_var, dv, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     MRS_HIP_TRY(hipMemcpyAsync(h_x_ts, dxt, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     MRS_HIP_TRY(hipMemcpyAsync(h_y_ts, dyt, (size_t)n * 4, hipMemcpyDeviceToHost, s));

@@ -12,8 +12,11 @@
  *     Map_feature           :1248-1296 G_Mapfeature :547-668, computerEigenvalue :64-186
  *     Raytracing            :1298-1312 G_Raytracing :706-893, G_Clear_maplowest :232-239
  *     Map_optmove :1210-1227, Map_closeloop :1229-1246, G_update_mapheight :1189-1197
- * PARITY UNPINNED: the reference is CUDA-only (no nvcc here) and has no test for it.  Two reference
- * behaviours are racy and are given their sequential-in-point-order reading here and in the HIP code:
+ * PINNED to the reference source itself: oracle/Makefile builds gpu_process.cu for the host (oracle/ref_elev_shim.cpp,
+ * oracle/_ref/libref_elev.so: launches run thread by thread in gid order, stand-ins for the CUDA runtime and the few Eigen
+ * operations), and tests/test_oracle_elev.py replays one multi-frame session on both: indices, layers, variances bit-identical,
+ * slope / traversability 6e-7.  Two reference behaviours are racy on a GPU and are given their sequential-in-point-order
+ * reading here, in the host build and in the HIP code:
  *   - the `map_lowest` update in G_pointsprocess (atomicMin followed by a non-atomic "+3 sigma" bump):
  *     read as  lowest = (h <= lowest) ? h + 3*var : lowest, points in input order;
  *   - G_fuse is already sequential per cell (each cell thread walks all points in order).
@@ -181,7 +184,7 @@ void orc_elev_move(void* h, const float* pos3, float* central, int* start, float
 }
 
 /* T: row-major 4x4; 3-vectors and row-major 3x3 matrices as plain floats */
-void orc_elev_process_points(void* h, int n, float* px, float* py, float* pz, const float* T, double lower, double upper,
+void orc_elev_process_points(void* h, int n, const float* px, const float* py, const float* pz, const float* T, double lower, double upper,
                              float min_r, float beam_a, float beam_c, const float* sensorJacobian, const float* rotationVariance,
                              const float* C_SB_transpose, const float* P_mul_C_BM_transpose, const float* B_r_BS_skew,
                              int* map_index, float* var, float* xts, float* yts, float* zts)
@@ -218,8 +221,8 @@ void orc_elev_process_points(void* h, int n, float* px, float* py, float* pz, co
             map_index[i] = points_to_index(m, xts[i], yts[i], true);
             if (gi != -1 && height <= m.lowest[gi]) m.lowest[gi] = height + 3 * hv;
         } else {
-            map_index[i] = -1;
-            px[i] = py[i] = pz[i] = -1;
+            map_index[i] = -1;   // the kernel also overwrites its DEVICE copy of x, y, z with -1; Process_points never copies
+                                 // that back (gpu_process.cu:1119-1123), so the caller's arrays stay as they were
             xts[i] = yts[i] = zts[i] = -1;
             var[i] = -1;
         }

@@ -349,7 +349,8 @@ def se3_exp(a):
 
 # ------------------------------------------------------------------------------ elevation map
 class ElevMap:
-    """ctypes handle on oracle/elev_oracle.cpp (sequential restatement of gpu_process.cu; unpinned)."""
+    """ctypes handle on oracle/elev_oracle.cpp (sequential restatement of gpu_process.cu; pinned to the reference source
+    built for the host, RefElevMap below, by tests/test_oracle_elev.py)."""
 
     def __init__(self, length, resolution, mahal=2.0, obstacle=0.6):
         L = lib()
@@ -414,4 +415,68 @@ class ElevMap:
     def frame(self):
         c = np.zeros(2, np.float32); s = np.zeros(2, np.int32)
         self._l.orc_elev_get_frame(self._h, _p(c), _p(s))
+        return c, s
+
+
+class RefElevMap:
+    """The reference's own gpu_process.cu built for the host (oracle/_ref/libref_elev.so, oracle/ref_elev_shim.cpp), same
+    methods as ElevMap.  The reference keeps one map per process in module-scope variables: one live instance at a time."""
+
+    def __init__(self, length, resolution, mahal=2.0, obstacle=0.6):
+        self._l, self.L = ref_lib("elev"), int(length)
+        self._l.ref_elev_create(self.L, C.c_float(resolution), C.c_float(mahal), C.c_float(obstacle))
+
+    def move(self, pos3):
+        p = _f32(pos3); c = np.zeros(2, np.float32); s = np.zeros(2, np.int32); a = np.zeros(2, np.float32)
+        self._l.ref_elev_move(_p(p), _p(c), _p(s), _p(a))
+        return c, s, a
+
+    def process_points(self, x, y, z, T, lower, upper, min_r, beam_a, beam_c, sj, rv, csb, pmul, bskew):
+        x, y, z = _f32(x).copy(), _f32(y).copy(), _f32(z).copy()
+        n = x.size
+        mi = np.empty(n, np.int32)
+        var, xt, yt, zt = (np.empty(n, np.float32) for _ in range(4))
+        a = [_f32(T).reshape(16), _f32(sj).reshape(3), _f32(rv).reshape(9), _f32(csb).reshape(9), _f32(pmul).reshape(3), _f32(bskew).reshape(9)]
+        self._l.ref_elev_process_points(n, _p(x), _p(y), _p(z), _p(a[0]), C.c_double(lower), C.c_double(upper), C.c_float(min_r),
+                                        C.c_float(beam_a), C.c_float(beam_c), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), _p(a[5]),
+                                        _p(mi), _p(var), _p(xt), _p(yt), _p(zt))
+        return dict(map_index=mi, x=x, y=y, z=z, var=var, x_ts=xt, y_ts=yt, z_ts=zt)
+
+    def fuse(self, index, cr, cg, cb, inten, h, v):
+        arrs = [np.ascontiguousarray(index, np.int32), np.ascontiguousarray(cr, np.int32), np.ascontiguousarray(cg, np.int32),
+                np.ascontiguousarray(cb, np.int32), _f32(inten), _f32(h), _f32(v)]
+        self._l.ref_elev_fuse(arrs[0].size, *[_p(a) for a in arrs])
+
+    def mapvar_update(self, v):
+        self._l.ref_elev_mapvar_update(C.c_float(v))
+
+    def map_feature(self):
+        n = self.L * self.L
+        f = {k: np.zeros(n, np.float32) for k in ("elevation", "var", "rough", "slope", "traver", "intensity")}
+        f["traver"][:] = -10
+        c = {k: np.zeros(n, np.int32) for k in ("colorR", "colorG", "colorB")}
+        self._l.ref_elev_map_feature(_p(f["elevation"]), _p(f["var"]), _p(c["colorR"]), _p(c["colorG"]), _p(c["colorB"]),
+                                     _p(f["rough"]), _p(f["slope"]), _p(f["traver"]), _p(f["intensity"]))
+        f.update(c)
+        return f
+
+    def raytracing(self):
+        self._l.ref_elev_raytracing()
+
+    def map_optmove(self, p, dh):
+        a = np.zeros(2, np.float32)
+        self._l.ref_elev_map_optmove(_p(_f32(p)), C.c_float(dh), _p(a))
+        return a
+
+    def map_closeloop(self, p, dh):
+        self._l.ref_elev_map_closeloop(_p(_f32(p)), C.c_float(dh))
+
+    def layer(self, which):
+        out = np.empty(self.L * self.L, np.float32)
+        self._l.ref_elev_get(int(which), _p(out))
+        return out
+
+    def frame(self):
+        c = np.zeros(2, np.float32); s = np.zeros(2, np.int32)
+        self._l.ref_elev_get_frame(_p(c), _p(s))
         return c, s

@@ -1,5 +1,6 @@
 // oracle/ref_cuda_host/cuda_runtime.h -- TEST INFRASTRUCTURE ONLY.
-// Host stand-in for the handful of CUDA runtime names the reference's generate_bev_* sources use
+// Host stand-in for the handful of CUDA runtime names the reference's generate_bev_* sources (and, further down, its
+// elevation_mapping/cuda/gpu_process.cu) use
 // (cudaMalloc / cudaMemcpy / cudaFree / cudaDeviceSynchronize, __global__, threadIdx / blockIdx /
 // blockDim, dim3), so that their kernel.cu + manager.cu -- host-only logic apart from one <<<>>>
 // launch -- compile with g++ from where they lie under /root/reference.  oracle/Makefile rewrites the
@@ -17,6 +18,7 @@
 #define __global__
 #define __device__
 #define __host__
+#define __constant__
 
 struct dim3 {
     unsigned x, y, z;
@@ -53,3 +55,27 @@ inline const char* cudaGetErrorString(cudaError_t) { return "no error (host stan
                 kernel(__VA_ARGS__);                                           \
             }                                                                  \
     } while (0)
+
+// ---- additions for elevation_mapping/cuda/gpu_process.cu: module-scope __device__ / __constant__ variables become plain
+// globals, so the "symbol" copies are memcpy's on the variable itself; atomics are their sequential reading.
+template <class T>
+inline cudaError_t cudaMemcpyToSymbol(T& symbol, const void* src, size_t n, size_t offset = 0, cudaMemcpyKind = cudaMemcpyHostToDevice)
+{
+    std::memcpy(reinterpret_cast<char*>(&symbol) + offset, src, n);
+    return cudaSuccess;
+}
+template <class T>
+inline cudaError_t cudaMemcpyFromSymbol(void* dst, const T& symbol, size_t n, size_t offset = 0, cudaMemcpyKind = cudaMemcpyDeviceToHost)
+{
+    std::memcpy(dst, reinterpret_cast<const char*>(&symbol) + offset, n);
+    return cudaSuccess;
+}
+inline cudaError_t cudaMemset(void* p, int v, size_t n) { std::memset(p, v, n); return cudaSuccess; }
+inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
+inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
+inline int atomicCAS(int* a, int compare, int val) { const int old = *a; if (old == compare) *a = val; return old; }
+inline int atomicAdd(int* a, int v) { const int old = *a; *a = old + v; return old; }
+inline float atomicAdd(float* a, float v) { const float old = *a; *a = old + v; return old; }
+inline int atomicMax(int* a, int v) { const int old = *a; if (v > old) *a = v; return old; }
+inline int atomicMin(int* a, int v) { const int old = *a; if (v < old) *a = v; return old; }
+inline int atomicExch(int* a, int v) { const int old = *a; *a = v; return old; }

@@ -1,5 +1,7 @@
 """GPU parity for the elevation-mapping row N3: a multi-frame session (move, process, fuse, variance update,
-features, ray tracing, loop-closure shifts) replayed on the HIP library and on the sequential restatement."""
+features, ray tracing, loop-closure shifts) replayed on the HIP library, on the sequential restatement and on the
+reference's own gpu_process.cu built for the host (oracle/_ref/libref_elev.so; tests/test_oracle_elev.py pins the
+restatement to it on the CPU)."""
 import numpy as np
 import pytest
 
@@ -15,45 +17,7 @@ def dev():
     return "cuda:0"
 
 
-def _frame_points(rng, n, pose_xy):
-    """A terrain-like cloud in the sensor frame: points behind the robot (y < -1) survive the reference's filter."""
-    x = rng.uniform(-6, 6, n).astype(np.float32)
-    y = rng.uniform(-7, 2, n).astype(np.float32)
-    z = (0.15 * np.sin(0.8 * (x + pose_xy[0])) + 0.1 * np.cos(1.1 * (y + pose_xy[1])) - 0.6 + rng.normal(0, 0.02, n)).astype(np.float32)
-    bump = (np.abs(x - 2) < 0.4) & (np.abs(y + 4) < 0.4)
-    z[bump] += 0.8
-    return x, y, z
-
-
-def _session(m, rng, frames, L):
-    out = []
-    pose = np.array([0.0, 0.0, 0.9], np.float32)
-    for k in range(frames):
-        pose[:2] += rng.uniform(-0.5, 0.7, 2).astype(np.float32)
-        out.append(("move", m.move(pose)))
-        x, y, z = _frame_points(rng, 6000, pose)
-        yaw = 0.1 * k
-        T = np.eye(4, dtype=np.float32)
-        T[:2, :2] = [[np.cos(yaw), -np.sin(yaw)], [np.sin(yaw), np.cos(yaw)]]
-        T[:3, 3] = [pose[0], pose[1], 0.9]
-        rv = np.diag([1e-4, 1e-4, 4e-4]).astype(np.float32)
-        res = m.process_points(x, y, z, T, -2.0, 3.0, 0.02, 0.003, 0.01, [0.0, 0.0, 1.0], rv, np.eye(3), [0.0, 0.0, 1.0],
-                               [[0, -0.2, 0.1], [0.2, 0, -0.05], [-0.1, 0.05, 0]])
-        out.append(("points", res))
-        n = x.size
-        cr = rng.integers(0, 256, n); cg = rng.integers(0, 256, n); cb = rng.integers(0, 256, n)
-        inten = rng.uniform(0, 1, n).astype(np.float32)
-        m.fuse(res["map_index"], cr, cg, cb, inten, res["z_ts"], res["var"])
-        m.mapvar_update(1e-4)
-        out.append(("feature", m.map_feature()))
-        m.raytracing()
-        out.append(("layers", [m.layer(w) for w in range(5)]))
-        if k == 2:
-            out.append(("optmove", m.map_optmove(pose[:2] + 0.33, 0.05)))
-        if k == 3:
-            m.map_closeloop(pose[:2] - 0.41, -0.02)
-            out.append(("frame", m.frame()))
-    return out
+from elev_session import session as _session  # noqa: E402
 
 
 @pytest.mark.parametrize("L", [60, 61])
@@ -93,3 +57,32 @@ def test_session_matches_sequential_restatement(dev, oracle, L):
                 keep = same_empty & (a != -10)
                 np.testing.assert_allclose(a[keep], b[keep], rtol=2e-6, atol=5e-3)
     assert seen_cells > 300
+
+
+def test_session_matches_the_reference_source_built_for_the_host(dev, oracle):
+    """Same session, HIP library vs the reference's gpu_process.cu itself (host build, threads in gid order)."""
+    if oracle.ref_lib("elev") is None:
+        pytest.skip("oracle/_ref/libref_elev.so not built")
+    from mr_slam_amd import elevation
+    L = 60
+    got = _session(elevation.ElevationMap(L, 0.2), np.random.default_rng(3), 5, L)
+    want = _session(oracle.RefElevMap(L, 0.2), np.random.default_rng(3), 5, L)
+    for (kg, g), (kw, w) in zip(got, want):
+        assert kg == kw
+        if kg == "points":
+            for k in ("map_index", "x", "y", "z", "x_ts", "y_ts", "z_ts"):
+                np.testing.assert_array_equal(g[k], w[k])
+            np.testing.assert_allclose(g["var"], w["var"], rtol=1e-6, atol=1e-12)
+        elif kg == "feature":
+            seen = w["elevation"] != -10                       # elsewhere the reference's rough / slope / traver are uninitialised
+            np.testing.assert_array_equal(g["elevation"] != -10, seen)
+            for k in ("elevation", "var", "intensity"):
+                np.testing.assert_allclose(g[k], w[k], rtol=2e-6, atol=1e-7)
+            for k in ("colorR", "colorG", "colorB"):
+                np.testing.assert_array_equal(g[k], w[k])
+            np.testing.assert_allclose(g["rough"][seen], w["rough"][seen], rtol=1e-4, atol=1e-5)
+            ok = np.abs(g["slope"] - w["slope"])[seen] < 2e-3
+            assert ok.mean() > 0.995
+        elif kg in ("move", "frame"):
+            for a, b in zip(g, w):
+                np.testing.assert_allclose(a, b, rtol=0, atol=1e-6)
