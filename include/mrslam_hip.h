@@ -443,6 +443,14 @@ int mrs_disco_rel_ori_literal(mrs_ctx* ctx, const float* d_a, const float* d_b, 
 int mrs_signature_search(mrs_ctx* ctx, const float* d_query, int32_t n_query, const float* d_db, int32_t n_db, int32_t dim,
                          int32_t* d_index, float* d_dist2, mrs_stream stream);
 
+/* The k nearest signatures per query, ascending by squared distance (ties: lower index first): what
+ * kdtree_knn_search(kdtree, query, NUM_CANDIDATES_FROM_TREE) + kdtree_knn_result return (global_manager.cpp:1002-1007,
+ * src/kdtree.cpp:535-586; the reference reports sqrt of these distances and walks the list from entry 1, entry 0 being
+ * the query's own descriptor, global_manager.cpp:1136-1139).  1 <= k <= 32; d_index / d_dist2 are [n_query][k], rows past
+ * the database size hold -1 / +inf. */
+int mrs_signature_knn(mrs_ctx* ctx, const float* d_query, int32_t n_query, const float* d_db, int32_t n_db, int32_t dim, int32_t k,
+                      int32_t* d_index, float* d_dist2, mrs_stream stream);
+
 /* ------------------------------------------------------------------------------------
  * Elevation mapping: the nine functions of the reference's libgpu.so
  * (Mapping/src/elevation_mapping_periodical/elevation_mapping/cuda/gpu_process.cu:938-1312; declared by hand

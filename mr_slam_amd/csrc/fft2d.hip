@@ -241,8 +241,10 @@ __global__ __launch_bounds__(1024) void k_relori_argmax(const double2* __restric
 // distances are >= 0, so their bit patterns order like the values and ties go to the smaller index.
 constexpr int kSigTile = 64, kSigSlice = 16;
 
+// ALL: every distance goes to dmat[nq][n] (the k-nearest selection reads it) instead of the per-query minimum.
+template <bool ALL>
 __global__ __launch_bounds__(256) void k_signature_tile(const float* __restrict__ q, int nq, const float* __restrict__ db, int n,
-                                                        int dim, unsigned long long* __restrict__ best)
+                                                        int dim, unsigned long long* __restrict__ best, float* __restrict__ dmat)
 {
     __shared__ __attribute__((aligned(16))) float qs[kSigSlice][kSigTile];
     __shared__ __attribute__((aligned(16))) float rs[kSigSlice][kSigTile];
@@ -280,6 +282,18 @@ __global__ __launch_bounds__(256) void k_signature_tile(const float* __restrict_
                 }
         }
     }
+    if (ALL) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int qi = q0 + 4 * ty + a;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int row = r0 + 4 * tx + b;
+                if (qi < nq && row < n) dmat[(size_t)qi * n + row] = acc[a][b];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         unsigned long long key = ~0ull;
@@ -307,6 +321,53 @@ __global__ void k_signature_unpack(const unsigned long long* __restrict__ best, 
     if (i >= nq) return;
     out_idx[i] = (int)(unsigned)(best[i] & 0xffffffffull);
     out_d2[i] = __uint_as_float((unsigned)(best[i] >> 32));
+}
+
+// k smallest (distance, index) pairs of one row of the distance matrix, ascending; ties by the lower index.  One workgroup per
+// query: every thread keeps the KMAX best of its strided share as packed keys (distance bits << 32 | index; distances are
+// >= 0, so the unsigned order is the float order), then the 256 x KMAX keys are sorted in LDS (bitonic) and the first k leave.
+template <int KMAX>
+__global__ __launch_bounds__(256) void k_signature_select(const float* __restrict__ dmat, int n, int k, int* __restrict__ out_idx,
+                                                          float* __restrict__ out_d2)
+{
+    extern __shared__ unsigned long long keys[];   // 256 * KMAX
+    const int qi = blockIdx.x;
+    const float* row = dmat + (size_t)qi * n;
+    unsigned long long mine[KMAX];
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) mine[s] = ~0ull;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        unsigned long long key = ((unsigned long long)__float_as_uint(row[j]) << 32) | (unsigned)j;
+        if (key < mine[KMAX - 1]) {
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s) {   // sorted insertion, static register indices
+                const unsigned long long cur = mine[s];
+                const bool take = key < cur;
+                mine[s] = take ? key : cur;
+                key = take ? cur : key;
+            }
+        }
+    }
+    constexpr int N = 256 * KMAX;
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) keys[s * 256 + threadIdx.x] = mine[s];
+    __syncthreads();
+    for (int size = 2; size <= N; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = threadIdx.x; i < N / 2; i += 256) {
+                const int lo = (i / stride) * 2 * stride + (i % stride), hi = lo + stride;
+                const bool up = ((lo / size) & 1) == 0;
+                const unsigned long long a = keys[lo], b = keys[hi];
+                if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    if (threadIdx.x < k) {
+        const unsigned long long key = keys[threadIdx.x];
+        const bool none = key == ~0ull;                      // fewer than k database rows
+        out_idx[(size_t)qi * k + threadIdx.x] = none ? -1 : (int)(unsigned)(key & 0xffffffffull);
+        out_d2[(size_t)qi * k + threadIdx.x] = none ? INFINITY : __uint_as_float((unsigned)(key >> 32));
+    }
 }
 
 inline int grid_for(size_t n) { size_t b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b ? b : 1)); }
@@ -429,10 +490,40 @@ int mrs_signature_search(mrs_ctx* ctx, const float* d_query, int32_t n_query, co
     if (st != MRS_OK) return st;
     MRS_HIP_TRY(hipMemsetAsync(best.p, 0xff, (size_t)n_query * sizeof(unsigned long long), s));
     MRS_REQUIRE((n_query + kSigTile - 1) / kSigTile <= mrs::kMaxGridY, "too many queries per call (split the batch)");
-    hipLaunchKernelGGL(k_signature_tile, dim3((n_db + kSigTile - 1) / kSigTile, (n_query + kSigTile - 1) / kSigTile), dim3(256), 0, s,
-                       d_query, n_query, d_db, n_db, dim, best.as<unsigned long long>());
+    hipLaunchKernelGGL(k_signature_tile<false>, dim3((n_db + kSigTile - 1) / kSigTile, (n_query + kSigTile - 1) / kSigTile), dim3(256), 0, s,
+                       d_query, n_query, d_db, n_db, dim, best.as<unsigned long long>(), (float*)nullptr);
     hipLaunchKernelGGL(k_signature_unpack, dim3((n_query + 255) / 256), dim3(256), 0, s, best.as<unsigned long long>(), n_query,
                        d_index, d_dist2);
+    MRS_HIP_TRY(hipGetLastError());
+    return MRS_OK;
+}
+
+int mrs_signature_knn(mrs_ctx* ctx, const float* d_query, int32_t n_query, const float* d_db, int32_t n_db, int32_t dim, int32_t k,
+                      int32_t* d_index, float* d_dist2, mrs_stream stream)
+{
+    MRS_REQUIRE(ctx && d_query && d_db && d_index && d_dist2, "null pointer");
+    MRS_REQUIRE(n_query > 0 && n_db > 0 && dim > 0, "sizes must be positive");
+    MRS_REQUIRE(k >= 1 && k <= 32, "k must be in [1, 32]");
+    MRS_HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    MRS_REQUIRE((n_query + kSigTile - 1) / kSigTile <= mrs::kMaxGridY, "too many queries per call (split the batch)");
+    mrs::Scratch dmat;
+    int st = dmat.alloc((size_t)n_query * n_db * sizeof(float), s);
+    if (st != MRS_OK) return st;
+    hipLaunchKernelGGL(k_signature_tile<true>, dim3((n_db + kSigTile - 1) / kSigTile, (n_query + kSigTile - 1) / kSigTile), dim3(256), 0, s,
+                       d_query, n_query, d_db, n_db, dim, (unsigned long long*)nullptr, dmat.as<float>());
+    if (k <= 8) {
+        hipLaunchKernelGGL(k_signature_select<8>, dim3(n_query), dim3(256), 256 * 8 * sizeof(unsigned long long), s, dmat.as<float>(), n_db, k,
+                           d_index, d_dist2);
+    } else if (k <= 16) {
+        hipLaunchKernelGGL(k_signature_select<16>, dim3(n_query), dim3(256), 256 * 16 * sizeof(unsigned long long), s, dmat.as<float>(), n_db, k,
+                           d_index, d_dist2);
+    } else {
+        auto kern = k_signature_select<32>;
+        const size_t lds = 256 * 32 * sizeof(unsigned long long);
+        MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(n_query), dim3(256), lds, s, dmat.as<float>(), n_db, k, d_index, d_dist2);
+    }
     MRS_HIP_TRY(hipGetLastError());
     return MRS_OK;
 }

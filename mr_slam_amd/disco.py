@@ -75,3 +75,16 @@ def signature_search(query, db):
     _lib.check(_lib.load().mrs_signature_search(_lib.ctx(d), _lib.ptr(query), Q, _lib.ptr(db), db.shape[0], dim,
                                                 _lib.ptr(idx), _lib.ptr(d2), _lib.current_stream(d)))
     return idx, d2
+
+
+def signature_knn(query, db, k):
+    """The k nearest signatures, ascending (what the Mapping side asks its kd-tree for, global_manager.cpp:1002-1007):
+    query [Q,dim], db [N,dim] float32 device -> (index [Q,k] int32, dist2 [Q,k]); rows past N hold -1 / inf."""
+    d = _dev(query)
+    query, db = query.contiguous(), db.contiguous()
+    Q, dim = query.shape
+    idx = torch.empty((Q, k), dtype=torch.int32, device=query.device)
+    d2 = torch.empty((Q, k), dtype=torch.float32, device=query.device)
+    _lib.check(_lib.load().mrs_signature_knn(_lib.ctx(d), _lib.ptr(query), Q, _lib.ptr(db), db.shape[0], dim, int(k),
+                                             _lib.ptr(idx), _lib.ptr(d2), _lib.current_stream(d)))
+    return idx, d2

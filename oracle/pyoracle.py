@@ -480,3 +480,15 @@ class RefElevMap:
         c = np.zeros(2, np.float32); s = np.zeros(2, np.int32)
         self._l.ref_elev_get_frame(_p(c), _p(s))
         return c, s
+
+
+def ref_kdtree_knn(db, query, k):
+    """The reference's own kd-tree (Mapping/src/global_manager/src/kdtree.cpp built in place): k nearest rows of db [n][dim]
+    to query [dim] -> (index int64 [m], distance float32 [m] = Euclidean distance, nearest first), m <= k."""
+    L = ref_lib("kdtree")
+    db, query = _f32(db), _f32(query)
+    idx = np.zeros(k, np.int64); dist = np.zeros(k, np.float32)
+    L.ref_kdtree_knn.restype = C.c_int
+    m = L.ref_kdtree_knn(_p(db), int(db.shape[0]), int(db.shape[1]), _p(query), int(k), _p(idx), _p(dist))
+    m = min(int(m), k)
+    return idx[:m], dist[:m]

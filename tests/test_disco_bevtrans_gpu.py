@@ -131,3 +131,30 @@ def test_mapping_side_calc_rel_ori_and_signature_search(dev):
     # rotation invariance of the DiSCO signature: all three rotated copies are (near-)zero distance apart
     _, d2r = disco.signature_search(sig, sig[:1].contiguous())
     assert float(d2r.max()) < 1e-3 * float((sig ** 2).sum(1).max())
+
+
+def test_signature_knn_equals_the_reference_kdtree(dev, oracle):
+    """Row N4, the Mapping side's candidate query: the k = 10 nearest DiSCO signatures, ascending, vs the reference's own
+    kd-tree built in place (oracle/_ref/libref_kdtree.so) and vs float64 brute force."""
+    import torch
+    from mr_slam_amd import disco
+    rng = np.random.default_rng(11)
+    for n, dim, k in ((3000, 1024, 10), (777, 37, 10), (100, 1024, 32), (5, 64, 10)):
+        db = rng.normal(size=(n, dim)).astype(np.float32)
+        q = np.stack([db[rng.integers(n)] + 0.05 * rng.normal(size=dim).astype(np.float32) for _ in range(3)]
+                     + [rng.normal(size=dim).astype(np.float32)])
+        idx, d2 = disco.signature_knn(torch.from_numpy(q).to(dev), torch.from_numpy(db).to(dev), k)
+        idx, d2 = idx.cpu().numpy(), d2.cpu().numpy()
+        full = ((q[:, None, :].astype(np.float64) - db[None]) ** 2).sum(-1)
+        m = min(k, n)
+        order = np.argsort(full, axis=1, kind="stable")[:, :m]
+        np.testing.assert_array_equal(idx[:, :m], order)
+        np.testing.assert_allclose(d2[:, :m], np.take_along_axis(full, order, 1), rtol=2e-5)
+        assert (idx[:, m:] == -1).all() and np.isinf(d2[:, m:]).all()
+        one_i, one_d = disco.signature_search(torch.from_numpy(q).to(dev), torch.from_numpy(db).to(dev))
+        assert np.array_equal(one_i.cpu().numpy(), idx[:, 0]) and np.array_equal(one_d.cpu().numpy(), d2[:, 0])   # same tile kernel
+        if oracle.ref_lib("kdtree") is not None:
+            for i in range(q.shape[0]):
+                ri, rd = oracle.ref_kdtree_knn(db, q[i], k)
+                np.testing.assert_array_equal(idx[i, :len(ri)], ri)
+                np.testing.assert_allclose(np.sqrt(d2[i, :len(ri)]), rd, rtol=2e-5)
