@@ -492,3 +492,14 @@ def ref_kdtree_knn(db, query, k):
     m = L.ref_kdtree_knn(_p(db), int(db.shape[0]), int(db.shape[1]), _p(query), int(k), _p(idx), _p(dist))
     m = min(int(m), k)
     return idx[:m], dist[:m]
+
+
+def ref_calc_rel_ori(a, b):
+    """GlobalManager::calcRelOri as the reference wrote it (global_manager.cpp:2719-2762 cut out by oracle/Makefile and built with
+    stand-ins for FFTW and Eigen::VectorXf -> oracle/_ref/libref_relori.so): a, b complex [height][width] -> degrees."""
+    L = ref_lib("relori")
+    a, b = np.asarray(a), np.asarray(b)
+    h, w = a.shape
+    ra, ia, rb, ib = (_f32(x).reshape(-1) for x in (a.real, a.imag, b.real, b.imag))
+    L.ref_calc_rel_ori.restype = C.c_float
+    return float(L.ref_calc_rel_ori(_p(ra), _p(ia), _p(rb), _p(ib), int(h), int(w)))

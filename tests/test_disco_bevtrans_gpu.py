@@ -97,7 +97,7 @@ def test_solve_translation_bev_matches_restatement(dev):
     assert (y1, x1) == (y[0], x[0])
 
 
-def test_mapping_side_calc_rel_ori_and_signature_search(dev):
+def test_mapping_side_calc_rel_ori_and_signature_search(dev, oracle):
     """Row N4: calcRelOri literal (global_manager.cpp:2719-2762) and the kd-tree's job (1-NN over signatures)."""
     import torch
     from mr_slam_amd import disco
@@ -113,6 +113,8 @@ def test_mapping_side_calc_rel_ori_and_signature_search(dev):
         cross = (ra * rb + ia * ib).astype(np.float64) + 1j * (ra * ib + rb * ia).astype(np.float64)
         real = (np.fft.ifft2(cross) * cross.size).real.astype(np.float32)
         assert got[i] == float(int(np.argmax(real)) % 120) * 3.0
+        if oracle.ref_lib("relori") is not None:      # the reference's own calcRelOri (host build with FFTW / Eigen stand-ins)
+            assert got[i] == oracle.ref_calc_rel_ori(A[i], B[i])
     # signature search: noisy copies of database entries must find their originals (exact brute force)
     dbn = rng.normal(size=(500, 1024)).astype(np.float32)
     pick = np.array([17, 499, 0, 256])
