@@ -503,3 +503,20 @@ def ref_calc_rel_ori(a, b):
     ra, ia, rb, ib = (_f32(x).reshape(-1) for x in (a.real, a.imag, b.real, b.imag))
     L.ref_calc_rel_ori.restype = C.c_float
     return float(L.ref_calc_rel_ori(_p(ra), _p(ia), _p(rb), _p(ib), int(h), int(w)))
+
+
+def ref_radon_parallel(img, angles, det, spacing=1.0, weight_bits=8):
+    """The reference's own Radon kernel (torch-radon/src/forward.cu:12-124, cut out at build time and run on the host with the
+    texture fetch the CUDA guide documents: oracle/_ref/libref_radon.so).  weight_bits = 8: the texture unit's 1.8 fixed-point
+    interpolation weights; 0: fp32 fractions.  img [B,H,W] or [H,W] -> sinogram [B,n_angles,det]."""
+    L = ref_lib("radon")
+    img = _f32(img)
+    squeeze = img.ndim == 2
+    if squeeze:
+        img = img[None]
+    B, H, W = img.shape
+    ang = _f32(angles)
+    out = np.empty((B, ang.size, det), np.float32)
+    L.ref_radon_set_weight_bits(int(weight_bits))
+    L.ref_radon_parallel(_p(img), B, H, W, _p(ang), ang.size, det, C.c_float(spacing), _p(out))
+    return out[0] if squeeze else out
