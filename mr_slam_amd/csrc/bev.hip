@@ -478,6 +478,9 @@ __global__ void k_polar_kth(const float* __restrict__ xyz, const int64_t* __rest
         const int lin = polar_lin(p, v.px[i], v.py[i], v.pz[i]);
         if (lin < 0) continue;
         if (prev && i <= prev[lin]) continue;
+        // a plain (possibly stale, i.e. too large) read first: points arrive roughly in index order, so after the first few
+        // a hot cell no longer sees same-address atomics queueing up in L2
+        if (__atomic_load_n(&cur[lin], __ATOMIC_RELAXED) <= i) continue;
         atomicMin(&cur[lin], i);
     }
 }
@@ -510,15 +513,18 @@ __global__ void k_cart_pass1(const float* __restrict__ xyz, const int64_t* __res
     last_idx += b * cells;
     zbits += b * cells;
     if (first_pos) first_pos += b * cells;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < v.n; i += gridDim.x * blockDim.x) {
+    // LAST point per cell: walk the scan from its end, so that the first arrival at a hot cell already holds (nearly) the final
+    // answer and the plain (possibly stale, i.e. too small) read lets the rest skip their same-address atomics
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < v.n; g += gridDim.x * blockDim.x) {
+        const int i = v.n - 1 - g;
         int col;
         const float z = v.pz[i];
         const int lin = cart_lin(p, v.px[i], v.py[i], z, col);
         if (lin < 0) continue;
-        atomicMax(&last_idx[lin], i);
+        if (__atomic_load_n(&last_idx[lin], __ATOMIC_RELAXED) < i) atomicMax(&last_idx[lin], i);
         if (z > 0.0f) {
             if (first_pos) atomicMin(&first_pos[lin], i);
-            else atomicMax(&zbits[lin], __float_as_int(z));
+            else if (__atomic_load_n(&zbits[lin], __ATOMIC_RELAXED) < __float_as_int(z)) atomicMax(&zbits[lin], __float_as_int(z));
         }
     }
 }
@@ -590,9 +596,9 @@ __global__ void k_feat_max(const float* __restrict__ pts, const int64_t* __restr
         if (lin < 0) continue;
         for (int j = COMPACT ? 3 : 0; j < p.F; ++j) {
             const float f = v.px[i + (size_t)j * v.n];
-            if (f > 0.0f) {
-                if (COMPACT) atomicMax(&dst[(size_t)(j - 3) * cells + lin], __float_as_int(f));
-                else atomicMax(&dst[(size_t)lin * p.F + j], __float_as_int(f));
+            if (f > 0.0f) {   // most points do not raise a cell's maximum: plain (possibly stale = too small) read before the atomic
+                int* cell = COMPACT ? &dst[(size_t)(j - 3) * cells + lin] : &dst[(size_t)lin * p.F + j];
+                if (__atomic_load_n(cell, __ATOMIC_RELAXED) < __float_as_int(f)) atomicMax(cell, __float_as_int(f));
             }
         }
     }

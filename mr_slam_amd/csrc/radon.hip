@@ -361,6 +361,28 @@ __global__ __launch_bounds__(kRadonWG) void k_radon(const float* __restrict__ im
     normalize_store<MAX_RAYS_PER_LANE>(val, rays, red, sino_norm + (size_t)b * rays, degenerate);
 }
 
+// Few images (a rospy callback hands over ONE): grid = (slices of 1024 rays, images), every workgroup stages the image and each
+// lane traces a single ray, so that one image occupies 15 workgroups instead of one; k_normalize (same lane <-> ray mapping and
+// reduction order as normalize_store: identical bits) follows.
+template <int STRIDE>
+__global__ __launch_bounds__(kRadonWG) void k_radon_split(const float* __restrict__ img, RadonP p, float* __restrict__ sino_raw)
+{
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const int b = blockIdx.y;
+    const float* src = img + (size_t)b * p.H * p.W;
+    const int rows = p.H + 2 * kPad;
+    for (int i = threadIdx.x; i < rows * p.stride; i += kRadonWG) tile[i] = 0.0f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < p.H * p.W; i += kRadonWG) {
+        const int y = i / p.W, x = i - y * p.W;
+        tile[(y + kPad) * p.stride + x + kPad] = src[i];
+    }
+    __syncthreads();
+    const int rays = p.A * p.D;
+    const int ray = blockIdx.x * kRadonWG + threadIdx.x;
+    if (ray < rays) sino_raw[(size_t)b * rays + ray] = trace_ray<STRIDE>(tile, p, ray);
+}
+
 // Two images per workgroup (see march2).  grid = ceil(batch / 2); an odd batch leaves the last workgroup's second slot
 // empty (zero image, nothing stored).
 template <int MAX_RAYS_PER_LANE, int STRIDE>
@@ -614,7 +636,21 @@ int mrs_radon_forward(mrs_radon_plan* plan, const float* d_img, int32_t batch, f
         MRS_HIP_TRY(hipGetLastError());
         return MRS_OK;
     }
-    if (per_lane <= 16 && plan->two_in_lds && batch > 1) {
+    if (per_lane <= 16 && batch <= 128) {
+        // latency path: spread every image over ceil(rays / 1024) workgroups
+        mrs::Scratch tmp;
+        float* raw = d_sino;
+        if (!raw) {
+            int st = tmp.alloc((size_t)batch * rays * sizeof(float), s);
+            if (st != MRS_OK) return st;
+            raw = tmp.as<float>();
+        }
+        auto kern = p.stride == 125 ? k_radon_split<125> : k_radon_split<0>;
+        if (lds > 48 * 1024)
+            MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(per_lane, batch), dim3(kRadonWG), lds, s, d_img, p, raw);
+        if (d_sino_norm) hipLaunchKernelGGL(k_normalize, dim3(batch), dim3(1024), 0, s, raw, d_sino_norm, rays, plan->d_degenerate);
+    } else if (per_lane <= 16 && plan->two_in_lds && batch > 1) {
         // two images per workgroup share the per-sample index arithmetic (march2)
         auto kern = per_lane <= 15 ? (p.stride == 125 ? k_radon2<15, 125> : k_radon2<15, 0>) : k_radon2<16, 0>;
         if (2 * lds > 48 * 1024)

@@ -415,23 +415,24 @@ def test_blank_scan_is_reported_not_silently_nan(dev):
 
 
 def test_two_images_per_workgroup_equal_one_image_per_workgroup(dev, oracle):
-    """k_radon2 (pairs of images interleaved in the LDS) == k_radon (one image) == the checker, bit for bit, for even and odd
-    batches."""
+    """The three LDS kernels give the same bits, raw and normalised: k_radon2 (batches > 128: pairs of images interleaved in
+    the LDS; even and odd batch), k_radon_split + k_normalize (batches <= 128: one image over 15 workgroups), and the checker."""
     import torch
     from mr_slam_amd import ring
     rng = np.random.default_rng(5)
-    imgs = (rng.random((7, 120, 120)) * (rng.random((7, 120, 120)) < 0.3)).astype(np.float32)
+    imgs = (rng.random((131, 120, 120)) * (rng.random((131, 120, 120)) < 0.3)).astype(np.float32)
     t = torch.from_numpy(imgs).to(dev)
     plan = ring.ring_plan(0)
-    s7, n7 = plan.forward(t, raw=True, normalized=True)
-    singles = [plan.forward(t[i:i + 1], raw=True, normalized=True) for i in range(7)]
+    s_odd, n_odd = plan.forward(t, raw=True, normalized=True)               # 131 images: k_radon2, last workgroup half empty
+    s_even, n_even = plan.forward(t[:130], raw=True, normalized=True)       # 130 images: k_radon2
+    assert torch.equal(s_even, s_odd[:130]) and torch.equal(n_even, n_odd[:130])
     ang = np.linspace(0, 2 * np.pi, 120).astype(np.float32)
-    want = oracle.radon_parallel(imgs, ang, 120, 1.0)
-    np.testing.assert_array_equal(s7.cpu().numpy(), want)
-    for i in range(7):
-        assert torch.equal(singles[i][0][0], s7[i]) and torch.equal(singles[i][1][0], n7[i])
-    s6, n6 = plan.forward(t[:6], raw=True, normalized=True)
-    assert torch.equal(s6, s7[:6]) and torch.equal(n6, n7[:6])
+    np.testing.assert_array_equal(s_odd[:9].cpu().numpy(), oracle.radon_parallel(imgs[:9], ang, 120, 1.0))
+    for lo, hi in ((0, 1), (1, 8), (8, 131 - 3), (130, 131)):             # 1, 7, 120 and 1 images: the split path
+        s, n = plan.forward(t[lo:hi], raw=True, normalized=True)
+        assert torch.equal(s, s_odd[lo:hi]) and torch.equal(n, n_odd[lo:hi])
+    only_norm = plan.forward(t[3:4], raw=False, normalized=True)[1]
+    assert torch.equal(only_norm, n_odd[3:4])
 
 
 def test_spectrum_corr_pairs_db_indexes_the_database_and_flags_missing_rows(dev):
