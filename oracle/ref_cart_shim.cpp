@@ -2,7 +2,7 @@
 // extern "C" handle around the reference's own Cartesian max-z rasteriser (module `voxelocc`), compiled from
 //   /root/reference/LoopDetection/generate_bev_cython_binary/src/{kernel.cu, manager.cu, manager.hh}
 // where they lie: oracle/Makefile rewrites the single <<<>>> launch of manager.cu into a host loop in a scratch
-// copy (oracle/_ref/build/cart/manager_host.cpp, git-ignored) and supplies oracle/ref_cuda_host/cuda_runtime.h.
+// copy (oracle/_ref/build/cart/manager_host.cpp, git-ignored, deleted again after linking) and supplies oracle/ref_cuda_host/cuda_runtime.h.
 // Built into oracle/_ref/libref_cart.so.  Pins oracle/bev_oracle.c rows A3 / A4.
 #include <manager_host.cpp>   // = the reference's manager.cu with the launch rewritten; pulls in kernel.cu, manager.hh
 

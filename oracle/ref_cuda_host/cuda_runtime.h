@@ -5,7 +5,7 @@
 // blockDim, dim3), so that their kernel.cu + manager.cu -- host-only logic apart from one <<<>>>
 // launch -- compile with g++ from where they lie under /root/reference.  oracle/Makefile rewrites the
 // launch `kernel<<<grid, block>>>(args)` into REF_LAUNCH(kernel, grid, block, args) in a scratch copy
-// under oracle/_ref/build/ (git-ignored); REF_LAUNCH runs the "threads" one after another in gid order,
+// under oracle/_ref/build/ (git-ignored, deleted again after linking); REF_LAUNCH runs the "threads" one after another in gid order,
 // i.e. the sequential reading of the kernel.  cudaFree tolerates the reference's double free
 // (generate_bev_cython_binary/src/manager.cu:87-90 and :94-99 free the same four buffers).
 #pragma once

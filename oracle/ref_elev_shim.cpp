@@ -6,7 +6,7 @@
 // REF_LAUNCH (threads one after another in gid order = the sequential reading of the kernels' racy updates);
 // ref_cuda_host/cuda_runtime.h supplies cudaMalloc / cudaMemcpy[To|From]Symbol / atomics, ref_cuda_host/Eigen/Core the few
 // fixed-size Eigen operations used (neither CUDA nor Eigen is in this image).  Nothing of the reference is copied into the
-// repository: the scratch copy lives under oracle/_ref/build/ (git-ignored).
+// repository: the scratch copy lives under oracle/_ref/build/ (git-ignored, deleted again after linking).
 // The reference keeps ONE map in module-scope variables: handles are not supported, create() re-initialises it.
 #include "gpu_process_host.cpp"
 

@@ -1,7 +1,7 @@
 // oracle/ref_radon_shim.cpp -- TEST INFRASTRUCTURE ONLY.
 // The reference's own Radon forward kernel (LoopDetection/torch-radon/src/forward.cu:12-124, `radon_forward_kernel`), run on the
 // host: oracle/Makefile cuts the kernel (and the two configuration constructors, src/parameter_classes.cu:6-23) out of the
-// reference files into scratch includes under oracle/_ref/build/radon/ (git-ignored), this file supplies the CUDA names around
+// reference files into scratch includes under oracle/_ref/build/radon/ (git-ignored, deleted again after linking), this file supplies the CUDA names around
 // it (ref_cuda_host/cuda_runtime.h: threadIdx / blockIdx ...; ref_cuda_host/ref_texture.h: the texture fetch as the CUDA guide
 // documents it) and runs one "thread" per (ray, angle, image).  The configuration classes are the reference's own header.
 #include <stdlib.h>
