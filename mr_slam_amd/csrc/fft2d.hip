@@ -506,23 +506,29 @@ int mrs_signature_knn(mrs_ctx* ctx, const float* d_query, int32_t n_query, const
     MRS_REQUIRE(k >= 1 && k <= 32, "k must be in [1, 32]");
     MRS_HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
-    MRS_REQUIRE((n_query + kSigTile - 1) / kSigTile <= mrs::kMaxGridY, "too many queries per call (split the batch)");
+    // the distance matrix of a chunk of queries stays below 1 GiB (256 M floats): 2 560 queries at a time against 100 k rows
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_query, ((size_t)1 << 28) / (size_t)n_db));
+    MRS_REQUIRE((chunk + kSigTile - 1) / kSigTile <= mrs::kMaxGridY, "too many queries per call (split the batch)");
     mrs::Scratch dmat;
-    int st = dmat.alloc((size_t)n_query * n_db * sizeof(float), s);
+    int st = dmat.alloc((size_t)chunk * n_db * sizeof(float), s);
     if (st != MRS_OK) return st;
-    hipLaunchKernelGGL(k_signature_tile<true>, dim3((n_db + kSigTile - 1) / kSigTile, (n_query + kSigTile - 1) / kSigTile), dim3(256), 0, s,
-                       d_query, n_query, d_db, n_db, dim, (unsigned long long*)nullptr, dmat.as<float>());
-    if (k <= 8) {
-        hipLaunchKernelGGL(k_signature_select<8>, dim3(n_query), dim3(256), 256 * 8 * sizeof(unsigned long long), s, dmat.as<float>(), n_db, k,
-                           d_index, d_dist2);
-    } else if (k <= 16) {
-        hipLaunchKernelGGL(k_signature_select<16>, dim3(n_query), dim3(256), 256 * 16 * sizeof(unsigned long long), s, dmat.as<float>(), n_db, k,
-                           d_index, d_dist2);
-    } else {
-        auto kern = k_signature_select<32>;
-        const size_t lds = 256 * 32 * sizeof(unsigned long long);
-        MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(n_query), dim3(256), lds, s, dmat.as<float>(), n_db, k, d_index, d_dist2);
+    for (int q0 = 0; q0 < n_query; q0 += chunk) {
+        const int nq = std::min(chunk, n_query - q0);
+        const float* q = d_query + (size_t)q0 * dim;
+        int32_t* oi = d_index + (size_t)q0 * k;
+        float* od = d_dist2 + (size_t)q0 * k;
+        hipLaunchKernelGGL(k_signature_tile<true>, dim3((n_db + kSigTile - 1) / kSigTile, (nq + kSigTile - 1) / kSigTile), dim3(256), 0, s, q, nq,
+                           d_db, n_db, dim, (unsigned long long*)nullptr, dmat.as<float>());
+        if (k <= 8) {
+            hipLaunchKernelGGL(k_signature_select<8>, dim3(nq), dim3(256), 256 * 8 * sizeof(unsigned long long), s, dmat.as<float>(), n_db, k, oi, od);
+        } else if (k <= 16) {
+            hipLaunchKernelGGL(k_signature_select<16>, dim3(nq), dim3(256), 256 * 16 * sizeof(unsigned long long), s, dmat.as<float>(), n_db, k, oi, od);
+        } else {
+            auto kern = k_signature_select<32>;
+            const size_t lds = 256 * 32 * sizeof(unsigned long long);
+            MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(nq), dim3(256), lds, s, dmat.as<float>(), n_db, k, oi, od);
+        }
     }
     MRS_HIP_TRY(hipGetLastError());
     return MRS_OK;

@@ -160,3 +160,19 @@ def test_signature_knn_equals_the_reference_kdtree(dev, oracle):
                 ri, rd = oracle.ref_kdtree_knn(db, q[i], k)
                 np.testing.assert_array_equal(idx[i, :len(ri)], ri)
                 np.testing.assert_allclose(np.sqrt(d2[i, :len(ri)]), rd, rtol=2e-5)
+
+
+def test_signature_knn_in_query_chunks(dev):
+    """More queries than one distance-matrix chunk holds (2^28 floats): the chunked calls give what single-query calls give."""
+    import torch
+    from mr_slam_amd import disco
+    g = torch.Generator(device=dev).manual_seed(3)
+    db = torch.randn((70000, 32), device=dev, generator=g)
+    q = torch.randn((4000, 32), device=dev, generator=g)            # 4000 x 70000 > 2^28: two chunks of 3834 + 166 queries
+    idx, d2 = disco.signature_knn(q, db, 5)
+    for i in (0, 3833, 3834, 3999):
+        one_i, one_d = disco.signature_knn(q[i:i + 1], db, 5)
+        assert torch.equal(one_i[0], idx[i]) and torch.equal(one_d[0], d2[i])
+    full = torch.cdist(q[3990:].double(), db.double()) ** 2
+    assert torch.equal(torch.topk(full, 5, dim=1, largest=False).indices.int(), idx[3990:])
+
