@@ -37,7 +37,14 @@ from mr_slam_amd import bev, ring, shard, synth  # noqa: E402
 N_POINTS = 120_000
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
 DIST_THRESHOLD = 0.48     # RING_ros/config.py:17
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+def _latest_pmc():
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc.json")))      # the newest round's counter passes
+    return files[-1] if files else os.path.join(ROOT, "profiles", "r02_pmc.json")
+
+
+PMC_FILE = _latest_pmc()
+PMC_NAME = os.path.relpath(PMC_FILE, ROOT)
 
 
 def make_shard(batch, chunks, rank, device):
@@ -570,7 +577,7 @@ def main():
             "roofline": {"kernel": "k_cart_lds (BEV scatter)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc.get("k_cart_lds", {}).get("hbm_bytes"), "algorithmic_bytes_per_launch": bev_bytes,
-                         "traffic_source": "profiles/r02_pmc.json (rocprofv3 --pmc passes of tools/pmc_targets.py)" if pmc.get("k_cart_lds") else None},
+                         "traffic_source": PMC_NAME + " (rocprofv3 --pmc passes of tools/pmc_targets.py)" if pmc.get("k_cart_lds") else None},
             "gicp": gicp_res,
         }
         if dist_on:
@@ -596,7 +603,7 @@ def main():
                                       "ms": kern_ms["radon"], "samples_per_s": samples / (kern_ms["radon"] * 1e-3),
                                       "valu_issue_frac": r.get("valu_issue_frac"), "lds_busy_frac": r.get("lds_busy_frac"),
                                       "lds_bank_conflict_frac_of_lds": r.get("lds_bank_conflict_frac"),
-                                      "hbm_bytes": r.get("hbm_bytes"), "source": "profiles/r02_pmc.json" if r else None}
+                                      "hbm_bytes": r.get("hbm_bytes"), "source": PMC_NAME if r else None}
             # the same box's device-to-device copy rate next to the nominal peak (a copy moves 2 bytes per byte copied)
             src_buf = chunks[0][0]
             dst_buf = torch.empty_like(src_buf)
