@@ -4,7 +4,7 @@
 // set_input_source / set_num_threads / set_max_correspondence_distance / set_correspondence_randomness / align /
 // get_final_transformation / get_fitness_score / has_converged, and the convenience align_points().  Bound to
 // libmrslam_hip.so through the C ABI; points travel as float64 [N,3] numpy arrays like upstream's Eigen::Matrix<double,-1,3>.
-// pybind11 + the HIP runtime API (upload of the points) only: g++ -lmrslam_hip -lamdhip64.
+// pybind11 + the C ABI only (host arrays in and out): g++ -lmrslam_hip.
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 
@@ -14,8 +14,6 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
-
-#include <hip/hip_runtime_api.h>
 
 #include "mrslam_hip.h"
 
@@ -28,11 +26,6 @@ void check(int st, const char* what)
 {
     if (st != MRS_OK) throw std::runtime_error(std::string(what) + ": " + mrs_status_str(st) + ": " + mrs_last_error());
 }
-void hip_check(hipError_t e, const char* what)
-{
-    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
-}
-
 mrs_ctx* ctx()
 {
     static mrs_ctx* c = nullptr;
@@ -41,22 +34,6 @@ mrs_ctx* ctx()
     if (!c) check(mrs_ctx_create(0, &c), "mrs_ctx_create");
     return c;
 }
-
-struct DeviceBuffer {   // grown on demand, freed with its owner
-    void* p = nullptr;
-    size_t bytes = 0;
-    void* reserve(size_t n)
-    {
-        if (n > bytes) {
-            if (p) (void)hipFree(p);
-            p = nullptr;
-            hip_check(hipMalloc(&p, n + n / 4), "hipMalloc");
-            bytes = n + n / 4;
-        }
-        return p;
-    }
-    ~DeviceBuffer() { if (p) (void)hipFree(p); }
-};
 
 void require_points(const Points& a)
 {
@@ -69,15 +46,12 @@ Points downsample(const Points& points, double resolution)
     require_points(points);
     const int64_t n = points.shape(0), stride = points.shape(1);
     if (n == 0) return Points(std::vector<py::ssize_t>{0, 3});
-    mrs_ctx* c = ctx();
-    DeviceBuffer in, out;
-    hip_check(hipMemcpy(in.reserve((size_t)n * stride * 8), points.data(), (size_t)n * stride * 8, hipMemcpyHostToDevice), "upload");
-    out.reserve((size_t)n * 3 * 8);
+    std::vector<double> out((size_t)n * 3);
     int32_t count = 0;
-    check(mrs_voxel_downsample_approx(c, in.p, 1, (int32_t)stride, (int32_t)n, resolution, static_cast<double*>(out.p), &count, nullptr),
-          "mrs_voxel_downsample_approx");
+    check(mrs_voxel_downsample_approx_host(ctx(), points.data(), 1, (int32_t)stride, (int32_t)n, resolution, out.data(), &count),
+          "mrs_voxel_downsample_approx_host");
     Points res(std::vector<py::ssize_t>{count, 3});
-    if (count) hip_check(hipMemcpy(res.mutable_data(), out.p, (size_t)count * 3 * 8, hipMemcpyDeviceToHost), "download");
+    for (int64_t i = 0; i < (int64_t)count * 3; ++i) res.mutable_data()[i] = out[i];
     return res;
 }
 
@@ -136,13 +110,11 @@ private:
         std::vector<float> f((size_t)n * 3);
         for (int64_t i = 0; i < n; ++i)
             for (int c = 0; c < 3; ++c) f[(size_t)i * 3 + c] = (float)p.data()[i * stride + c];      // upstream narrows to pcl::PointXYZ
-        hip_check(hipMemcpy(stage_.reserve(f.size() * 4 + 16), f.data(), f.size() * 4, hipMemcpyHostToDevice), "upload");
         const int64_t offs[2] = {0, n};
-        check(mrs_gicp_batch_set_clouds(h_, which, static_cast<const float*>(stage_.p), 3, offs, nullptr), "mrs_gicp_batch_set_clouds");
+        check(mrs_gicp_batch_set_clouds_host(h_, which, f.data(), 3, offs), "mrs_gicp_batch_set_clouds_host");
     }
     mrs_gicp_batch* h_ = nullptr;
     mrs_gicp_params prm_;
-    DeviceBuffer stage_;
     double final_[16];
     bool converged_ = false;
     int iterations_ = 0;

@@ -25,7 +25,6 @@
 
 #include "mrslam_hip.h"
 
-#include <hip/hip_runtime_api.h>  // hipMalloc / hipMemcpy for the point upload
 
 namespace fast_gicp {
 
@@ -65,7 +64,6 @@ public:
     {
         mrs_gicp_batch_destroy(h_);
         mrs_ctx_destroy(ctx_);
-        if (stage_) (void)hipFree(stage_);
     }
     FastGICP(const FastGICP&) = delete;
     FastGICP& operator=(const FastGICP&) = delete;
@@ -128,20 +126,12 @@ private:
     template <class Cloud>
     void upload(int which, const Cloud& cloud)
     {
-        // PCL points are 16-byte aligned structs whose first three floats are x, y, z
+        // PCL points are 16-byte aligned structs whose first three floats are x, y, z; the library stages the host array through
+        // its own scratch cache (no allocation per call once warm)
         const int stride = static_cast<int>(sizeof(typename Cloud::PointType) / sizeof(float));
-        const size_t bytes = cloud.points.size() * sizeof(typename Cloud::PointType);
-        if (bytes > stage_bytes_) {   // one staging buffer per object, grown on demand (no hipMalloc / hipFree per call)
-            if (stage_) (void)hipFree(stage_);
-            stage_ = nullptr; stage_bytes_ = 0;
-            if (hipMalloc(reinterpret_cast<void**>(&stage_), bytes + bytes / 4) != hipSuccess)
-                throw std::runtime_error("FastGICP(mrslam_hip): staging allocation failed");
-            stage_bytes_ = bytes + bytes / 4;
-        }
-        if (hipMemcpy(stage_, cloud.points.data(), bytes, hipMemcpyHostToDevice) != hipSuccess)
-            throw std::runtime_error("FastGICP(mrslam_hip): point upload failed");
         const int64_t offs[2] = {0, static_cast<int64_t>(cloud.points.size())};
-        check(mrs_gicp_batch_set_clouds(h_, which, stage_, stride, offs, nullptr), "mrs_gicp_batch_set_clouds");   // copies out of the staging buffer
+        check(mrs_gicp_batch_set_clouds_host(h_, which, reinterpret_cast<const float*>(cloud.points.data()), stride, offs),
+              "mrs_gicp_batch_set_clouds_host");
     }
     template <class M>
     static void to_row_major(const M& m, double* out)
@@ -159,8 +149,6 @@ private:
     mrs_gicp_batch* h_ = nullptr;
     mrs_gicp_params prm_;
     double hessian_[36] = {0};
-    float* stage_ = nullptr;
-    size_t stage_bytes_ = 0;
 };
 
 // Drop-in for fast_gicp::FastVGICPCuda (the launch-file default `registration_method=FAST_VGICP_CUDA`,

@@ -262,6 +262,11 @@ int mrs_gicp_batch_set_params(mrs_gicp_batch* h, const mrs_gicp_params* p);
 int mrs_gicp_batch_set_clouds(mrs_gicp_batch* h, int32_t which, const float* d_points, int32_t stride_floats,
                               const int64_t* h_offsets, mrs_stream stream);
 
+/* The same with the points in HOST memory (the form a pcl::PointCloud / numpy caller has: setInputSource / setInputTarget of
+ * the C++ adapter, pygicp.FastGICP.set_input_*): staged through the library's scratch cache, synchronous. */
+int mrs_gicp_batch_set_clouds_host(mrs_gicp_batch* h, int32_t which, const float* h_points, int32_t stride_floats,
+                                   const int64_t* h_offsets);
+
 /* G2: FastGICP::calculate_covariances (brute-force kNN, PLANE regularisation).  Called lazily
  * by align; exposed so that it can be timed / cached per submap.  d_knn_out (optional, may be
  * NULL): int32[total_points][k] neighbour indices (cloud-local, ascending distance). */
@@ -416,6 +421,9 @@ int mrs_voxel_downsample(mrs_ctx* ctx, const void* d_points, int32_t is_double, 
  * filter bit for bit, order included.  Synchronises `stream`. */
 int mrs_voxel_downsample_approx(mrs_ctx* ctx, const void* d_points, int32_t is_double, int32_t stride, int32_t n,
                                 double leaf_size, double* d_out, int32_t* h_count, mrs_stream stream);
+/* host arrays in and out (pygicp.downsample's calling convention); h_out: room for n x 3 doubles */
+int mrs_voxel_downsample_approx_host(mrs_ctx* ctx, const void* h_points, int32_t is_double, int32_t stride, int32_t n,
+                                     double leaf_size, double* h_out, int32_t* h_count);
 
 /* load_pc_infer (RING_ros/util.py:91-112, disco_ros/main.py:94-113) for a batch of raw clouds: float32
  * cast, keep |x|,|y| < 70 and 0 < z < 30, divide by 70/70/30.  Raw cloud b = points

@@ -1702,6 +1702,24 @@ int mrs_gicp_batch_set_clouds(mrs_gicp_batch* h, int32_t which, const float* d_p
     return MRS_OK;
 }
 
+/* host-array form of set_clouds (what a pcl::PointCloud / numpy caller holds): staged through a scratch buffer */
+int mrs_gicp_batch_set_clouds_host(mrs_gicp_batch* h, int32_t which, const float* h_points, int32_t stride_floats, const int64_t* h_offsets)
+{
+    MRS_REQUIRE(h && h_points && h_offsets, "null pointer");
+    MRS_REQUIRE(stride_floats >= 3, "stride_floats must be >= 3");
+    MRS_REQUIRE(h_offsets[0] == 0 && h_offsets[h->n_pairs] > 0, "offsets must start at 0 and hold points");
+    MRS_HIP_TRY(hipSetDevice(h->ctx->device));
+    const size_t bytes = (size_t)h_offsets[h->n_pairs] * stride_floats * sizeof(float);
+    mrs::Scratch stage;
+    int st = stage.alloc(bytes, nullptr);
+    if (st != MRS_OK) return st;
+    MRS_HIP_TRY(hipMemcpy(stage.p, h_points, bytes, hipMemcpyHostToDevice));
+    st = mrs_gicp_batch_set_clouds(h, which, stage.as<float>(), stride_floats, h_offsets, nullptr);
+    if (st != MRS_OK) return st;
+    MRS_HIP_TRY(hipStreamSynchronize(nullptr));     // the staging buffer goes back to the cache only after set_clouds has read it
+    return MRS_OK;
+}
+
 int mrs_gicp_batch_compute_covariances(mrs_gicp_batch* h, int32_t which, int32_t* d_knn_out, mrs_stream stream)
 {
     MRS_REQUIRE(h, "null handle");

@@ -345,6 +345,25 @@ int mrs_voxel_downsample_approx(mrs_ctx* ctx, const void* d_points, int32_t is_d
                      : approx_voxel_grid_impl<float>(ctx, (const float*)d_points, stride, n, (float)leaf_size, d_out, h_count, (hipStream_t)stream);
 }
 
+/* host-array form (pygicp.downsample hands over a numpy array): h_out holds up to n x 3 doubles */
+int mrs_voxel_downsample_approx_host(mrs_ctx* ctx, const void* h_points, int32_t is_double, int32_t stride, int32_t n, double leaf_size,
+                                     double* h_out, int32_t* h_count)
+{
+    MRS_REQUIRE(ctx && h_points && h_out && h_count, "null pointer");
+    MRS_REQUIRE(n > 0 && stride >= 3, "n must be positive and stride >= 3");
+    MRS_HIP_TRY(hipSetDevice(ctx->device));
+    const size_t in_bytes = (size_t)n * stride * (is_double ? 8 : 4);
+    mrs::Scratch in, out;
+    int st = in.alloc(in_bytes, nullptr);
+    if (st != MRS_OK) return st;
+    if ((st = out.alloc((size_t)n * 3 * sizeof(double), nullptr)) != MRS_OK) return st;
+    MRS_HIP_TRY(hipMemcpy(in.p, h_points, in_bytes, hipMemcpyHostToDevice));
+    st = mrs_voxel_downsample_approx(ctx, in.p, is_double, stride, n, leaf_size, out.as<double>(), h_count, nullptr);
+    if (st != MRS_OK) return st;
+    if (*h_count > 0) MRS_HIP_TRY(hipMemcpy(h_out, out.p, (size_t)*h_count * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    return MRS_OK;
+}
+
 int mrs_crop_scale_batch(mrs_ctx* ctx, const void* d_points, int32_t is_double, int32_t stride, const int64_t* d_raw_offsets,
                          const int64_t* h_raw_offsets, int32_t batch, float* d_xyz_soa, int64_t* d_out_offsets, mrs_stream stream)
 {

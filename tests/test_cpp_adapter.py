@@ -15,7 +15,8 @@ def _compile():
     if not os.path.exists(os.path.join(lib_dir, "libmrslam_hip.so")):
         import __graft_entry__
         __graft_entry__.build()
-    cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+    # plain g++: the adapter header needs the C ABI only (no HIP headers, no hipcc in the Mapping workspace's build)
+    cmd = ["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
            "-I" + os.path.join(ROOT, "tests", "cpp"), os.path.join(ROOT, "tests", "cpp", "adapter_main.cpp"),
            "-o", OUT, "-L" + lib_dir, "-lmrslam_hip", "-Wl,-rpath," + lib_dir]
     r = subprocess.run(cmd, capture_output=True, text=True)
