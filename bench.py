@@ -37,6 +37,7 @@ from mr_slam_amd import bev, ring, shard, synth  # noqa: E402
 N_POINTS = 120_000
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
 DIST_THRESHOLD = 0.48     # RING_ros/config.py:17
+FUSE_DEFAULT = 0          # launches whose scans share one fused BEV + Radon kernel (0 = separate kernels)
 def _latest_pmc():
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc.json")))      # the newest round's counter passes
@@ -58,8 +59,9 @@ def make_shard(batch, chunks, rank, device):
     offs = torch.arange(batch + 1, dtype=torch.int64, device=device) * N_POINTS
     out = []
     sub = 64
+    whole = torch.empty((chunks, batch, 3, N_POINTS), dtype=torch.float32, device=device)   # one allocation: launches over several chunks
     for c in range(chunks):
-        xyz = torch.empty((batch, 3, N_POINTS), dtype=torch.float32, device=device)
+        xyz = whole[c]
         for i0 in range(0, batch, sub):
             n = min(sub, batch - i0)
             th = torch.rand(n, generator=g, device=device) * (2 * np.pi)
@@ -76,6 +78,7 @@ def make_shard(batch, chunks, rank, device):
             x = torch.where(ok, x, x.gather(1, first)); y = torch.where(ok, y, y.gather(1, first)); z = torch.where(ok, z, z.gather(1, first))
             xyz[i0:i0 + n, 0] = x / 70.0; xyz[i0:i0 + n, 1] = y / 70.0; xyz[i0:i0 + n, 2] = z / 30.0
         out.append((xyz.view(-1), offs))
+    make_shard.whole = whole
     return out
 
 
@@ -359,7 +362,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="scan pairs per launch")
-    ap.add_argument("--chunks", type=int, default=32, help="launches per step (resident shard = batch x chunks scans)")
+    ap.add_argument("--chunks", type=int, default=48, help="launches per step (resident shard = batch x chunks scans)")
+    ap.add_argument("--fuse", type=int, default=FUSE_DEFAULT, help="BEV + Radon + normalisation of this many launches' scans in ONE persistent "
+                    "kernel (mrs_ring_descriptors_batch; same bits); 0 = the two kernels per launch")
     ap.add_argument("--gicp-pairs", type=int, default=256, help="120k-pt pairs per rank in the GICP leg (BASELINE configs[2]: 256; 0 = skip)")
     ap.add_argument("--gicp-iters", type=int, default=20)
     ap.add_argument("--cpu-sample", type=int, default=256, help="scans in the CPU baseline sample")
@@ -429,7 +434,12 @@ def main():
     rescorer = shard.OwnerRescorer(DIST_THRESHOLD, margin=2e-3, slots=64) if dist_on else None
     setup_s = time.perf_counter() - t_setup
 
-    ev = {k: [] for k in ("bev", "radon", "corr", "sweep", "wait")}
+    ev = {k: [] for k in ("bev", "radon", "bev_radon", "corr", "sweep", "wait")}
+    FUSE = max(0, min(args.fuse, CH))
+    if FUSE:
+        whole = make_shard.whole                                   # [CH][B][3][N], one allocation
+        norm_group = torch.empty((FUSE * B, 120, 120), dtype=torch.float32, device=device)
+        group_offs = torch.arange(FUSE * B + 1, dtype=torch.int64, device=device) * N_POINTS
 
     def step(record):
         def mark():
@@ -439,11 +449,23 @@ def main():
         spec32[CH:] = spec32[CH - DEPTH:CH]            # last launches of the previous step = databases of this step's first
         for c, (xyz, offs) in enumerate(chunks):
             g = launch_no[0]; launch_no[0] += 1
-            e0 = mark() if record else None
-            bev.cart_bev(xyz, offs, 1, 1, 120, 120, 1, out=img.view(B, -1))
-            e1 = mark() if record else None
-            _, norm = plan.forward(img.view(B, 120, 120), raw=False, normalized=True)
-            e2 = mark() if record else None
+            if FUSE:
+                if c % FUSE == 0:                  # rasterise + Radon + normalise the scans of the next FUSE launches in one kernel
+                    ng = min(FUSE, CH - c)
+                    ef0 = mark() if record else None
+                    ring.ring_descriptors_fused(whole[c:c + ng].view(-1), group_offs[:ng * B + 1], raw=False, normalized=True,
+                                                out_norm=norm_group[:ng * B])
+                    if record:
+                        ev["bev_radon"].append((ef0, mark(), ng))
+                norm = norm_group[(c % FUSE) * B:(c % FUSE + 1) * B]
+                e0 = e1 = None
+                e2 = mark() if record else None
+            else:
+                e0 = mark() if record else None
+                bev.cart_bev(xyz, offs, 1, 1, 120, 120, 1, out=img.view(B, -1))
+                e1 = mark() if record else None
+                _, norm = plan.forward(img.view(B, 120, 120), raw=False, normalized=True)
+                e2 = mark() if record else None
             if dist_on:
                 ew0 = mark() if record else None
                 while len(pending) >= DEPTH:           # the compute stream waits for the exchange of launch g - DEPTH
@@ -464,7 +486,9 @@ def main():
             if dist_on:
                 pending.append((dist.all_gather_into_tensor(gathered[g % (DEPTH + 1)], spec16, async_op=True), spec16))
             if record:
-                ev["bev"].append((e0, e1)); ev["radon"].append((e1, e2)); ev["corr"].append((e2, e3)); ev["sweep"].append((e3, e4))
+                if not FUSE:
+                    ev["bev"].append((e0, e1)); ev["radon"].append((e1, e2))
+                ev["corr"].append((e2, e3)); ev["sweep"].append((e3, e4))
                 if dist_on:
                     ev["wait"].append((ew0, ew1))
         if dist_on:
@@ -500,7 +524,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kern_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items() if v}
+    kern_ms = {k: float(np.mean([t[0].elapsed_time(t[1]) for t in v])) for k, v in ev.items() if v and k != "bev_radon"}
+    if ev["bev_radon"]:       # per launch of B scans, like the other entries
+        kern_ms["bev_radon"] = float(sum(a.elapsed_time(b) for a, b, _ in ev["bev_radon"]) / sum(n for _, _, n in ev["bev_radon"]))
 
     extra = {}
     gicp_res = None
@@ -549,7 +575,16 @@ def main():
         pmc = load_pmc()
         cells = 120 * 120
         bev_bytes = B * (12 * N_POINTS + 4 * cells)          # 12 B/point + 4 B/cell
-        achieved = bev_bytes / (kern_ms["bev"] * 1e-3) / 1e9
+        if FUSE:
+            # the rasteriser no longer runs on its own in the timed region: its stand-alone roofline is measured right here (same
+            # scans, same box), the timed region's dominant kernel is the fused one (12 B/point in, one normalised sinogram out)
+            xyz0, offs0 = chunks[0]
+            kern_ms["bev_standalone"] = ev_ms(lambda: bev.cart_bev(xyz0, offs0, 1, 1, 120, 120, 1, out=img.view(B, -1)))
+            kern_ms["radon_standalone"] = ev_ms(lambda: plan.forward(img.view(B, 120, 120), raw=False, normalized=True))
+            fused_bytes = B * (12 * N_POINTS + 4 * cells)
+            achieved = fused_bytes / (kern_ms["bev_radon"] * 1e-3) / 1e9
+        else:
+            achieved = bev_bytes / (kern_ms["bev"] * 1e-3) / 1e9
         line = {
             "metric": "loop-candidate pairs/sec (BEV+Radon+corr), 120k-pt scans",
             "value": world * B * CH * args.steps / elapsed,
@@ -580,6 +615,24 @@ def main():
                          "traffic_source": PMC_NAME + " (rocprofv3 --pmc passes of tools/pmc_targets.py)" if pmc.get("k_cart_lds") else None},
             "gicp": gicp_res,
         }
+        if FUSE:
+            # one kernel with an HBM-bound half (rasteriser) and a VALU-bound half (Radon march) per workgroup, overlapped across
+            # compute units: its time is bounded below by max(HBM time of the points, VALU time of the rays), not by either alone
+            r = pmc.get("k_bev_radon2", {})
+            sa = bev_bytes / (kern_ms["bev_standalone"] * 1e-3) / 1e9
+            line["config"]["fused_launches"] = FUSE
+            line["roofline"] = {"kernel": f"k_bev_radon2 (BEV scatter + Radon + normalise, {FUSE} x {B} scans per launch)", "bound": "hbm",
+                                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                "traffic": r.get("hbm_bytes"), "algorithmic_bytes_per_launch": bev_bytes,
+                                "traffic_source": PMC_NAME if r else None,
+                                "note": "per 1024 scans; the kernel also carries the VALU-bound Radon march (1.47 M two-tap samples per image), "
+                                        "so the HBM fraction of the fused kernel is below the stand-alone rasteriser's by construction",
+                                "ms_vs_separate_kernels": {"fused": kern_ms["bev_radon"], "bev_standalone": kern_ms["bev_standalone"],
+                                                           "radon_standalone": kern_ms["radon_standalone"]}}
+            line["roofline_bev_scatter"] = {"kernel": "k_cart_lds (BEV scatter, stand-alone launch outside the timed region)", "bound": "hbm",
+                                            "achieved": sa, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sa / HBM_PEAK_GBS,
+                                            "ms": kern_ms["bev_standalone"], "traffic": pmc.get("k_cart_lds", {}).get("hbm_bytes"),
+                                            "algorithmic_bytes_per_launch": bev_bytes}
         if dist_on:
             per_launch = (world - 1) * B * 29280
             line["exchange"] = {"format": "fp16 half spectra, 29 280 B per descriptor", "allgather_bytes_in_per_rank_per_launch": per_launch,
@@ -598,9 +651,10 @@ def main():
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": pbytes / ms / 1e6 / HBM_PEAK_GBS, "ms": ms,
                                       "traffic": pmc.get("k_polar_lds", {}).get("hbm_bytes"), "algorithmic_bytes_per_launch": pbytes}
             samples = 1.47e6 * B                       # two-tap samples per launch (120 angles x 120 rays x ~102 steps)
+            radon_ms = kern_ms.get("radon", kern_ms.get("radon_standalone"))
             r = pmc.get("k_radon2", {})
             line["roofline_radon"] = {"kernel": "k_radon2 (two images per workgroup)", "bound": "valu+lds (not HBM: 115 KB per image)",
-                                      "ms": kern_ms["radon"], "samples_per_s": samples / (kern_ms["radon"] * 1e-3),
+                                      "ms": radon_ms, "samples_per_s": samples / (radon_ms * 1e-3),
                                       "valu_issue_frac": r.get("valu_issue_frac"), "lds_busy_frac": r.get("lds_busy_frac"),
                                       "lds_bank_conflict_frac_of_lds": r.get("lds_bank_conflict_frac"),
                                       "hbm_bytes": r.get("hbm_bytes"), "source": PMC_NAME if r else None}

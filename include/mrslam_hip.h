@@ -157,6 +157,25 @@ int mrs_radon_forward(mrs_radon_plan* plan, const float* d_img, int32_t batch, f
  * dist = 1) and count the event so that the host mirror can raise the same error.  Synchronises the device. */
 int mrs_radon_plan_degenerate_count(mrs_radon_plan* plan, int32_t reset, int32_t* out_count);
 
+/* A3/A4 + R1 + R2a in one launch: the front half of generate_RING (RING_ros/util.py:174-197: voxelocc.GPUTransformer
+ * transform() + retreive(), channel 2 -> ParallelBeam.forward -> fn.normalize) for a batch of scans.  One persistent workgroup
+ * per compute unit rasterises two scans straight into the Radon kernel's LDS tile and marches the rays; the BEV image goes to
+ * HBM only when d_bev is given.  Results are bit-identical to mrs_bev_cart_batch(MRS_BEV_OUT_COMPACT) followed by
+ * mrs_radon_forward.  d_xyz / d_offsets as for mrs_bev_cart_batch; cfg: num_height == 1 and n0 x n1 == the plan's image
+ * (H x W).  Each of d_bev float[batch][n0][n1], d_sino, d_sino_norm float[batch][n_angles][det_count] may be NULL (not
+ * all).  MRS_ERR_UNSUPPORTED when the configuration needs the two-call path (num_height > 1, a tile that does not fit the
+ * LDS twice, more than 16 384 rays). */
+int mrs_ring_descriptors_batch(mrs_radon_plan* plan, const float* d_xyz, const int64_t* d_offsets, int32_t batch,
+                               const mrs_bev_cfg* cfg, float* d_bev, float* d_sino, float* d_sino_norm, mrs_stream stream);
+
+/* Tuning knobs of mrs_ring_descriptors_batch (results do not depend on them). */
+enum mrs_radon_option {
+    MRS_RADON_OPT_FUSED_STAGGER_US = 1, /* odd workgroups start this many microseconds late (0 = off)            */
+    MRS_RADON_OPT_FUSED_PREFETCH = 2,   /* 16-byte load triplets in flight per lane while rasterising: 2 or 4    */
+    MRS_RADON_OPT_FUSED_GRID = 3        /* persistent workgroups (0 = one per compute unit)                      */
+};
+int mrs_radon_plan_set_option(mrs_radon_plan* plan, int32_t option, int32_t value);
+
 /* (x - mean) / std over n_groups consecutive groups of group_len floats (unbiased std):
  * torchvision fn.normalize(t, mean=t.mean(), std=t.std()) as RING_ros/util.py:197,339-340,429-430
  * use it (RING++ normalises a whole [C,H,W] descriptor with ONE mean/std -> group_len=C*H*W).

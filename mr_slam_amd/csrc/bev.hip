@@ -692,22 +692,6 @@ int make_polar(mrs_ctx* ctx, const mrs_bev_cfg* c, PolarP& p)
     return MRS_OK;
 }
 
-int make_cart(const mrs_bev_cfg* c, bool feat, CartP& p)
-{
-    MRS_REQUIRE(c->n0 > 0 && c->n1 > 0 && c->num_height > 0, "grid sizes must be positive");
-    MRS_REQUIRE(c->max_length > 0 && c->max_height > 0, "max_length / max_height must be positive");
-    MRS_REQUIRE(!feat || c->enough_large >= 3, "featsize must be >= 3 (x,y,z planes)");
-    MRS_REQUIRE((int64_t)c->n0 * c->n1 * c->num_height * (feat ? c->enough_large : 3) < (1ll << 28), "grid too large");
-    MRS_REQUIRE(c->num_height <= 1024, "num_height > 1024 unsupported");
-    p.NX = c->n0; p.NY = c->n1; p.H = c->num_height; p.F = feat ? c->enough_large : 3;
-    p.gap_x = (float)(2.0 * (float)c->max_length / (float)c->n0);           // kernel.cu:22-24
-    p.gap_y = (float)(2.0 * (float)c->max_length / (float)c->n1);
-    p.gap_h = (float)(2.0 * (float)c->max_height / (float)c->num_height);
-    p.inv_x = 1.0f / p.gap_x; p.inv_y = 1.0f / p.gap_y; p.inv_h = 1.0f / p.gap_h;
-    p.eps_x = eps_for(p.NX); p.eps_y = eps_for(p.NY); p.eps_h = eps_for(p.H);
-    return MRS_OK;
-}
-
 inline int blocks_for(size_t work, int threads, int cap) {
     size_t b = (work + threads - 1) / threads;
     if (b < 1) b = 1;

@@ -1,0 +1,242 @@
+// fused.hip -- the front half of generate_RING (RING_ros/util.py:174-197) in ONE persistent kernel for gfx950:
+// Cartesian max-z BEV (rows A3/A4, generate_bev_cython_binary/src/kernel.cu:14-61 + manager.cu:53-91) rasterised straight
+// into the Radon kernel's LDS tile, then the sinogram (row R1, torch-radon/src/forward.cu:12-124) and its normalisation
+// (row R2a, util.py:197).  Nothing is copied from the reference; the arithmetic is the one of k_cart_lds (bev.hip) and
+// k_radon2 (radon.hip), shared through bev_cart.hpp / radon_device.hpp, so the results are bit-identical to running the
+// two kernels back to back.
+//
+// Why fuse: the rasteriser is HBM-bound (12 B per point, 0.8 of the HBM peak, VALU 43 % busy) and the Radon march is
+// VALU-bound (115 KB of HBM traffic per image).  Run back to back each leaves the other resource idle.  Here one workgroup
+// per compute unit (the two interleaved images take 124 KB of the 160 KB LDS) loops over pairs of scans: rasterise both
+// scans into the (A, B) texel cells, march the rays, take the next pair from a global counter.  Workgroups drift out of phase
+// (a workgroup that streams points while its neighbours march rays has the memory system to itself and gets ahead: the
+// drift feeds itself; `fused_stagger_us` seeds it by starting every other workgroup half a period late), so that at any time
+// some compute units pull points from HBM while the others are busy in the VALU.  The BEV image never goes to HBM unless asked for.
+#include "common.hpp"
+#include "bev_cart.hpp"
+#include "radon_device.hpp"
+
+#include <algorithm>
+
+namespace {
+
+// Rasterise one scan into image `which` (0 = A, 1 = B) of the interleaved tile: the per-point logic of k_cart_lds (bev.hip),
+// with cell (ix, iy) at int index 2 * ((ix + kPad) * stride + iy + kPad) + which.  PF 16-byte load triplets per lane are
+// requested before the first point of a round is processed (one workgroup per compute unit: the loads in flight have to come
+// from fewer waves than in the stand-alone rasteriser).
+template <int PF>
+__device__ __forceinline__ void rasterise_scan(int* icells, int which, const float* __restrict__ px, const float* __restrict__ py,
+                                               const float* __restrict__ pz, int n, const CartP& p, int stride)
+{
+    // Only z > 0 can change the map (max_h starts at 0: manager.cu:57,69).  Common case in one test: 0 < z < 1 and
+    // 0 < |x|,|y| <= 1 and both quotients at least eps away from a bin edge -> the fp32 quotient's floor IS the reference's
+    // double floor.  Everything else (rare) takes the exact per-axis path of cart_lin().
+    const float eps = fmaxf(p.eps_x, p.eps_y);
+    const float inv_x = p.inv_x, inv_y = p.inv_y;
+    const int NY = p.NY;
+    int* const origin = icells + 2 * (kPad * stride + kPad) + which;
+    auto put = [&](float x, float y, float z) {
+        const float gx = __builtin_fmaf(x, inv_x, inv_x), gy = __builtin_fmaf(y, inv_y, inv_y);
+        const float fx = floorf(gx), fy = floorf(gy);
+        const float ex = 0.5f - fabsf((gx - fx) - 0.5f), ey = 0.5f - fabsf((gy - fy) - 0.5f);  // distance to a bin edge
+        // every comparison is false for a NaN operand: NaN x or y leave the fast path
+        const bool fast = (bool)((int)(z > 0.0f) & (int)(z < 1.0f) & (int)(fabsf(x) <= 1.0f) & (int)(fabsf(y) <= 1.0f) & (int)(x * y != 0.0f) &
+                                 (int)(ex >= eps) & (int)(ey >= eps));
+        if (fast) {
+            int* cell = origin + 2 * ((int)fx * stride + (int)fy);
+            const int zi = __float_as_int(z);
+            if (*cell < zi) atomicMax(cell, zi);   // plain read first: same-cell lidar returns broadcast instead of serialising
+        } else if (z > 0.0f) {
+            int col;
+            const int lin = cart_lin(p, x, y, z, col);
+            if (lin >= 0) {
+                const int ix = lin / NY, iy = lin - ix * NY;
+                atomicMax(origin + 2 * (ix * stride + iy), __float_as_int(z));
+            }
+        }
+    };
+    int done = 0;
+    if (aligned16(px) && aligned16(py) && aligned16(pz)) {
+        const int n4 = n >> 2;
+        const float4* x4 = reinterpret_cast<const float4*>(px);
+        const float4* y4 = reinterpret_cast<const float4*>(py);
+        const float4* z4 = reinterpret_cast<const float4*>(pz);
+#pragma nounroll
+        for (int i = threadIdx.x; i < n4; i += PF * kRadonWG) {
+            float4 X[PF], Y[PF], Z[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int k = i + u * kRadonWG;
+                if (k < n4) { X[u] = stream_load4(x4 + k); Y[u] = stream_load4(y4 + k); Z[u] = stream_load4(z4 + k); }
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                if (i + u * kRadonWG < n4) {
+                    put(X[u].x, Y[u].x, Z[u].x);
+                    put(X[u].y, Y[u].y, Z[u].y);
+                    put(X[u].z, Y[u].z, Z[u].z);
+                    put(X[u].w, Y[u].w, Z[u].w);
+                }
+            }
+        }
+        done = n4 << 2;
+    }
+    for (int i = done + threadIdx.x; i < n; i += kRadonWG) put(px[i], py[i], pz[i]);
+}
+
+// grid = persistent workgroups (one per compute unit); pair 2k, 2k+1 of the batch per round, rounds handed out by *next_pair
+// (zeroed by the host before the launch).  bev_out / sino_raw / sino_norm may each be null.
+template <int MAX_RAYS_PER_LANE, int STRIDE, int PF>
+__global__ __launch_bounds__(kRadonWG) void k_bev_radon2(const float* __restrict__ xyz, const int64_t* __restrict__ offs, CartP cp, RadonP p,
+                                                         int batch, float* __restrict__ bev_out, float* __restrict__ sino_raw,
+                                                         float* __restrict__ sino_norm, int* __restrict__ degenerate,
+                                                         unsigned* __restrict__ next_pair, unsigned stagger_ticks)
+{
+    extern __shared__ __attribute__((aligned(16))) int lds_i[];   // [rows][stride] cells of (A, B) texels, as ints while rasterising
+    __shared__ double red[2][16];
+    __shared__ unsigned s_next;
+    const v2f* cells = reinterpret_cast<const v2f*>(lds_i);
+    const int pairs = (batch + 1) >> 1;
+    const int rows = p.H + 2 * kPad;
+    const int rays = p.A * p.D;
+    const int hw = p.H * p.W;
+    if (stagger_ticks != 0u && (blockIdx.x & 1u)) {
+        const unsigned long long t0 = wall_clock64();   // constant-rate counter (100 MHz)
+        while (wall_clock64() - t0 < (unsigned long long)stagger_ticks) __builtin_amdgcn_s_sleep(64);
+    }
+    unsigned pair = blockIdx.x;
+    while (pair < (unsigned)pairs) {
+        // opaque copy of the lane id: the ray-table addresses of 15 rays x 5 arrays per lane are loop-invariant and would otherwise be
+        // hoisted out of the persistent loop (150 VGPRs -> scratch spills)
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int b0 = 2 * (int)pair, b1 = b0 + 1;
+        const bool two = b1 < batch;
+        int2* z2 = reinterpret_cast<int2*>(lds_i);
+        for (int i = threadIdx.x; i < rows * p.stride; i += kRadonWG) z2[i] = make_int2(0, 0);
+        __syncthreads();
+        {
+            const int64_t o = offs[b0];
+            const int n = (int)(offs[b0 + 1] - o);
+            const float* px = xyz + 3 * o;
+            rasterise_scan<PF>(lds_i, 0, px, px + n, px + 2 * (size_t)n, n, cp, p.stride);
+        }
+        if (two) {
+            const int64_t o = offs[b1];
+            const int n = (int)(offs[b1 + 1] - o);
+            const float* px = xyz + 3 * o;
+            rasterise_scan<PF>(lds_i, 1, px, px + n, px + 2 * (size_t)n, n, cp, p.stride);
+        }
+        __syncthreads();
+        if (bev_out) {   // the COMPACT layout of mrs_bev_cart_batch: [b][ix][iy]
+            for (int i = threadIdx.x; i < hw; i += kRadonWG) {
+                const int y = i / p.W, x = i - y * p.W;
+                const int2 c = z2[(y + kPad) * p.stride + x + kPad];
+                bev_out[(size_t)b0 * hw + i] = __int_as_float(c.x);
+                if (two) bev_out[(size_t)b1 * hw + i] = __int_as_float(c.y);
+            }
+        }
+        float va[MAX_RAYS_PER_LANE], vb[MAX_RAYS_PER_LANE];
+#pragma unroll
+        for (int k = 0; k < MAX_RAYS_PER_LANE; ++k) {
+            const int ray = tid + k * kRadonWG;
+            float a = 0.0f, b = 0.0f;
+            if (ray < rays) {
+                trace_ray2<STRIDE>(cells, p, ray, a, b);
+                if (sino_raw) {
+                    sino_raw[(size_t)b0 * rays + ray] = a;
+                    if (two) sino_raw[(size_t)b1 * rays + ray] = b;
+                }
+            }
+            va[k] = a; vb[k] = b;
+        }
+        if (sino_norm) {
+            normalize_store<MAX_RAYS_PER_LANE>(va, rays, red, sino_norm + (size_t)b0 * rays, degenerate);
+            if (two) normalize_store<MAX_RAYS_PER_LANE>(vb, rays, red, sino_norm + (size_t)b1 * rays, degenerate);
+        }
+        __syncthreads();   // every wave is done with the tile (and with red) before the next round clears it
+        if (threadIdx.x == 0) s_next = gridDim.x + atomicAdd(next_pair, 1u);
+        __syncthreads();
+        pair = s_next;
+    }
+}
+
+template <int M, int S>
+void* fused_kernel(int pf)
+{
+    return pf >= 4 ? reinterpret_cast<void*>(k_bev_radon2<M, S, 4>) : reinterpret_cast<void*>(k_bev_radon2<M, S, 2>);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mrs_radon_plan_set_option(mrs_radon_plan* plan, int32_t option, int32_t value)
+{
+    MRS_REQUIRE(plan, "null plan");
+    switch (option) {
+        case MRS_RADON_OPT_FUSED_STAGGER_US:
+            MRS_REQUIRE(value >= 0 && value <= 100000, "stagger must be within [0, 100000] microseconds");
+            plan->fused_stagger_us = value;
+            return MRS_OK;
+        case MRS_RADON_OPT_FUSED_PREFETCH:
+            MRS_REQUIRE(value == 2 || value == 4, "prefetch depth must be 2 or 4");
+            plan->fused_prefetch = value;
+            return MRS_OK;
+        case MRS_RADON_OPT_FUSED_GRID:
+            MRS_REQUIRE(value >= 0 && value <= 65535, "workgroup count must be within [0, 65535]");
+            plan->fused_grid = value;
+            return MRS_OK;
+        default:
+            mrs::set_error("unknown plan option %d", (int)option);
+            return MRS_ERR_ARG;
+    }
+}
+
+int mrs_ring_descriptors_batch(mrs_radon_plan* plan, const float* d_xyz, const int64_t* d_offsets, int32_t batch,
+                               const mrs_bev_cfg* cfg, float* d_bev, float* d_sino, float* d_sino_norm, mrs_stream stream)
+{
+    MRS_REQUIRE(plan && d_xyz && d_offsets && cfg, "null pointer");
+    MRS_REQUIRE(d_bev || d_sino || d_sino_norm, "at least one output required");
+    MRS_REQUIRE(batch > 0, "batch must be positive");
+    MRS_HIP_TRY(hipSetDevice(plan->ctx->device));
+    CartP cp;
+    int st = make_cart(cfg, false, cp);
+    if (st != MRS_OK) return st;
+    const int rays = plan->n_angles * plan->det;
+    const int per_lane = (rays + kRadonWG - 1) / kRadonWG;
+    if (cfg->num_height != 1 || cfg->n0 != plan->H || cfg->n1 != plan->W || !plan->two_in_lds || per_lane > 16) {
+        mrs::set_error("fused descriptor kernel needs num_height == 1, a %d x %d grid (the plan's image), two images in the LDS and at most "
+                       "16384 rays: run mrs_bev_cart_batch + mrs_radon_forward instead", plan->H, plan->W);
+        return MRS_ERR_UNSUPPORTED;
+    }
+    RadonP p;
+    p.A = plan->n_angles; p.D = plan->det; p.H = plan->H; p.W = plan->W;
+    p.stride = (plan->W + 2 * kPad) | 1;
+    const size_t nr = (size_t)p.A * p.D;
+    p.meta = plan->d_meta;
+    p.base = plan->d_meta + nr;
+    p.q = reinterpret_cast<const float*>(plan->d_meta + 2 * nr);
+    p.vm = p.q + nr;
+    p.nrm = p.vm + nr;
+    const size_t lds = 2 * (size_t)(p.H + 2 * kPad) * p.stride * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    mrs::Scratch ctr;
+    if ((st = ctr.alloc(256, s)) != MRS_OK) return st;
+    MRS_HIP_TRY(hipMemsetAsync(ctr.p, 0, sizeof(unsigned), s));
+    const int pf = plan->fused_prefetch;
+    void* kern = per_lane <= 15 ? (p.stride == 125 ? fused_kernel<15, 125>(pf) : fused_kernel<15, 0>(pf)) : fused_kernel<16, 0>(pf);
+    if (lds > 48 * 1024) MRS_HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int pairs = (batch + 1) / 2;
+    const int grid = std::min(pairs, plan->fused_grid > 0 ? plan->fused_grid : std::max(plan->ctx->num_cu, 1));
+    unsigned stagger_ticks = (unsigned)plan->fused_stagger_us * 100u;   // wall_clock64 ticks at 100 MHz
+    if (grid < 2) stagger_ticks = 0;
+    unsigned* d_ctr = ctr.as<unsigned>();
+    int* d_deg = plan->d_degenerate;
+    void* args[] = {(void*)&d_xyz, (void*)&d_offsets, (void*)&cp, (void*)&p, (void*)&batch, (void*)&d_bev, (void*)&d_sino,
+                    (void*)&d_sino_norm, (void*)&d_deg, (void*)&d_ctr, (void*)&stagger_ticks};
+    MRS_HIP_TRY(hipLaunchKernel(kern, dim3(grid), dim3(kRadonWG), args, lds, s));
+    return MRS_OK;
+}
+
+}  // extern "C"

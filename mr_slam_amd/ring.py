@@ -49,6 +49,12 @@ class RadonPlan:
         _lib.check(_lib.load().mrs_radon_plan_degenerate_count(self._h, int(bool(reset)), C.byref(n)))
         return n.value
 
+    OPT_FUSED_STAGGER_US, OPT_FUSED_PREFETCH, OPT_FUSED_GRID = 1, 2, 3
+
+    def set_option(self, option, value):
+        """Tuning knobs of the fused descriptor kernel (mrs_radon_plan_set_option); results do not depend on them."""
+        _lib.check(_lib.load().mrs_radon_plan_set_option(self._h, int(option), int(value)))
+
     def forward(self, img, raw=True, normalized=False):
         """img float32 [B,H,W] (device, contiguous) -> (sino [B,A,D] | None, sino_norm | None)."""
         d = _dev(img)
@@ -109,14 +115,46 @@ def forward_row_fft(x):
     return out
 
 
-def ring_descriptors(xyz, offsets, num_ring=NUM_RING, num_sector=NUM_SECTOR, want_bev=False):
+# Batches of at least this many scans take the single-launch kernel (mrs_ring_descriptors_batch) in ring_descriptors();
+# None = always the two-call sequence.  Both give the same bits.
+FUSED_MIN_BATCH = None
+
+
+def ring_descriptors(xyz, offsets, num_ring=NUM_RING, num_sector=NUM_SECTOR, want_bev=False, fused=None):
     """Batched generate_RING front half (util.py:174-197): Cartesian BEV -> Radon -> normalise.
-    Returns (bev | None, sinogram [B,A,D], normalised sinogram [B,A,D])."""
+    Returns (bev | None, sinogram [B,A,D], normalised sinogram [B,A,D]).  fused: True / False picks the single-launch
+    kernel / the two-call sequence (same bits), None decides by FUSED_MIN_BATCH."""
     d = _dev(xyz)
+    if fused is None:
+        fused = FUSED_MIN_BATCH is not None and offsets.numel() - 1 >= FUSED_MIN_BATCH
+    if fused:
+        return ring_descriptors_fused(xyz, offsets, num_ring, num_sector, want_bev=want_bev, raw=True, normalized=True)
     img = bev.cart_bev(xyz, offsets, MAX_LENGTH, MAX_HEIGHT, num_ring, num_sector, 1, layout=OUT_COMPACT)
     img = img.view(-1, num_ring, num_sector)
     sino, norm = ring_plan(d, num_ring, num_sector).forward(img, raw=True, normalized=True)
     return (img if want_bev else None), sino, norm
+
+
+def ring_descriptors_fused(xyz, offsets, num_ring=NUM_RING, num_sector=NUM_SECTOR, want_bev=False, raw=True, normalized=True, out_norm=None):
+    """The same in ONE launch (C ABI mrs_ring_descriptors_batch): a persistent workgroup per compute unit rasterises two scans
+    straight into the Radon kernel's LDS tile and marches the rays; the BEV image reaches HBM only if want_bev.
+    Bit-identical to ring_descriptors(fused=False)."""
+    d = _dev(xyz)
+    assert xyz.dtype == torch.float32 and xyz.is_contiguous() and offsets.dtype == torch.int64
+    B = offsets.numel() - 1
+    plan = ring_plan(d, num_ring, num_sector)
+    dev = xyz.device
+    img = torch.empty((B, num_ring, num_sector), dtype=torch.float32, device=dev) if want_bev else None
+    sino = torch.empty((B, plan.n_angles, plan.det), dtype=torch.float32, device=dev) if raw else None
+    norm = None
+    if normalized:
+        norm = out_norm if out_norm is not None else torch.empty((B, plan.n_angles, plan.det), dtype=torch.float32, device=dev)
+        assert norm.is_contiguous() and norm.numel() == B * plan.n_angles * plan.det
+    cfg = _lib.BevCfg(MAX_LENGTH, MAX_HEIGHT, num_ring, num_sector, 1, 1)
+    _lib.check(_lib.load().mrs_ring_descriptors_batch(plan._h, _lib.ptr(xyz), _lib.ptr(offsets), B, C.byref(cfg),
+                                                      _lib.ptr(img) if want_bev else None, _lib.ptr(sino) if raw else None,
+                                                      _lib.ptr(norm) if normalized else None, _lib.current_stream(d)))
+    return img, sino, norm
 
 
 def generate_RING(pc, device="cuda:0"):
