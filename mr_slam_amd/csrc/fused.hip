@@ -21,9 +21,11 @@
 namespace {
 
 // Rasterise one scan into image `which` (0 = A, 1 = B) of the interleaved tile: the per-point logic of k_cart_lds (bev.hip),
-// with cell (ix, iy) at int index 2 * ((ix + kPad) * stride + iy + kPad) + which.  PF 16-byte load triplets per lane are
-// requested before the first point of a round is processed (one workgroup per compute unit: the loads in flight have to come
-// from fewer waves than in the stand-alone rasteriser).
+// with cell (ix, iy) at int index 2 * ((ix + kPad) * stride + iy + kPad) + which.  One workgroup per compute unit means 4 waves
+// per SIMD instead of the stand-alone rasteriser's 8, so latencies are hidden in the code instead of by occupancy:
+//   * the loads of the next PF point quads are in flight while the current ones are rasterised (two register stages);
+//   * the 4 * PF cells of a stage are read from the LDS together, then compared, then (rarely) raised by ds_max: one LDS round
+//     trip per stage instead of one per point.  A read that is stale by the time of its compare only costs a redundant ds_max.
 template <int PF>
 __device__ __forceinline__ void rasterise_scan(int* icells, int which, const float* __restrict__ px, const float* __restrict__ py,
                                                const float* __restrict__ pz, int n, const CartP& p, int stride)
@@ -35,18 +37,18 @@ __device__ __forceinline__ void rasterise_scan(int* icells, int which, const flo
     const float inv_x = p.inv_x, inv_y = p.inv_y;
     const int NY = p.NY;
     int* const origin = icells + 2 * (kPad * stride + kPad) + which;
-    auto put = [&](float x, float y, float z) {
+    // offset of the point's cell from `origin` and the bits of its z; (0, 0) for a point that cannot raise anything through the
+    // fast path (0 never exceeds a cell), after the exact path has dealt with it
+    auto prep = [&](float x, float y, float z, int& off, int& zi) {
         const float gx = __builtin_fmaf(x, inv_x, inv_x), gy = __builtin_fmaf(y, inv_y, inv_y);
         const float fx = floorf(gx), fy = floorf(gy);
         const float ex = 0.5f - fabsf((gx - fx) - 0.5f), ey = 0.5f - fabsf((gy - fy) - 0.5f);  // distance to a bin edge
         // every comparison is false for a NaN operand: NaN x or y leave the fast path
         const bool fast = (bool)((int)(z > 0.0f) & (int)(z < 1.0f) & (int)(fabsf(x) <= 1.0f) & (int)(fabsf(y) <= 1.0f) & (int)(x * y != 0.0f) &
                                  (int)(ex >= eps) & (int)(ey >= eps));
-        if (fast) {
-            int* cell = origin + 2 * ((int)fx * stride + (int)fy);
-            const int zi = __float_as_int(z);
-            if (*cell < zi) atomicMax(cell, zi);   // plain read first: same-cell lidar returns broadcast instead of serialising
-        } else if (z > 0.0f) {
+        off = fast ? 2 * ((int)fx * stride + (int)fy) : 0;
+        zi = fast ? __float_as_int(z) : 0;
+        if (!fast && z > 0.0f) {
             int col;
             const int lin = cart_lin(p, x, y, z, col);
             if (lin >= 0) {
@@ -55,29 +57,50 @@ __device__ __forceinline__ void rasterise_scan(int* icells, int which, const flo
             }
         }
     };
+    auto put = [&](float x, float y, float z) {
+        int off, zi;
+        prep(x, y, z, off, zi);
+        if (origin[off] < zi) atomicMax(origin + off, zi);
+    };
     int done = 0;
     if (aligned16(px) && aligned16(py) && aligned16(pz)) {
         const int n4 = n >> 2;
         const float4* x4 = reinterpret_cast<const float4*>(px);
         const float4* y4 = reinterpret_cast<const float4*>(py);
         const float4* z4 = reinterpret_cast<const float4*>(pz);
-#pragma nounroll
-        for (int i = threadIdx.x; i < n4; i += PF * kRadonWG) {
-            float4 X[PF], Y[PF], Z[PF];
+        const float4 none = make_float4(0.0f, 0.0f, 0.0f, 0.0f);     // z == 0 is substituted by 1e-4 only on the exact path, which z > 0 guards
+        float4 X[PF], Y[PF], Z[PF];
+        auto fetch = [&](int i, float4 (&A)[PF], float4 (&Bv)[PF], float4 (&Cv)[PF]) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 const int k = i + u * kRadonWG;
-                if (k < n4) { X[u] = stream_load4(x4 + k); Y[u] = stream_load4(y4 + k); Z[u] = stream_load4(z4 + k); }
+                if (k < n4) { A[u] = stream_load4(x4 + k); Bv[u] = stream_load4(y4 + k); Cv[u] = stream_load4(z4 + k); }
+                else { A[u] = none; Bv[u] = none; Cv[u] = none; }   // a quad past the end: four points that change nothing
             }
+        };
+        int i = threadIdx.x;
+        fetch(i, X, Y, Z);
+#pragma nounroll
+        while (i < n4) {
+            float4 Xn[PF], Yn[PF], Zn[PF];
+            const int inext = i + PF * kRadonWG;
+            fetch(inext, Xn, Yn, Zn);                                 // in flight while this stage is rasterised
+            int off[4 * PF], zi[4 * PF], cur[4 * PF];
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                if (i + u * kRadonWG < n4) {
-                    put(X[u].x, Y[u].x, Z[u].x);
-                    put(X[u].y, Y[u].y, Z[u].y);
-                    put(X[u].z, Y[u].z, Z[u].z);
-                    put(X[u].w, Y[u].w, Z[u].w);
-                }
+                prep(X[u].x, Y[u].x, Z[u].x, off[4 * u + 0], zi[4 * u + 0]);
+                prep(X[u].y, Y[u].y, Z[u].y, off[4 * u + 1], zi[4 * u + 1]);
+                prep(X[u].z, Y[u].z, Z[u].z, off[4 * u + 2], zi[4 * u + 2]);
+                prep(X[u].w, Y[u].w, Z[u].w, off[4 * u + 3], zi[4 * u + 3]);
             }
+#pragma unroll
+            for (int k = 0; k < 4 * PF; ++k) cur[k] = origin[off[k]];
+#pragma unroll
+            for (int k = 0; k < 4 * PF; ++k)
+                if (cur[k] < zi[k]) atomicMax(origin + off[k], zi[k]);
+#pragma unroll
+            for (int u = 0; u < PF; ++u) { X[u] = Xn[u]; Y[u] = Yn[u]; Z[u] = Zn[u]; }
+            i = inext;
         }
         done = n4 << 2;
     }
@@ -164,7 +187,8 @@ __global__ __launch_bounds__(kRadonWG) void k_bev_radon2(const float* __restrict
 template <int M, int S>
 void* fused_kernel(int pf)
 {
-    return pf >= 4 ? reinterpret_cast<void*>(k_bev_radon2<M, S, 4>) : reinterpret_cast<void*>(k_bev_radon2<M, S, 2>);
+    // `pf` load triplets in flight per lane = two register stages of pf / 2 quads each
+    return pf >= 4 ? reinterpret_cast<void*>(k_bev_radon2<M, S, 2>) : reinterpret_cast<void*>(k_bev_radon2<M, S, 1>);
 }
 
 }  // namespace
@@ -230,7 +254,7 @@ int mrs_ring_descriptors_batch(mrs_radon_plan* plan, const float* d_xyz, const i
     const int pairs = (batch + 1) / 2;
     const int grid = std::min(pairs, plan->fused_grid > 0 ? plan->fused_grid : std::max(plan->ctx->num_cu, 1));
     unsigned stagger_ticks = (unsigned)plan->fused_stagger_us * 100u;   // wall_clock64 ticks at 100 MHz
-    if (grid < 2) stagger_ticks = 0;
+    if (pairs <= grid) stagger_ticks = 0;   // a single round: nothing to phase-shift, the delay would only add latency
     unsigned* d_ctr = ctr.as<unsigned>();
     int* d_deg = plan->d_degenerate;
     void* args[] = {(void*)&d_xyz, (void*)&d_offsets, (void*)&cp, (void*)&p, (void*)&batch, (void*)&d_bev, (void*)&d_sino,

@@ -16,7 +16,7 @@ import bench  # noqa: E402
 from mr_slam_amd import bev, ring  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--chunks", type=int, default=8)
+ap.add_argument("--chunks", type=int, default=24)
 ap.add_argument("--batch", type=int, default=1024)
 args = ap.parse_args()
 dev = "cuda:0"
@@ -54,8 +54,8 @@ print("bit identical:", res["bit_identical"], flush=True)
 ms_sep = bench.ev_ms(lambda: separate(1), reps=5, warm=2)
 res["separate_ms_per_1024"] = ms_sep * 1024 / B
 print(f"separate kernels: {ms_sep:.4f} ms per launch of {B}", flush=True)
-for nch in sorted({1, 2, min(4, CH), CH}):
-    for stagger in (0, 60, 90, 130):
+for nch in sorted({1, min(8, CH), CH}):
+    for stagger in (0, 70, 90, 110):
         for pf in (2, 4):
             plan.set_option(plan.OPT_FUSED_STAGGER_US, stagger)
             plan.set_option(plan.OPT_FUSED_PREFETCH, pf)
@@ -63,7 +63,7 @@ for nch in sorted({1, 2, min(4, CH), CH}):
             row = {"launch_scans": nch * B, "stagger_us": stagger, "prefetch": pf, "ms_per_1024": ms / nch * 1024 / B}
             res["rows"].append(row)
             print(row, flush=True)
-for grid in (128, 192, 512):     # fewer / more persistent workgroups than compute units
+for grid in (240, 512):     # fewer / more persistent workgroups than compute units
     plan.set_option(plan.OPT_FUSED_STAGGER_US, 0); plan.set_option(plan.OPT_FUSED_PREFETCH, 2); plan.set_option(plan.OPT_FUSED_GRID, grid)
     ms = bench.ev_ms(lambda: fused(CH, buf), reps=3, warm=1)
     res["rows"].append({"launch_scans": CH * B, "grid": grid, "ms_per_1024": ms / CH * 1024 / B})

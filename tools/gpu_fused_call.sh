@@ -16,10 +16,8 @@ run() {   # name, timeout, command...
 }
 run ab 170 python tools/ab_fused.py
 run pytest_fused 150 python -m pytest tests/test_fused_gpu.py -x -q
-run bench_fuse8 120 python bench.py --steps 5 --warmup 2 --chunks 16 --fuse 8 --no-extra-legs --gicp-pairs 0 --no-cpu-baseline
-run bench_fuse0 120 python bench.py --steps 5 --warmup 2 --chunks 16 --fuse 0 --no-extra-legs --gicp-pairs 0 --no-cpu-baseline
-[ $SECONDS -lt 400 ] && run pytest_recent 200 python -m pytest tests/test_pybind_pygicp.py tests/test_cpp_adapter.py tests/test_disco_bevtrans_gpu.py tests/test_bench_contract_gpu.py -x -q -m gpu
-[ $SECONDS -lt 420 ] && run bench_default 240 python bench.py
-[ $SECONDS -lt 500 ] && run pytest_all 400 python -m pytest tests -x -q -m gpu
+run bench_fuse8 120 python bench.py --steps 5 --warmup 2 --chunks 24 --fuse 8 --no-extra-legs --gicp-pairs 0 --no-cpu-baseline
+run bench_fuse24 120 python bench.py --steps 5 --warmup 2 --chunks 24 --fuse 24 --no-extra-legs --gicp-pairs 0 --no-cpu-baseline
+[ $SECONDS -lt 300 ] && run pytest_all 300 python -m pytest tests -x -q -m gpu
 cat $S
 tail -3 $OUT/ab.log; tail -2 $OUT/pytest_fused.log

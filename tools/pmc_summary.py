@@ -24,7 +24,7 @@ def newest(paths):
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
-KEYS = {"k_cart_lds": "k_cart_lds", "k_polar_lds": "k_polar_lds", "k_radon2": "k_radon2", "k_ring_spec_corr_pairs": "k_ring_spec_corr_pairs",
+KEYS = {"k_cart_lds": "k_cart_lds", "k_polar_lds": "k_polar_lds", "k_radon2": "k_radon2", "k_bev_radon2": "k_bev_radon2", "k_ring_spec_corr_pairs": "k_ring_spec_corr_pairs",
         "k_ring_corr_fft": "k_ring_corr_fft", "k_linearize": "k_linearize", "k_nn_scan": "k_nn_scan", "k_knn_cov": "k_knn_cov"}
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in newest(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))):

@@ -20,6 +20,8 @@ for _ in range(3):
     bev.cart_bev(xyz, offs, 1, 1, 120, 120, 1, out=img.view(B, -1))
     bev.polar_bev(xyz, offs, 1, 1, 40, 120, 20)
     _, norm = plan.forward(img.view(B, 120, 120), raw=False, normalized=True)
+for _ in range(3):      # the single-launch form of the three kernels above (k_bev_radon2)
+    ring.ring_descriptors_fused(xyz, offs, raw=False, normalized=True)
 spec = ring.half_spectrum(norm)
 db = spec[torch.arange(10000, device=dev) % B].contiguous()
 for nq in (1, 4):
