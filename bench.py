@@ -37,7 +37,8 @@ from mr_slam_amd import bev, ring, shard, synth  # noqa: E402
 N_POINTS = 120_000
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
 DIST_THRESHOLD = 0.48     # RING_ros/config.py:17
-FUSE_DEFAULT = 0          # launches whose scans share one fused BEV + Radon kernel (0 = separate kernels)
+FUSE_DEFAULT = 16         # launches whose scans share one fused BEV + Radon kernel (0 = separate kernels): measured 1.97-1.99 M pairs/s
+                          # at 8-24 against 1.76 M with the two kernels per launch
 def _latest_pmc():
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc.json")))      # the newest round's counter passes
@@ -403,9 +404,12 @@ def main():
     img = torch.empty((B, 1, 120, 120), dtype=torch.float32, device=device)
     # the rank's exact database entries: Hermitian half spectra [61][120] complex64 (58 560 B) of the normalised
     # sinograms of every resident scan; slots CH, CH + 1 = the entries of the previous step's last two launches.
-    # The database a launch reads is the one built TWO launches earlier (DEPTH): its exchange then has two launches of
-    # kernels to hide behind.
-    DEPTH = 2
+    # The database a launch reads is the one built DEPTH launches earlier: its exchange then has DEPTH launches of kernels to
+    # hide behind.
+    FUSE = max(0, min(args.fuse, CH))
+    # with fused groups the exchanges of a group's launches are issued in a burst after its descriptor kernel: the database a
+    # launch reads is then one group (+ 2 launches) old, so that the burst has the next group's descriptor kernel to hide behind
+    DEPTH = min(FUSE + 2, CH) if FUSE else 2
     assert CH >= DEPTH
     spec32 = torch.empty((CH + DEPTH, B, 61, 120), dtype=torch.complex64, device=device)
     for c, (xyz, offs) in enumerate(chunks):
@@ -435,7 +439,6 @@ def main():
     setup_s = time.perf_counter() - t_setup
 
     ev = {k: [] for k in ("bev", "radon", "bev_radon", "corr", "sweep", "wait")}
-    FUSE = max(0, min(args.fuse, CH))
     if FUSE:
         whole = make_shard.whole                                   # [CH][B][3][N], one allocation
         norm_group = torch.empty((FUSE * B, 120, 120), dtype=torch.float32, device=device)

@@ -12,7 +12,7 @@ struct mrs_radon_plan {
     int* d_degenerate = nullptr;  // sinograms with zero / non-finite std seen by the fused normalisation
     bool two_in_lds = false; // two interleaved images fit the LDS (k_radon2)
     // tuning of the fused rasterise + Radon kernel (fused.hip; mrs_radon_plan_set_option)
-    int fused_stagger_us = 0;   // odd workgroups start this many microseconds late (phase-shifts the HBM-bound and the VALU-bound halves)
+    int fused_stagger_us = 70;  // odd workgroups start this many microseconds late (phase-shifts the HBM-bound and the VALU-bound halves)
     int fused_prefetch = 2;     // 16-byte load triplets in flight per lane while rasterising (2 or 4)
     int fused_grid = 0;         // persistent workgroups (0 = one per compute unit)
 };

@@ -10,11 +10,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra_env=None):
+def _run(extra_env=None, extra_args=()):
     env = dict(os.environ)
     env.update(extra_env or {})
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "32",
-                        "--chunks", "3", "--cpu-sample", "8", "--gicp-pairs", "2", "--gicp-iters", "6"], capture_output=True, text=True, env=env, timeout=600)
+                        "--chunks", "3", "--cpu-sample", "8", "--gicp-pairs", "2", "--gicp-iters", "6", *extra_args],
+                       capture_output=True, text=True, env=env, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     return json.loads(lines[-1])          # the JSON is the LAST line of stdout
@@ -39,6 +40,18 @@ def test_bench_line_contract():
     for leg in ("roofline_polar", "roofline_radon", "sweeps", "pipeline_shard", "dropin_latency"):
         assert leg in d, leg
     assert d["roofline_polar"]["bound"] == "hbm" and d["sweeps"]["ring_q1"]["pairs_per_s"] > 0 and d["sweeps"]["disco_q4"]["queries_per_s"] > 0
+    # default step: BEV + Radon + normalisation of a group of launches in one kernel; the rasteriser's own roofline rides along
+    assert d["config"]["fused_launches"] == 3 and "k_bev_radon2" in r["kernel"] and d["kernel_ms"]["bev_radon"] > 0
+    b = d["roofline_bev_scatter"]
+    assert b["bound"] == "hbm" and "k_cart_lds" in b["kernel"] and abs(b["frac"] - b["achieved"] / b["peak"]) < 1e-12
+
+
+def test_bench_line_two_kernel_step():
+    """--fuse 0: the rasteriser and the Radon kernel as separate launches (the roofline block is then the rasteriser's)"""
+    d = _run(extra_args=("--fuse", "0", "--no-extra-legs", "--no-cpu-baseline"))
+    assert "fused_launches" not in d["config"] and "k_cart_lds" in d["roofline"]["kernel"]
+    assert d["kernel_ms"]["bev"] > 0 and d["kernel_ms"]["radon"] > 0 and "bev_radon" not in d["kernel_ms"]
+    assert abs(d["value"] - 32 * 3 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
 
 
 def test_bench_collective_path_on_one_gpu():

@@ -88,7 +88,7 @@ def test_fused_blank_scan_counts_as_degenerate(dev):
     assert torch.isfinite(norm).all()
 
 
-@pytest.mark.parametrize("opts", [dict(), dict(stagger=40), dict(prefetch=4), dict(grid=7), dict(stagger=25, prefetch=4, grid=64)])
+@pytest.mark.parametrize("opts", [dict(), dict(stagger=70), dict(prefetch=4), dict(grid=7), dict(stagger=25, prefetch=4, grid=64)])
 def test_fused_persistent_rounds_and_tuning_knobs(dev, opts):
     """more pairs than workgroups (rounds handed out by the global counter), with every tuning knob: same bits"""
     import torch
@@ -115,7 +115,7 @@ def test_fused_persistent_rounds_and_tuning_knobs(dev, opts):
         b2 = ring.ring_descriptors(xyz, offs, want_bev=True, fused=True)        # run to run: the same bits (order-free max, fixed sums)
         _same(b, b2)
     finally:
-        plan.set_option(plan.OPT_FUSED_STAGGER_US, 0); plan.set_option(plan.OPT_FUSED_PREFETCH, 2); plan.set_option(plan.OPT_FUSED_GRID, 0)
+        plan.set_option(plan.OPT_FUSED_STAGGER_US, 70); plan.set_option(plan.OPT_FUSED_PREFETCH, 2); plan.set_option(plan.OPT_FUSED_GRID, 0)
 
 
 def test_fused_rejects_what_it_cannot_do(dev):

@@ -15,4 +15,5 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python $R/to
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python $R/tools/pmc_targets.py > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $OUT/pmc_valu -- python $R/tools/pmc_targets.py > $OUT/pmc_valu.log 2>&1
 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc_lds -- python $R/tools/pmc_targets.py > $OUT/pmc_lds.log 2>&1
+[ -n "$WITH_TESTS" ] && (cd $R && timeout 400 python -m pytest tests -x -q -m gpu > $OUT/pytest_all.log 2>&1; tail -2 $OUT/pytest_all.log)
 ls $OUT; tail -2 $OUT/*.log
