@@ -61,7 +61,7 @@ json.dump(traffic, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), inde
 with open(os.path.join(dst, f"{tag}_summary.md"), "w") as o:
     o.write(f"# rocprofv3 summary, round tag `{tag}`\n\n")
     o.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs` (tools/run_profiles.sh; "
-            "1 x MI355X, 32 launches x 1024 scan pairs per step, GICP leg 256 pairs x 120k: 5 cold + 20 forced iterations + a run to convergence).\n"
+            "1 x MI355X, 48 launches x 1024 scan pairs per step, BEV + Radon + normalisation of 16 launches per fused kernel call, GICP leg 256 pairs x 120k: 5 cold + 20 forced iterations + a run to convergence).\n"
             "PMC passes (separate runs over tools/pmc_targets.py, `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, no tracing; more counters in " + tag + "_pmc.md).\n\n")
     o.write("| kernel | calls | avg us | min us | max us | % of GPU time |\n|---|---|---|---|---|---|\n")
     for r in rows[:14]:
