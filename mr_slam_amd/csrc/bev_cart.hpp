@@ -10,6 +10,7 @@ struct CartP {
     float inv_x, inv_y, inv_h;
     float eps_x, eps_y, eps_h;
     int NX, NY, H, F;
+    float eps_fast;   // fused.hip: edge distance below which a point leaves the fma fast path (see make_cart)
 };
 
 __host__ __device__ inline float eps_for(int bins)
@@ -93,6 +94,9 @@ inline int make_cart(const mrs_bev_cfg* c, bool feat, CartP& p)
     p.gap_h = (float)(2.0 * (float)c->max_height / (float)c->num_height);
     p.inv_x = 1.0f / p.gap_x; p.inv_y = 1.0f / p.gap_y; p.inv_h = 1.0f / p.gap_h;
     p.eps_x = eps_for(p.NX); p.eps_y = eps_for(p.NY); p.eps_h = eps_for(p.H);
+    // fast-path quotient g = fma(v, inv, inv) with inv = fl32(1 / gap): two roundings, |g - (v + 1) / gap| <= bins * 2^-23 * (1 + 2^-24);
+    // the fraction / edge-distance arithmetic adds at most 2^-26.  (bins + 2) * 4e-7 is 3.4 times that bound.
+    p.eps_fast = (float)((p.NX > p.NY ? p.NX : p.NY) + 2) * 4e-7f;
     return MRS_OK;
 }
 

@@ -22,10 +22,17 @@ namespace {
 
 // Rasterise one scan into image `which` (0 = A, 1 = B) of the interleaved tile: the per-point logic of k_cart_lds (bev.hip),
 // with cell (ix, iy) at int index 2 * ((ix + kPad) * stride + iy + kPad) + which.  One workgroup per compute unit means 4 waves
-// per SIMD instead of the stand-alone rasteriser's 8, so latencies are hidden in the code instead of by occupancy:
-//   * the loads of the next PF point quads are in flight while the current ones are rasterised (two register stages);
+// per SIMD instead of the stand-alone rasteriser's 8, and the fused kernel as a whole is VALU-bound (rasterising + ray march
+// issue ~80 % of the VALU slots of a round), so this loop counts instructions:
+//   * full stages of PF point quads per lane run without bounds tests, the next stage's loads in flight while the current one is
+//     rasterised (two register stages); the ragged end of the scan takes the simple per-point form;
 //   * the 4 * PF cells of a stage are read from the LDS together, then compared, then (rarely) raised by ds_max: one LDS round
-//     trip per stage instead of one per point.  A read that is stale by the time of its compare only costs a redundant ds_max.
+//     trip per stage instead of one per point.  A read that is stale by the time of its compare only costs a redundant ds_max;
+//   * the cell offset is formed in fp32 (fx * stride + fy is an exact small integer: one fma + one conversion instead of two
+//     conversions and a quarter-rate integer multiply);
+//   * eps_fast (bev_cart.hpp): the distance from a bin edge below which a point leaves the fp32 path is 3.4x the worst-case error
+//     of the fma quotient instead of the stand-alone kernel's 17x, so that 1.3 % instead of 6 % of the wave-points drag their
+//     wave through the exact (fp64 division) path.  Same bits: tools/ab_fused.py compares billions of points per run.
 template <int PF>
 __device__ __forceinline__ void rasterise_scan(int* icells, int which, const float* __restrict__ px, const float* __restrict__ py,
                                                const float* __restrict__ pz, int n, const CartP& p, int stride)
@@ -33,8 +40,9 @@ __device__ __forceinline__ void rasterise_scan(int* icells, int which, const flo
     // Only z > 0 can change the map (max_h starts at 0: manager.cu:57,69).  Common case in one test: 0 < z < 1 and
     // 0 < |x|,|y| <= 1 and both quotients at least eps away from a bin edge -> the fp32 quotient's floor IS the reference's
     // double floor.  Everything else (rare) takes the exact per-axis path of cart_lin().
-    const float eps = fmaxf(p.eps_x, p.eps_y);
+    const float eps = p.eps_fast;
     const float inv_x = p.inv_x, inv_y = p.inv_y;
+    const float fstride = (float)stride;
     const int NY = p.NY;
     int* const origin = icells + 2 * (kPad * stride + kPad) + which;
     // offset of the point's cell from `origin` and the bits of its z; (0, 0) for a point that cannot raise anything through the
@@ -46,7 +54,8 @@ __device__ __forceinline__ void rasterise_scan(int* icells, int which, const flo
         // every comparison is false for a NaN operand: NaN x or y leave the fast path
         const bool fast = (bool)((int)(z > 0.0f) & (int)(z < 1.0f) & (int)(fabsf(x) <= 1.0f) & (int)(fabsf(y) <= 1.0f) & (int)(x * y != 0.0f) &
                                  (int)(ex >= eps) & (int)(ey >= eps));
-        off = fast ? 2 * ((int)fx * stride + (int)fy) : 0;
+        const int cell = (int)__builtin_fmaf(fx, fstride, fy);    // exact for the fast path's 0 <= fx, fy < 2^11; discarded otherwise
+        off = fast ? 2 * cell : 0;
         zi = fast ? __float_as_int(z) : 0;
         if (!fast && z > 0.0f) {
             int col;
@@ -68,39 +77,49 @@ __device__ __forceinline__ void rasterise_scan(int* icells, int which, const flo
         const float4* x4 = reinterpret_cast<const float4*>(px);
         const float4* y4 = reinterpret_cast<const float4*>(py);
         const float4* z4 = reinterpret_cast<const float4*>(pz);
-        const float4 none = make_float4(0.0f, 0.0f, 0.0f, 0.0f);     // z == 0 is substituted by 1e-4 only on the exact path, which z > 0 guards
-        float4 X[PF], Y[PF], Z[PF];
-        auto fetch = [&](int i, float4 (&A)[PF], float4 (&Bv)[PF], float4 (&Cv)[PF]) {
+        constexpr int kStage = PF * kRadonWG;       // quads per stage of the whole workgroup
+        const int stages = n4 / kStage;             // full stages: every lane owns PF valid quads, no bounds tests
+        auto fetch = [&](int s, float4 (&A)[PF], float4 (&Bv)[PF], float4 (&Cv)[PF]) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                const int k = i + u * kRadonWG;
-                if (k < n4) { A[u] = stream_load4(x4 + k); Bv[u] = stream_load4(y4 + k); Cv[u] = stream_load4(z4 + k); }
-                else { A[u] = none; Bv[u] = none; Cv[u] = none; }   // a quad past the end: four points that change nothing
+                const int k = s * kStage + u * kRadonWG + (int)threadIdx.x;
+                A[u] = stream_load4(x4 + k); Bv[u] = stream_load4(y4 + k); Cv[u] = stream_load4(z4 + k);
             }
         };
-        int i = threadIdx.x;
-        fetch(i, X, Y, Z);
-#pragma nounroll
-        while (i < n4) {
-            float4 Xn[PF], Yn[PF], Zn[PF];
-            const int inext = i + PF * kRadonWG;
-            fetch(inext, Xn, Yn, Zn);                                 // in flight while this stage is rasterised
+        auto rasterise = [&](const float4 (&A)[PF], const float4 (&Bv)[PF], const float4 (&Cv)[PF]) {
             int off[4 * PF], zi[4 * PF], cur[4 * PF];
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                prep(X[u].x, Y[u].x, Z[u].x, off[4 * u + 0], zi[4 * u + 0]);
-                prep(X[u].y, Y[u].y, Z[u].y, off[4 * u + 1], zi[4 * u + 1]);
-                prep(X[u].z, Y[u].z, Z[u].z, off[4 * u + 2], zi[4 * u + 2]);
-                prep(X[u].w, Y[u].w, Z[u].w, off[4 * u + 3], zi[4 * u + 3]);
+                prep(A[u].x, Bv[u].x, Cv[u].x, off[4 * u + 0], zi[4 * u + 0]);
+                prep(A[u].y, Bv[u].y, Cv[u].y, off[4 * u + 1], zi[4 * u + 1]);
+                prep(A[u].z, Bv[u].z, Cv[u].z, off[4 * u + 2], zi[4 * u + 2]);
+                prep(A[u].w, Bv[u].w, Cv[u].w, off[4 * u + 3], zi[4 * u + 3]);
             }
 #pragma unroll
             for (int k = 0; k < 4 * PF; ++k) cur[k] = origin[off[k]];
 #pragma unroll
             for (int k = 0; k < 4 * PF; ++k)
                 if (cur[k] < zi[k]) atomicMax(origin + off[k], zi[k]);
+        };
+        if (stages > 0) {
+            float4 X[PF], Y[PF], Z[PF];
+            fetch(0, X, Y, Z);
+#pragma nounroll
+            for (int s = 1; s < stages; ++s) {
+                float4 Xn[PF], Yn[PF], Zn[PF];
+                fetch(s, Xn, Yn, Zn);                                 // in flight while stage s - 1 is rasterised
+                rasterise(X, Y, Z);
 #pragma unroll
-            for (int u = 0; u < PF; ++u) { X[u] = Xn[u]; Y[u] = Yn[u]; Z[u] = Zn[u]; }
-            i = inext;
+                for (int u = 0; u < PF; ++u) { X[u] = Xn[u]; Y[u] = Yn[u]; Z[u] = Zn[u]; }
+            }
+            rasterise(X, Y, Z);
+        }
+        for (int k = stages * kStage + (int)threadIdx.x; k < n4; k += kRadonWG) {      // the ragged end: fewer quads than lanes x PF
+            const float4 A = stream_load4(x4 + k), Bv = stream_load4(y4 + k), Cv = stream_load4(z4 + k);
+            put(A.x, Bv.x, Cv.x);
+            put(A.y, Bv.y, Cv.y);
+            put(A.z, Bv.z, Cv.z);
+            put(A.w, Bv.w, Cv.w);
         }
         done = n4 << 2;
     }
