@@ -1,0 +1,59 @@
+/* fastpath_oracle.c -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+ *
+ * Exhaustive host check of the fp32 fast path of the Cartesian rasterisers (mr_slam_amd/csrc/bev.hip k_cart_lds,
+ * fused.hip rasterise_scan) against the reference formula of generate_bev_cython_binary/src/kernel.cu:52-54,
+ *     idx = (int)floor(((double)v + 1.0) / (double)gap),   gap = (float)(2.0 * max_length / num)  (kernel.cu:22-24).
+ * The device fast path is built from correctly rounded IEEE operations only (v_fma_f32, v_floor_f32, subtractions, compares),
+ * so the same expression evaluated here with fmaf / floorf (-ffp-contract=off, no fast-math) gives the device's bits:
+ *     g = fmaf(v, inv, inv), inv = 1.0f / gap;  f = floorf(g);  e = 0.5f - fabsf((g - f) - 0.5f);
+ *     the point stays on the fast path iff 0 < |v| <= 1 and e >= eps, and then uses (int)f.
+ * mrs_fastpath_check walks EVERY float bit pattern of the requested range (both signs), and reports how many values the fast path
+ * accepts, how many of those disagree with the reference (must be 0), and the largest |g - q| seen in units of bins
+ * (the bound eps has to stay above: bins * 2^-23).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+static inline float bits_to_float(uint32_t b)
+{
+    float f;
+    memcpy(&f, &b, sizeof f);
+    return f;
+}
+
+/* bits_lo..bits_hi: magnitude bit patterns (0x00000001 .. 0x3f800000 covers every non-zero |v| <= 1). */
+int mrs_fastpath_check(int bins, int max_length, float eps, uint32_t bits_lo, uint32_t bits_hi, uint64_t* accepted,
+                       uint64_t* mismatches, double* max_err_bins, float* first_bad)
+{
+    const float gap = (float)(2.0 * (float)max_length / (float)bins);
+    const float inv = 1.0f / gap;
+    uint64_t acc = 0, bad = 0;
+    double worst = 0.0;
+    float bad_v = 0.0f;
+#pragma omp parallel for schedule(static) reduction(+ : acc, bad) reduction(max : worst)
+    for (int64_t b = (int64_t)bits_lo; b <= (int64_t)bits_hi; ++b) {
+        for (int sign = 0; sign < 2; ++sign) {
+            const float v = bits_to_float((uint32_t)b | (sign ? 0x80000000u : 0u));
+            if (!(fabsf(v) <= 1.0f) || v == 0.0f) continue;
+            const float g = fmaf(v, inv, inv);
+            const float f = floorf(g);
+            const float e = 0.5f - fabsf((g - f) - 0.5f);
+            const double q = ((double)v + 1.0) / (double)gap;
+            const double err = fabs((double)g - q);
+            if (err > worst) worst = err;
+            if (!(e >= eps)) continue;
+            ++acc;
+            if ((int)f != (int)floor(q)) {
+                ++bad;
+#pragma omp critical
+                bad_v = v;
+            }
+        }
+    }
+    *accepted = acc;
+    *mismatches = bad;
+    *max_err_bins = worst;
+    *first_bad = bad_v;
+    return 0;
+}

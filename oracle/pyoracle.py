@@ -59,6 +59,18 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+def cart_fastpath_check(bins, eps, max_length=1, bits_lo=1, bits_hi=0x3F800000):
+    """Walks every float with magnitude bits in [bits_lo, bits_hi] (default: every non-zero |v| <= 1, both signs) through the
+    Cartesian rasterisers' fp32 fast path as the device evaluates it and compares with the reference's double formula
+    (oracle/fastpath_oracle.c).  Returns (accepted, mismatches, max |g - q| in bins, an offending value or 0.0)."""
+    f = lib().mrs_fastpath_check
+    f.argtypes = [C.c_int, C.c_int, C.c_float, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                  C.POINTER(C.c_double), C.POINTER(C.c_float)]
+    acc, bad, worst, v = C.c_uint64(), C.c_uint64(), C.c_double(), C.c_float()
+    f(int(bins), int(max_length), float(eps), int(bits_lo), int(bits_hi), C.byref(acc), C.byref(bad), C.byref(worst), C.byref(v))
+    return acc.value, bad.value, worst.value, v.value
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
