@@ -10,6 +10,8 @@
  * mrs_fastpath_check walks EVERY float bit pattern of the requested range (both signs), and reports how many values the fast path
  * accepts, how many of those disagree with the reference (must be 0), and the largest |g - q| seen in units of bins
  * (the bound eps has to stay above: bins * 2^-23).
+ * mrs_axispath_check does the same for cart_axis() (bev_cart.hpp; index kernels, reference-layout kernels and the exact path's
+ * first try): g = (v + 1.0f) * inv (three roundings), accepted iff eps <= g - floorf(g) <= 1 - eps.
  */
 #include <math.h>
 #include <stdint.h>
@@ -43,6 +45,41 @@ int mrs_fastpath_check(int bins, int max_length, float eps, uint32_t bits_lo, ui
             const double err = fabs((double)g - q);
             if (err > worst) worst = err;
             if (!(e >= eps)) continue;
+            ++acc;
+            if ((int)f != (int)floor(q)) {
+                ++bad;
+#pragma omp critical
+                bad_v = v;
+            }
+        }
+    }
+    *accepted = acc;
+    *mismatches = bad;
+    *max_err_bins = worst;
+    *first_bad = bad_v;
+    return 0;
+}
+
+int mrs_axispath_check(int bins, int max_length, float eps, uint32_t bits_lo, uint32_t bits_hi, uint64_t* accepted,
+                       uint64_t* mismatches, double* max_err_bins, float* first_bad)
+{
+    const float gap = (float)(2.0 * (float)max_length / (float)bins);
+    const float inv = 1.0f / gap;
+    uint64_t acc = 0, bad = 0;
+    double worst = 0.0;
+    float bad_v = 0.0f;
+#pragma omp parallel for schedule(static) reduction(+ : acc, bad) reduction(max : worst)
+    for (int64_t b = (int64_t)bits_lo; b <= (int64_t)bits_hi; ++b) {
+        for (int sign = 0; sign < 2; ++sign) {
+            const float v = bits_to_float((uint32_t)b | (sign ? 0x80000000u : 0u));
+            if (!(fabsf(v) <= 1.0f) || v == 0.0f) continue;   /* what cart_prep() leaves: non-zero, within [-1, 1] */
+            const float g = (v + 1.0f) * inv;
+            const float f = floorf(g);
+            const float fr = g - f;
+            const double q = ((double)v + 1.0) / (double)gap;
+            const double err = fabs((double)g - q);
+            if (err > worst) worst = err;
+            if (!(fr >= eps && fr <= 1.0f - eps)) continue;
             ++acc;
             if ((int)f != (int)floor(q)) {
                 ++bad;

@@ -59,11 +59,12 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
-def cart_fastpath_check(bins, eps, max_length=1, bits_lo=1, bits_hi=0x3F800000):
+def cart_fastpath_check(bins, eps, max_length=1, bits_lo=1, bits_hi=0x3F800000, axis_form=False):
     """Walks every float with magnitude bits in [bits_lo, bits_hi] (default: every non-zero |v| <= 1, both signs) through the
     Cartesian rasterisers' fp32 fast path as the device evaluates it and compares with the reference's double formula
-    (oracle/fastpath_oracle.c).  Returns (accepted, mismatches, max |g - q| in bins, an offending value or 0.0)."""
-    f = lib().mrs_fastpath_check
+    (oracle/fastpath_oracle.c); axis_form: cart_axis()'s (v + 1.0f) * inv instead of the fma.  Returns (accepted, mismatches,
+    max |g - q| in bins, an offending value or 0.0)."""
+    f = lib().mrs_axispath_check if axis_form else lib().mrs_fastpath_check
     f.argtypes = [C.c_int, C.c_int, C.c_float, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                   C.POINTER(C.c_double), C.POINTER(C.c_float)]
     acc, bad, worst, v = C.c_uint64(), C.c_uint64(), C.c_double(), C.c_float()

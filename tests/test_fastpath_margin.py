@@ -27,3 +27,11 @@ def test_cart_fast_path_needs_its_margin(oracle):
     """without a margin the fp32 quotient does cross bin edges: the check is able to fail"""
     accepted, mismatches, _, bad = oracle.cart_fastpath_check(120, 0.0)
     assert mismatches > 0 and bad != 0.0
+
+
+@pytest.mark.parametrize("bins", [120, 1000])
+def test_cart_axis_fast_try_is_exact_for_every_float(oracle, bins):
+    """cart_axis() (index kernels, reference-layout kernels, first try of the exact path): (v + 1.0f) * inv, three roundings"""
+    accepted, mismatches, worst, bad = oracle.cart_fastpath_check(bins, _eps_stand_alone(bins), axis_form=True)
+    assert mismatches == 0, f"bins={bins}: v={bad!r}"
+    assert accepted > 2.0e8 and worst <= bins * 3 * 2.0 ** -24 * 1.001 and _eps_stand_alone(bins) >= 5 * worst
