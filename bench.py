@@ -440,6 +440,12 @@ def main():
 
     ev = {k: [] for k in ("bev", "radon", "bev_radon", "corr", "sweep", "wait")}
     if FUSE:
+        if dist_on:
+            # one workgroup per pair of scans instead of persistent ones: a persistent workgroup holds its compute unit's whole
+            # register file (4 waves x 128 VGPRs per SIMD) until the launch ends, so RCCL's all-gather kernels could not start
+            # before that; workgroups that retire every ~0.2 ms let the collective's workgroups in between them
+            plan.set_option(plan.OPT_FUSED_GRID, 65535)
+            plan.set_option(plan.OPT_FUSED_STAGGER_US, 0)
         whole = make_shard.whole                                   # [CH][B][3][N], one allocation
         norm_group = torch.empty((FUSE * B, 120, 120), dtype=torch.float32, device=device)
         group_offs = torch.arange(FUSE * B + 1, dtype=torch.int64, device=device) * N_POINTS
