@@ -12,6 +12,8 @@
 // (a workgroup that streams points while its neighbours march rays has the memory system to itself and gets ahead: the
 // drift feeds itself; `fused_stagger_us` seeds it by starting every other workgroup half a period late), so that at any time
 // some compute units pull points from HBM while the others are busy in the VALU.  The BEV image never goes to HBM unless asked for.
+// Measured: 0.39-0.41 ms per 1024 scans from 8192 scans per launch against 0.50-0.54 for the two kernels; a round issues
+// about 0.8 of the VALU slots it has, i.e. the fused kernel sits near the VALU roof with 3.8 TB/s of point traffic underneath.
 #include "common.hpp"
 #include "bev_cart.hpp"
 #include "radon_device.hpp"
