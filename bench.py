@@ -634,6 +634,7 @@ def main():
                                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                 "traffic": r.get("hbm_bytes"), "algorithmic_bytes_per_launch": bev_bytes,
                                 "traffic_source": PMC_NAME if r else None,
+                                "valu_issue_frac": r.get("valu_issue_frac"), "lds_busy_frac": r.get("lds_busy_frac"),
                                 "note": "per 1024 scans; the kernel also carries the VALU-bound Radon march (1.47 M two-tap samples per image), "
                                         "so the HBM fraction of the fused kernel is below the stand-alone rasteriser's by construction",
                                 "ms_vs_separate_kernels": {"fused": kern_ms["bev_radon"], "bev_standalone": kern_ms["bev_standalone"],
