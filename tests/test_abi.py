@@ -40,6 +40,11 @@ def test_no_cpu_fallback_without_gpu():
     t = voxelocc.GPUTransformer(np.zeros(30, np.float32), 10, 1, 1, 120, 120, 1, 1)
     with pytest.raises(_lib.MrsError):
         t.retreive()
+    from mr_slam_amd import ring
+    xyz, offs = torch.zeros(30), torch.tensor([0, 10])
+    for fused in (False, True):       # host tensors are rejected, not computed on
+        with pytest.raises(_lib.MrsError):
+            ring.ring_descriptors(xyz, offs, fused=fused)
 
 
 def test_product_never_imports_oracle():
