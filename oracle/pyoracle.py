@@ -59,6 +59,16 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+def polar_height_fastpath_check(num_height, max_height, eps):
+    """Every finite float z through the polar rasterisers' height fast path against the reference's float formula
+    (oracle/fastpath_oracle.c).  Returns (accepted, mismatches, an offending z or 0.0)."""
+    f = lib().mrs_polar_height_check
+    f.argtypes = [C.c_int, C.c_int, C.c_float, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
+    acc, bad, v = C.c_uint64(), C.c_uint64(), C.c_float()
+    f(int(num_height), int(max_height), float(eps), C.byref(acc), C.byref(bad), C.byref(v))
+    return acc.value, bad.value, v.value
+
+
 def cart_fastpath_check(bins, eps, max_length=1, bits_lo=1, bits_hi=0x3F800000, axis_form=False):
     """Walks every float with magnitude bits in [bits_lo, bits_hi] (default: every non-zero |v| <= 1, both signs) through the
     Cartesian rasterisers' fp32 fast path as the device evaluates it and compares with the reference's double formula

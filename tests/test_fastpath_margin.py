@@ -35,3 +35,12 @@ def test_cart_axis_fast_try_is_exact_for_every_float(oracle, bins):
     accepted, mismatches, worst, bad = oracle.cart_fastpath_check(bins, _eps_stand_alone(bins), axis_form=True)
     assert mismatches == 0, f"bins={bins}: v={bad!r}"
     assert accepted > 2.0e8 and worst <= bins * 3 * 2.0 ** -24 * 1.001 and _eps_stand_alone(bins) >= 5 * worst
+
+
+@pytest.mark.parametrize("num_height", [20, 1])
+def test_polar_height_fast_path_is_exact_for_every_float(oracle, num_height):
+    """height layer of the polar rasterisers (kernel.cpp:48,66: float add, float division, floor), every finite float z"""
+    eps = max(2e-5, (2 * num_height + 16) * 2e-6)            # bev.hip make_polar()
+    accepted, mismatches, bad = oracle.polar_height_fastpath_check(num_height, 1, eps)
+    assert mismatches == 0, f"num_height={num_height}: z={bad!r}"
+    assert accepted > 1.0e9
