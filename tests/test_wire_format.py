@@ -1,0 +1,37 @@
+"""Host logic on the far side of the boundary (row N2): the loop-message ids and the loopinfo.txt line, pinned to the reference's own
+robotid_to_key (RING_ros/util.py:253-260, imported from /root/reference where that tree is present) and to the literal statement of
+main_RING.py:221-222,229-231 (the NCLT record decoder is pinned in tests/test_oracle_bev.py)."""
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import ref_import  # noqa: E402
+
+
+def test_loop_ids_and_loopinfo_line():
+    from mr_slam_amd import preprocess as P
+    id0, id1 = P.loop_ids(0, 41, 2, 7)
+    assert id0 == (97 << 56) + 42 and id1 == (99 << 56) + 8                  # main_RING.py:221-222: key + index + 1
+    assert chr(id0 >> 56) == "a" and chr(id1 >> 56) == "c" and (id0 & ((1 << 56) - 1)) == 42
+    assert id0 < 2 ** 63                                                      # fits dislam_msgs/Loop.msg's int64 up to robot 'z' + ...
+    assert P.loop_ids(25, 0, 0, 0)[0] == (122 << 56) + 1
+    # main_RING.py:229-231: ' '.join(str(i) for i in [ids..., position xyz, orientation xyzw])
+    assert P.loopinfo_line(0, 41, 2, 7, (1.0, 2.0, 3.0), (0.0, 0.0, 0.0, 1.0)) == "0 41 2 7 1.0 2.0 3.0 0.0 0.0 0.0 1.0"
+    line = P.loopinfo_line(1, 5, 0, 9, (np.float64(0.25), -1.5, 2.0), (0.0, 0.0, 0.5, 0.5))
+    assert line.split(" ") == ["1", "5", "0", "9", "0.25", "-1.5", "2.0", "0.0", "0.0", "0.5", "0.5"]
+
+
+@pytest.mark.skipif(not ref_import.available(), reason="/root/reference not present")
+def test_robotid_to_key_equals_the_reference_function():
+    from mr_slam_amd import preprocess as P
+    with ref_import.reference_modules("dropin") as ref:
+        for robot in range(26):
+            with contextlib.redirect_stdout(io.StringIO()):                   # the reference prints every call
+                want = ref.util.robotid_to_key(robot)
+            assert P.robotid_to_key(robot) == want
