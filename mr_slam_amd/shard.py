@@ -8,7 +8,9 @@ the CPU tests).  The reference has no collective at all; what shards here:
                             every rank holds the whole database, exactly like the per-robot
                             Python lists of RING_ros/main_RING.py:285-289 but device resident;
   * candidate scoring     : the (query, candidate) pair list / the GICP pair list is split
-                            contiguously; only the tiny result rows are gathered.
+                            contiguously; only the tiny result rows are gathered;
+  * alternatives that keep the database sharded: sharded_topk_sweep (queries travel, top-k rows
+                            come back) and fetch_rows (only the candidate rows asked for travel).
 No kernel contains an exchange step.
 """
 import torch
@@ -113,6 +115,41 @@ def sharded_topk_sweep(queries, local_db, sweep_fn, k, group=None):
     # rank-major concatenation = ascending global row among equal distances -> the stable sort keeps that order
     order = torch.argsort(pd, dim=1, stable=True)[:, :k]
     return torch.gather(pd, 1, order), torch.gather(pa, 1, order), torch.gather(pr, 1, order)
+
+
+def fetch_rows(local_db, global_rows, shard_rows, group=None):
+    """Request-based alternative to replicating the database for candidate scoring: every rank names the GLOBAL rows it needs
+    (`global_rows` int64 [M], any order, repeats allowed; rank r owns rows [sum(shard_rows[:r]), sum(shard_rows[:r + 1])) ) and
+    receives exactly those rows of the owners' exact entries, in request order.  Moves M rows per rank instead of the whole
+    database: with B candidates per launch out of N * B rows that is 1 / N of the all-gather's bytes, at the price of one request
+    round trip (three all-to-all collectives: counts, indices, rows).  `shard_rows`: rows per rank, the same list on every rank."""
+    world, rank = _world(group), _rank(group)
+    dev = local_db.device
+    rows = global_rows.to(torch.int64).reshape(-1)
+    bounds = torch.tensor([0] + list(shard_rows), dtype=torch.int64, device=dev).cumsum(0)      # [world + 1]
+    assert int(bounds[-1]) > 0 and len(shard_rows) == world and local_db.shape[0] == int(shard_rows[rank])
+    if rows.numel():
+        assert int(rows.min()) >= 0 and int(rows.max()) < int(bounds[-1]), "row outside the database"
+    if world == 1:
+        return local_db[rows]
+    owner = torch.bucketize(rows, bounds[1:], right=True)                       # rank that owns each requested row
+    order = torch.argsort(owner, stable=True)                                   # requests grouped by owner, original order within
+    send_idx = rows[order].contiguous()
+    send_counts = torch.bincount(owner, minlength=world).to(torch.int64)
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts, group=group)               # how many rows each peer wants from me
+    sc, rc = send_counts.tolist(), recv_counts.tolist()
+    want = torch.empty(int(sum(rc)), dtype=torch.int64, device=dev)
+    dist.all_to_all_single(want, send_idx, output_split_sizes=rc, input_split_sizes=sc, group=group)
+    payload = local_db[want - bounds[rank]].contiguous()                        # the rows my peers asked for, in their order
+    real = torch.view_as_real(payload) if payload.is_complex() else payload
+    got = torch.empty((int(sum(sc)),) + tuple(real.shape[1:]), dtype=real.dtype, device=dev)
+    dist.all_to_all_single(got, real.contiguous(), output_split_sizes=sc, input_split_sizes=rc, group=group)
+    if payload.is_complex():
+        got = torch.view_as_complex(got)
+    out = torch.empty_like(got)
+    out[order] = got                                                            # back to request order
+    return out
 
 
 class OwnerRescorer:

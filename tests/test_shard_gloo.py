@@ -88,3 +88,48 @@ def test_allgather_and_sharded_sweep_world2(tmp_path):
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def _fetch_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mr_slam_amd import shard
+    rng = np.random.default_rng(7)                                       # the same database on every rank, sharded raggedly
+    sizes = [5, 0, 3][:world] if world == 3 else [4, 6]
+    n_db = sum(sizes)
+    db = torch.from_numpy(rng.normal(size=(n_db, 3, 2)).astype(np.float32))
+    cdb = torch.view_as_complex(torch.from_numpy(rng.normal(size=(n_db, 4, 2)).astype(np.float32)))   # complex64 like the spectra
+    lo = sum(sizes[:rank])
+    local, clocal = db[lo:lo + sizes[rank]].clone(), cdb[lo:lo + sizes[rank]].clone()
+    rr = np.random.default_rng(100 + rank)                               # different requests per rank: repeats, own rows, remote rows
+    want = torch.from_numpy(rr.integers(0, n_db, size=11 + 3 * rank))
+    got = shard.fetch_rows(local, want, sizes)
+    assert got.shape == (want.numel(), 3, 2) and torch.equal(got, db[want])
+    cgot = shard.fetch_rows(clocal, want, sizes)
+    assert cgot.dtype == torch.complex64 and torch.equal(torch.view_as_real(cgot), torch.view_as_real(cdb[want]))
+    # a rank that asks for nothing still takes part in the collectives
+    none = shard.fetch_rows(local, torch.zeros(0, dtype=torch.int64) if rank == 0 else want[:2], sizes)
+    assert none.shape[0] == (0 if rank == 0 else 2) and (rank == 0 or torch.equal(none, db[want[:2]]))
+    # only rows of one owner
+    owner0 = torch.arange(sizes[0]).flip(0)
+    assert torch.equal(shard.fetch_rows(local, owner0, sizes), db[owner0])
+    dist.barrier()
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_fetch_rows_returns_the_owners_rows_in_request_order(tmp_path, world):
+    port = 31500 + (os.getpid() % 2000) + world
+    mp.spawn(_fetch_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def test_fetch_rows_single_process():
+    from mr_slam_amd import shard
+    db = torch.arange(12, dtype=torch.float32).view(6, 2)
+    rows = torch.tensor([5, 0, 0, 3])
+    assert torch.equal(shard.fetch_rows(db, rows, [6]), db[rows])
+    with pytest.raises(AssertionError):
+        shard.fetch_rows(db, torch.tensor([6]), [6])
