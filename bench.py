@@ -102,6 +102,18 @@ def ev_ms(fn, reps=5, warm=2):
     return a.elapsed_time(b) / reps
 
 
+def valu_roofline(pmc_entry, ms_per_launch, clock_ghz=2.4, simds=256 * 4):
+    """VALU-issue floor of a kernel from its PMC instruction count (SQ_INSTS_VALU per launch, wave instructions): every wave64
+    VALU instruction occupies its SIMD for 4 cycles, so the launch cannot take less than insts x 4 / (SIMDs x clock).  Clock = the
+    2.4 GHz maximum (MI355X_MICROARCH.md), i.e. the most demanding floor; returns None without counters."""
+    n = ((pmc_entry or {}).get("counters") or {}).get("SQ_INSTS_VALU")
+    if not n or not ms_per_launch:
+        return None
+    floor_ms = float(n) * 4.0 / (simds * clock_ghz * 1e9) * 1e3
+    return {"insts_valu_per_launch": float(n), "floor_ms": floor_ms, "frac": floor_ms / ms_per_launch, "clock_ghz": clock_ghz,
+            "note": "wave VALU instructions x 4 cycles / (1024 SIMDs x clock): the roof this kernel actually sits under"}
+
+
 def load_pmc():
     try:
         return json.load(open(PMC_FILE))
@@ -635,6 +647,7 @@ def main():
                                 "traffic": r.get("hbm_bytes"), "algorithmic_bytes_per_launch": bev_bytes,
                                 "traffic_source": PMC_NAME if r else None,
                                 "valu_issue_frac": r.get("valu_issue_frac"), "lds_busy_frac": r.get("lds_busy_frac"),
+                                "valu_roofline": valu_roofline(r, kern_ms["bev_radon"]),
                                 "note": "per 1024 scans; the kernel also carries the VALU-bound Radon march (1.47 M two-tap samples per image), "
                                         "so the HBM fraction of the fused kernel is below the stand-alone rasteriser's by construction",
                                 "ms_vs_separate_kernels": {"fused": kern_ms["bev_radon"], "bev_standalone": kern_ms["bev_standalone"],

@@ -35,3 +35,15 @@ def test_robotid_to_key_equals_the_reference_function():
             with contextlib.redirect_stdout(io.StringIO()):                   # the reference prints every call
                 want = ref.util.robotid_to_key(robot)
             assert P.robotid_to_key(robot) == want
+
+
+def test_bench_valu_roofline_helper():
+    """bench.py's VALU floor from the committed PMC counters: instruction count x 4 cycles over 1024 SIMDs at 2.4 GHz"""
+    import json
+    import bench
+    pmc = json.load(open(bench.PMC_FILE))
+    e = pmc["k_bev_radon2"]
+    v = bench.valu_roofline(e, 0.405)
+    assert v and abs(v["floor_ms"] - e["counters"]["SQ_INSTS_VALU"] * 4 / (1024 * 2.4e9) * 1e3) < 1e-12
+    assert 0.6 < v["frac"] < 1.0 and 0.25 < v["floor_ms"] < 0.40       # 196 M wave instructions per 1024 scans -> 0.32 ms
+    assert bench.valu_roofline({}, 0.4) is None and bench.valu_roofline(None, 0.4) is None and bench.valu_roofline(e, 0.0) is None
