@@ -166,6 +166,53 @@ def cpu_baseline(scans):
     return out
 
 
+def verify_timed_outputs(n, whole, norm_group, group_first, out_dist, out_ang, cand_idx, db_launch_of, seed=0):
+    """Checker leg, run AFTER the timed region (the oracle is the checker, never the thing measured): proves that the timed kernels did the
+    work.  For n random (launch, scan) picks out of the LAST fused descriptor launch of the timed loop:
+      * the normalised sinogram the timed launch left in HBM is bit-identical to a fresh launch of the same kernel on that scan, whose BEV
+        image and raw sinogram are bit-identical to the oracle's (bev_oracle.c / radon_oracle.c) and whose normalisation is within 2e-5 of
+        the reference's (util.py:197 restated);
+      * the (distance, angle) the timed correlation kernel wrote for that scan and its candidate equals fast_corr (util.py:362-374
+        restated) of the two ORACLE descriptors: angle exact, distance within 1e-5."""
+    from oracle import pyoracle as O
+    from oracle import corr_oracle as K
+    rng = np.random.default_rng(seed)
+    CHl, B = out_dist.shape
+    G = norm_group.shape[0] // B
+    ang = np.linspace(0, 2 * np.pi, 120).astype(np.float32)
+    offs1 = torch.arange(2, dtype=torch.int64, device=whole.device) * N_POINTS
+
+    def oracle_descriptor(c, i):
+        soa = whole[c, i].reshape(-1).cpu().numpy()
+        img = O.bev_cart(soa, 1, 1, 120, 120, 1).reshape(-1, 3)[:, 2].reshape(1, 120, 120)
+        sino = O.radon_parallel(img, ang, 120, 1.0)
+        return img, sino, K.tiring_from_sinogram(sino)
+    res = {"checked": 0, "bev_mismatches": 0, "sinogram_mismatches": 0, "timed_vs_fresh_launch_mismatches": 0, "angle_mismatches": 0,
+           "max_err_norm": 0.0, "max_err_dist": 0.0}
+    for _ in range(n):
+        g, i = int(rng.integers(0, G)), int(rng.integers(0, B))
+        c = group_first + g
+        img_o, sino_o, tir_o = oracle_descriptor(c, i)
+        img, sino, norm = ring.ring_descriptors_fused(whole[c, i].reshape(-1), offs1, want_bev=True, raw=True, normalized=True)
+        timed = norm_group[g * B + i]
+        res["timed_vs_fresh_launch_mismatches"] += int(not torch.equal(timed, norm[0]))
+        res["bev_mismatches"] += int(not np.array_equal(img[0].cpu().numpy(), img_o[0]))
+        res["sinogram_mismatches"] += int(not np.array_equal(sino[0].cpu().numpy(), sino_o[0]))
+        res["max_err_norm"] = max(res["max_err_norm"], float(np.abs(timed.cpu().numpy() - K.ring_normalize(sino_o)[0].numpy()).max()))
+        cl, ci = db_launch_of(c), int(cand_idx[c, i])
+        _, _, tir_c = oracle_descriptor(cl, ci)
+        wd, wa, _ = K.fast_corr(tir_o, tir_c)
+        res["max_err_dist"] = max(res["max_err_dist"], abs(float(out_dist[c, i]) - float(wd)))
+        res["angle_mismatches"] += int(int(out_ang[c, i]) != int(wa))
+        res["checked"] += 1
+    res["max_err"] = max(res["max_err_norm"], res["max_err_dist"])
+    res["ok"] = bool(res["bev_mismatches"] == 0 and res["sinogram_mismatches"] == 0 and res["timed_vs_fresh_launch_mismatches"] == 0 and
+                     res["angle_mismatches"] == 0 and res["max_err_norm"] < 2e-5 and res["max_err_dist"] < 1e-5)
+    res["what"] = ("random scans of the last fused launch of the timed loop: timed normalised sinogram == fresh launch (bits), BEV + raw sinogram "
+                   "== oracle (bits), normalisation < 2e-5, timed (dist, angle) vs fast_corr of the oracle descriptors (1e-5, exact)")
+    return res
+
+
 def _gicp_pairs(n_pairs, rank, seed0=500):
     from scipy.spatial.transform import Rotation as Rot
     rng = np.random.default_rng(2000 + rank)
@@ -383,6 +430,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=256, help="scans in the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="only the headline step (+ GICP unless --gicp-pairs 0)")
+    ap.add_argument("--verify", type=int, default=8, help="after the timed region: this many random outputs of the last fused launch against the "
+                    "oracle (N = 1, fused step only; 0 = skip)")
     ap.add_argument("--verify-exchange", action="store_true", help="N > 1: re-derive the last launch's replica scores from the exact remote entries")
     args = ap.parse_args()
 
@@ -693,6 +742,11 @@ def main():
             line["sweeps"] = sweep_legs(device, spec32[:CH].reshape(-1, 61, 120))
             line["pipeline_shard"] = pipeline_shard_leg(device, spec32[:CH].reshape(-1, 61, 120), gicp_res)
             line["dropin_latency"] = dropin_latency_leg(host_scans(chunks[0][0], 1)[0])
+        if FUSE and not dist_on and args.verify > 0:
+            # the outputs of the timed loop's last fused launch are still in norm_group / out_dist / out_ang
+            last = ((CH - 1) // FUSE) * FUSE
+            line["verify"] = verify_timed_outputs(args.verify, make_shard.whole, norm_group[:(CH - last) * B], last, out_dist, out_ang, cand_idx,
+                                                  lambda c: c - DEPTH if c >= DEPTH else CH - DEPTH + c)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(host_scans(chunks[0][0], min(args.cpu_sample, B)))
     else:

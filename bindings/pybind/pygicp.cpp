@@ -75,6 +75,8 @@ public:
     void set_max_iterations(int n) { prm_.max_iterations = n; }
     void set_rotation_epsilon(double e) { prm_.rotation_epsilon = e; }
     void set_transformation_epsilon(double e) { prm_.transformation_epsilon = e; }
+    // VGICP / VGICP_CUDA of align_points(): voxelised target, upstream's default neighbourhood (DIRECT1)
+    void set_voxel_mode(double resolution) { prm_.voxel_resolution = resolution; prm_.voxel_neighbors = 1; }
 
     py::array_t<double> align(const py::array_t<double, py::array::c_style | py::array::forcecast>& initial_guess)
     {
@@ -138,7 +140,10 @@ py::array_t<double> align_points(const Points& target, const Points& source, dou
     }
     g.set_max_correspondence_distance(max_correspondence_distance);
     g.set_correspondence_randomness(k_correspondences);
-    (void)voxel_resolution;
+    if (method != "GICP") {
+        if (!(voxel_resolution > 0.0)) throw std::invalid_argument("voxel_resolution must be positive for VGICP / VGICP_CUDA");
+        g.set_voxel_mode(voxel_resolution);       // the C ABI's voxel mode (mrs_gicp_params.voxel_resolution / voxel_neighbors)
+    }
     return g.align(initial_guess);
 }
 

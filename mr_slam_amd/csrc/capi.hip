@@ -1,6 +1,8 @@
 // capi.hip -- context management and status reporting of the C ABI (include/mrslam_hip.h).
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace mrs {
 
 static thread_local char g_err[512] = "";
@@ -25,6 +27,36 @@ struct ScratchBlock {
 };
 std::mutex g_scratch_mu;
 std::vector<ScratchBlock> g_scratch;   // a few dozen blocks at most: linear search
+
+// idle blocks kept for reuse: MRS_SCRATCH_IDLE_CAP_MB (default 8192).  A process that shares the GPU with another allocator
+// (torch's) can set it low; 0 returns every block as soon as its work is done
+size_t idle_cap()
+{
+    static const size_t cap = [] {
+        const char* e = getenv("MRS_SCRATCH_IDLE_CAP_MB");
+        const long long mb = e ? atoll(e) : 8192;
+        return (size_t)(mb < 0 ? 0 : mb) << 20;
+    }();
+    return cap;
+}
+
+// give idle blocks whose last use has completed back to the driver (all of them, or until `keep` bytes remain idle); lock held
+void trim_idle_locked(size_t keep, const void* spare)
+{
+    size_t idle = 0;
+    for (const ScratchBlock& b : g_scratch) idle += b.busy ? 0 : b.cap;
+    for (size_t i = 0; i < g_scratch.size() && idle > keep;) {
+        ScratchBlock& b = g_scratch[i];
+        if (!b.busy && b.p != spare && hipEventQuery(b.ev) == hipSuccess) {
+            idle -= b.cap;
+            (void)hipFree(b.p);
+            (void)hipEventDestroy(b.ev);
+            g_scratch.erase(g_scratch.begin() + i);
+        } else {
+            ++i;
+        }
+    }
+}
 }  // namespace
 
 void* scratch_acquire(size_t bytes, hipStream_t stream)
@@ -48,7 +80,15 @@ void* scratch_acquire(size_t bytes, hipStream_t stream)
         }
     }
     ScratchBlock nb{nullptr, want, dev, stream, nullptr, true};
-    if (hipMalloc(&nb.p, want) != hipSuccess) return nullptr;
+    if (hipMalloc(&nb.p, want) != hipSuccess) {
+        // out of memory with idle blocks in the cache: return every finished one to the driver and try once more
+        (void)hipGetLastError();
+        {
+            std::lock_guard<std::mutex> lock(g_scratch_mu);
+            trim_idle_locked(0, nullptr);
+        }
+        if (hipMalloc(&nb.p, want) != hipSuccess) return nullptr;
+    }
     if (hipEventCreateWithFlags(&nb.ev, hipEventDisableTiming) != hipSuccess) { (void)hipFree(nb.p); return nullptr; }
     std::lock_guard<std::mutex> lock(g_scratch_mu);
     g_scratch.push_back(nb);
@@ -65,21 +105,8 @@ void scratch_release(void* p, hipStream_t stream)
             b.busy = false;
             break;
         }
-    // keep the cache bounded: beyond 8 GiB of idle blocks, give finished ones back
-    size_t idle = 0;
-    for (const ScratchBlock& b : g_scratch) idle += b.busy ? 0 : b.cap;
-    if (idle > ((size_t)8 << 30)) {
-        for (size_t i = 0; i < g_scratch.size();) {
-            ScratchBlock& b = g_scratch[i];
-            if (!b.busy && b.p != p && hipEventQuery(b.ev) == hipSuccess) {
-                (void)hipFree(b.p);
-                (void)hipEventDestroy(b.ev);
-                g_scratch.erase(g_scratch.begin() + i);
-            } else {
-                ++i;
-            }
-        }
-    }
+    // keep the cache bounded: beyond the idle cap, give finished blocks back (not the one just released: its work is in flight)
+    trim_idle_locked(idle_cap(), p);
 }
 
 }  // namespace mrs

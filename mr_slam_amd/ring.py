@@ -126,10 +126,17 @@ def ring_descriptors(xyz, offsets, num_ring=NUM_RING, num_sector=NUM_SECTOR, wan
     Returns (bev | None, sinogram [B,A,D], normalised sinogram [B,A,D]).  fused: True / False picks the single-launch
     kernel / the two-call sequence (same bits), None decides by FUSED_MIN_BATCH."""
     d = _dev(xyz)
-    if fused is None:
+    auto = fused is None
+    if auto:
         fused = FUSED_MIN_BATCH is not None and offsets.numel() - 1 >= FUSED_MIN_BATCH
     if fused:
-        return ring_descriptors_fused(xyz, offsets, num_ring, num_sector, want_bev=want_bev, raw=True, normalized=True)
+        try:
+            return ring_descriptors_fused(xyz, offsets, num_ring, num_sector, want_bev=want_bev, raw=True, normalized=True)
+        except _lib.MrsError as e:
+            # geometries whose two interleaved images do not fit the LDS (or with more than 16 rays per lane) only have the
+            # two-call path: an automatic choice falls back to it, an explicit fused=True reports the refusal
+            if not auto or "unsupported configuration" not in str(e):
+                raise
     img = bev.cart_bev(xyz, offsets, MAX_LENGTH, MAX_HEIGHT, num_ring, num_sector, 1, layout=OUT_COMPACT)
     img = img.view(-1, num_ring, num_sector)
     sino, norm = ring_plan(d, num_ring, num_sector).forward(img, raw=True, normalized=True)
@@ -163,8 +170,10 @@ def generate_RING(pc, device="cuda:0"):
     pc_RING [1,A,D] cpu tensor, pc_TIRING complex64 [1,A,D] cpu tensor)."""
     xyz, offs = bev.pack_scans([np.asarray(pc)[:, 0:3]], device)
     img, sino, norm = ring_descriptors(xyz, offs, want_bev=True)
-    if ring_plan(_dev(xyz)).degenerate_count():
-        # torchvision's fn.normalize at util.py:197 raises for a constant sinogram (blank scan)
+    if not bool(norm.any()):
+        # torchvision's fn.normalize at util.py:197 raises for a constant sinogram (blank scan).  The kernels write an all-zero
+        # descriptor for such an image (a valid normalised sinogram has unit variance, so it can never be all zeros): the test is on
+        # THIS call's output, not on the plan-wide counter, which other callers and threads of the cached plan share
         raise ValueError("std evaluated to zero after conversion to torch.float32, leading to division by zero.")
     tiring = fft_angle(norm)
     return img.cpu().numpy(), sino.cpu(), tiring.cpu()
@@ -231,16 +240,17 @@ def fast_corr_RINGplusplus(a, b, device="cuda:0"):
     return dist.cpu().numpy()[0, 0], ang.cpu().numpy()[0, 0]
 
 
-def solve_translation(query, positive, rot_angle, device="cuda:0", want_shifts=False, literal=False):
-    """util.py:388-423: query, positive float32 [C,H,W]; returns (x, y, error).
+def solve_translation(query, positive, rot_angle, device="cuda:0", want_shifts=False, least_squares=False):
+    """util.py:388-423: query, positive float32 [C,H,W]; returns (x, y, error) -- by default the numbers the reference returns.
 
-    The 120 row correlations and their integer shifts always run on the GPU.  The final 120 x 2 solve has two readings:
-    literal=False (default) is the least-squares (pseudo-inverse) solution the function intends, evaluated in the kernel;
-    literal=True reproduces the reference's SVD branch as written (util.py:488-506: `v.t() @ s_inv @ u.t() @ b`, where
-    torch.svd already returns V, so the product is the least-squares solution turned by an orthogonal matrix that
-    depends on the SVD routine's sign / ordering choices).  A is almost isotropic (both singular values ~ sqrt(H/2)), so V
-    is not a property of the data but of the LAPACK build: the literal value is formed on the host with the same
-    torch.svd call the reference makes on CPU tensors (tests/golden/ref_corr.npz holds the reference-run numbers)."""
+    The 120 row correlations and their integer shifts always run on the GPU.  The final 120 x 2 solve:
+    default = the reference's call, `solve_overdetermined_linear_system(A, b, method='svd')` (util.py:415, 488-506), i.e. the product
+    `v.t() @ s_inv @ u.t() @ b` as written.  torch.svd already returns V, so this is the least-squares solution turned by an
+    orthogonal matrix that depends on the SVD routine's sign / ordering choices (A is almost isotropic, both singular values
+    ~ sqrt(H/2)): it is formed on the host with the same torch.svd call the reference makes on CPU tensors, on the GPU-computed
+    shifts, and equals the reference-run numbers of tests/golden/ref_corr.npz.  main_RING.py:177-178 consumes exactly these x, y.
+    least_squares=True returns the pseudo-inverse solution instead (the reference's own `method='pinv'` branch), evaluated in
+    the kernel."""
     q = torch.as_tensor(query, dtype=torch.float32).to(device).contiguous()
     p = torch.as_tensor(positive, dtype=torch.float32).to(device).contiguous()
     Cc, H, W = q.shape
@@ -248,11 +258,11 @@ def solve_translation(query, positive, rot_angle, device="cuda:0", want_shifts=F
     angles = torch.from_numpy(np.linspace(0, 2 * np.pi, H).astype(np.float32)).to(q.device)
     rot = torch.tensor([float(rot_angle)], dtype=torch.float32, device=q.device)
     res = torch.empty(3, dtype=torch.float32, device=q.device)
-    sh = torch.empty(H, dtype=torch.float32, device=q.device) if (want_shifts or literal) else None
+    sh = torch.empty(H, dtype=torch.float32, device=q.device) if (want_shifts or not least_squares) else None
     _lib.check(_lib.load().mrs_ring_solve_translation(_lib.ctx(d), _lib.ptr(q), _lib.ptr(p), 1, Cc, H, W,
                                                       _lib.ptr(angles), _lib.ptr(rot), _lib.ptr(res),
                                                       _lib.ptr(sh) if sh is not None else None, _lib.current_stream(d)))
-    if literal:
+    if not least_squares:
         b = sh.cpu()
         ang = torch.FloatTensor(np.linspace(0, 2 * np.pi, H).astype(np.float32)) + rot_angle
         A = torch.stack([torch.cos(ang), torch.sin(ang)], dim=1)

@@ -161,13 +161,14 @@ class OwnerRescorer:
     So every (query, candidate) whose replica distance lies within `margin` of the threshold is sent to the candidate's
     owner, scored there against the exact entry, and the decision is taken on that number.
 
-    Collectives have static shapes (at most `slots` requests per rank and call, padded), so every rank issues the same
-    sequence whatever its data: one all-gather of the requests (row index + the query's fp32 descriptor), one
-    all-reduce of the answers."""
+    Collectives have static shapes (`slots` requests per rank and round, padded), so every rank issues the same
+    sequence whatever its data: per round one all-gather of the requests (row index + the query's fp32 descriptor), one
+    all-reduce of the answers and one of the number of candidates still waiting; rounds repeat until no rank has any left, so
+    no ambiguous candidate is ever decided on its replica score."""
 
     def __init__(self, threshold, margin=2e-3, slots=64, group=None):
         self.threshold, self.margin, self.slots, self.group = float(threshold), float(margin), int(slots), group
-        self.stats = {"calls": 0, "requested": 0, "dropped": 0, "flipped": 0}
+        self.stats = {"calls": 0, "requested": 0, "rounds": 0, "flipped": 0}
 
     def ambiguous(self, dist_replica):
         return torch.nonzero((dist_replica - self.threshold).abs() < self.margin).reshape(-1)
@@ -184,39 +185,46 @@ class OwnerRescorer:
         amb = self.ambiguous(dist_replica)
         self.stats["calls"] += 1
         self.stats["requested"] += int(amb.numel())
-        if amb.numel() > S:                                  # bounded: the closest to the threshold first
-            keep = torch.argsort((dist_replica[amb] - self.threshold).abs())[:S]
-            self.stats["dropped"] += int(amb.numel()) - S
-            amb = amb[keep]
-        m = int(amb.numel())
-        rows = torch.full((S,), -1, dtype=torch.int64, device=dev)
-        rows[:m] = cand_row[amb].to(torch.int64)
-        q = torch.zeros((S,) + tuple(query_desc.shape[1:]), dtype=query_desc.dtype, device=dev)
-        q[:m] = query_desc[amb]
-        if world > 1:
-            all_rows = torch.empty((world * S,), dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(all_rows, rows, group=self.group)
-            qr = torch.view_as_real(q) if q.is_complex() else q
-            all_q = torch.empty((world * S,) + tuple(qr.shape[1:]), dtype=qr.dtype, device=dev)
-            dist.all_gather_into_tensor(all_q, qr.contiguous(), group=self.group)
-            if q.is_complex():
-                all_q = torch.view_as_complex(all_q)
-        else:
-            all_rows, all_q = rows, q
-        ans_d = torch.zeros((world * S,), dtype=torch.float32, device=dev)
-        ans_a = torch.zeros((world * S,), dtype=torch.int32, device=dev)
-        valid = all_rows >= 0
-        mine = torch.nonzero(valid & (owner_of_row(all_rows.clamp(min=0)) == rank)).reshape(-1)
-        if mine.numel():
-            d, a = exact_pair_fn(all_q[mine], local_row_of(all_rows[mine]))
-            ans_d[mine] = d.to(torch.float32); ans_a[mine] = a.to(torch.int32)
-        if world > 1:                                        # exactly one rank fills each slot
-            dist.all_reduce(ans_d, group=self.group)
-            dist.all_reduce(ans_a, group=self.group)
+        if amb.numel() > S:                                  # the closest to the threshold first
+            amb = amb[torch.argsort((dist_replica[amb] - self.threshold).abs())]
         out_d, out_a = dist_replica.clone(), angle_replica.clone()
-        if m:
-            new_d = ans_d[rank * S: rank * S + m]
-            self.stats["flipped"] += int(((new_d < self.threshold) != (dist_replica[amb] < self.threshold)).sum())
-            out_d[amb] = new_d
-            out_a[amb] = ans_a[rank * S: rank * S + m]
+        # fixed-size rounds of `slots` requests per rank until NO rank has an ambiguous candidate left: every rank issues the
+        # same sequence of collectives (the number of rounds is agreed on by an all-reduce of the remaining counts)
+        while True:
+            take, amb = amb[:S], amb[S:]
+            m = int(take.numel())
+            rows = torch.full((S,), -1, dtype=torch.int64, device=dev)
+            rows[:m] = cand_row[take].to(torch.int64)
+            q = torch.zeros((S,) + tuple(query_desc.shape[1:]), dtype=query_desc.dtype, device=dev)
+            q[:m] = query_desc[take]
+            if world > 1:
+                all_rows = torch.empty((world * S,), dtype=torch.int64, device=dev)
+                dist.all_gather_into_tensor(all_rows, rows, group=self.group)
+                qr = torch.view_as_real(q) if q.is_complex() else q
+                all_q = torch.empty((world * S,) + tuple(qr.shape[1:]), dtype=qr.dtype, device=dev)
+                dist.all_gather_into_tensor(all_q, qr.contiguous(), group=self.group)
+                if q.is_complex():
+                    all_q = torch.view_as_complex(all_q)
+            else:
+                all_rows, all_q = rows, q
+            ans_d = torch.zeros((world * S,), dtype=torch.float32, device=dev)
+            ans_a = torch.zeros((world * S,), dtype=torch.int32, device=dev)
+            valid = all_rows >= 0
+            mine = torch.nonzero(valid & (owner_of_row(all_rows.clamp(min=0)) == rank)).reshape(-1)
+            if mine.numel():
+                d, a = exact_pair_fn(all_q[mine], local_row_of(all_rows[mine]))
+                ans_d[mine] = d.to(torch.float32); ans_a[mine] = a.to(torch.int32)
+            left = torch.tensor([int(amb.numel())], dtype=torch.int64, device=dev)
+            if world > 1:                                        # exactly one rank fills each slot
+                dist.all_reduce(ans_d, group=self.group)
+                dist.all_reduce(ans_a, group=self.group)
+                dist.all_reduce(left, op=dist.ReduceOp.MAX, group=self.group)
+            if m:
+                new_d = ans_d[rank * S: rank * S + m]
+                self.stats["flipped"] += int(((new_d < self.threshold) != (dist_replica[take] < self.threshold)).sum())
+                out_d[take] = new_d
+                out_a[take] = ans_a[rank * S: rank * S + m]
+            self.stats["rounds"] = self.stats.get("rounds", 0) + 1
+            if int(left.item()) == 0:
+                break
         return out_d, out_a

@@ -114,9 +114,9 @@ def row_shifts(query, positive):
     return b
 
 
-def solve_translation(query, positive, rot_angle, literal=False):
-    """util.py:388-423.  Returns (x, y, error, shifts).  literal=True reproduces the v.t() quirk
-    of the reference's SVD branch (platform dependent), literal=False the intended solution."""
+def solve_translation(query, positive, rot_angle, literal=True):
+    """util.py:388-423.  Returns (x, y, error, shifts).  literal=True (default) is the reference's call, method='svd'
+    (util.py:415) with its v.t() product as written (platform dependent); literal=False its 'pinv' branch."""
     query = torch.as_tensor(query, dtype=torch.float32)
     _, H, W = query.shape
     angles = torch.FloatTensor(np.linspace(0, 2 * np.pi, H).astype(np.float32)) + rot_angle

@@ -270,3 +270,28 @@ def test_cloud_beyond_the_ordered_tile_window(dev, oracle):
     assert np.array_equal(oracle.pair_d2(src, T, tgt, corr), oracle.pair_d2(src, T, tgt, wcorr))   # exact up to true ties
     assert (corr == wcorr).mean() > 0.999 and (wcorr >= 0).mean() > 0.9
     assert abs(e[0] - we) < 2e-3 * abs(we)
+
+
+def test_timed_protocol_batch_matches_restatement(dev, oracle):
+    """The protocol bench.py times (BASELINE configs[2]): 256 pairs x 120k x 120k points in ONE batch, force_iterations = 20, k = 15,
+    max_correspondence_distance 5.0.  Eight pairs sampled out of that batch against the restatement run with the same forced
+    iteration count: within the north_star tolerance, and every pair did exactly 20 iterations with one NN pass each."""
+    import bench
+    from mr_slam_amd import gicp
+    n_pairs, iters = 256, 20
+    srcs, tgts = bench._gicp_pairs(n_pairs, 0)
+    b = gicp.GicpBatch(n_pairs)
+    b.set_params(k_correspondences=15, max_correspondence_distance=5.0, force_iterations=iters)
+    b.set_sources(srcs); b.set_targets(tgts)
+    T, conv, its = b.align()
+    assert (its == iters).all() and b.nn_passes == iters
+    rng = np.random.default_rng(4)
+    worst = (0.0, 0.0)
+    for i in sorted(rng.choice(n_pairs, 8, replace=False)):
+        g = oracle.Gicp(k=15, max_corr=5.0, threads=16)
+        g.set_source(srcs[i]); g.set_target(tgts[i])
+        wT, _, wits, _ = g.align(np.eye(4), force_iters=iters)
+        dt, dr = _pose_err(T[i], wT)
+        assert wits == iters and dt < TOL_T and dr < TOL_R, (i, dt, dr)
+        worst = (max(worst[0], dt), max(worst[1], dr))
+    print("timed-protocol GICP parity, worst of 8 pairs: %.2e m, %.2e rad" % worst)

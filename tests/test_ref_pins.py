@@ -90,15 +90,15 @@ def test_solve_translation_matches_reference_literal_and_pinv(G):
     from oracle import corr_oracle as K
     RA, RBs, RBe, rad, rad_e = _loop_AB(G)
     for i, (pos, r, tag) in enumerate(((RBs, rad, ""), (RBe, rad_e, "_extra"))):
-        x, y, err, sh = K.solve_translation(RA, pos, r, literal=True)
+        x, y, err, sh = K.solve_translation(RA, pos, r)            # default = the reference's call (method='svd')
         np.testing.assert_array_equal(sh, G["solve_translation_b"][i])                        # the 120 integer row shifts
         want = G[f"solve_translation_AB{tag}"]
         # the literal v.t() product of util.py:488-506 (CPU LAPACK): same library here -> same result
         np.testing.assert_allclose([_f(x), _f(y), _f(err)], want, rtol=2e-4, atol=2e-4)
         x, y, err, _ = K.solve_translation(RA, pos, r, literal=False)
         np.testing.assert_allclose([_f(x), _f(y)], G[f"solve_translation_AB{tag}_pinv"], rtol=1e-4, atol=1e-4)
-    # the data behind DESIGN.md's C3 decision: the literal result is the least-squares solution turned by an orthogonal
-    # matrix (same norm, larger residual), so it is not what the function intends
+    # for the record: the reference's result is its own least-squares solution turned by an orthogonal matrix
+    # (same norm, larger residual); the drop-in returns the reference's numbers by default
     lit, pinv = G["solve_translation_AB"][:2], G["solve_translation_AB_pinv"]
     assert abs(np.linalg.norm(lit) - np.linalg.norm(pinv)) < 1e-3 and np.linalg.norm(lit - pinv) > 1.0
 

@@ -57,14 +57,17 @@ def test_fast_corr_matches_reference(G, clouds):
 
 
 def test_loop_sequence_and_solve_translation_match_reference(G):
-    """main_RING.py:147-178 replayed on the product: fast_corr -> row shifts -> solve_translation (both branches)."""
+    """main_RING.py:147-178 replayed on the product: fast_corr -> row shifts -> solve_translation.  The DEFAULT call returns the
+    reference-run numbers (its method='svd' call, util.py:415); least_squares=True its 'pinv' branch."""
     from mr_slam_amd import ring
     RA, RBs, RBe, rad, rad_e = _loop_AB(G)
     for i, (pos, r, tag) in enumerate(((RBs, rad, ""), (RBe, rad_e, "_extra"))):
-        x, y, err, sh = ring.solve_translation(RA, pos, r, DEV, want_shifts=True, literal=True)
+        x, y, err, sh = ring.solve_translation(RA, pos, r, DEV, want_shifts=True)
         np.testing.assert_array_equal(sh, G["solve_translation_b"][i])                  # every one of the 120 row shifts
         np.testing.assert_allclose([_f(x), _f(y), _f(err)], G[f"solve_translation_AB{tag}"], rtol=2e-4, atol=2e-4)
         x, y, err = ring.solve_translation(RA, pos, r, DEV)
+        np.testing.assert_allclose([_f(x), _f(y), _f(err)], G[f"solve_translation_AB{tag}"], rtol=2e-4, atol=2e-4)
+        x, y, err = ring.solve_translation(RA, pos, r, DEV, least_squares=True)
         np.testing.assert_allclose([_f(x), _f(y)], G[f"solve_translation_AB{tag}_pinv"], rtol=1e-4, atol=1e-4)
 
 

@@ -75,7 +75,14 @@ def _worker(rank, world, port, out_dir):
                               lambda qq, lr: ((qq[:, 0] - own[lr]).abs(), torch.full((qq.shape[0],), 7, dtype=torch.int32)))
     amb = (replica - thr).abs() < 2e-3
     assert amb[0] and torch.equal(got_d[amb], exact[amb]) and torch.equal(got_d[~amb], replica[~amb])
-    assert (got_a[amb] == 7).all() and rs.stats["flipped"] >= 1 and rs.stats["dropped"] == 0
+    assert (got_a[amb] == 7).all() and rs.stats["flipped"] >= 1 and rs.stats["rounds"] == 1
+    # more ambiguous candidates than slots: further rounds until no rank has any left (nothing is decided on a replica score)
+    assert int(amb.sum()) == 2
+    rs1 = shard.OwnerRescorer(thr, margin=2e-3, slots=1)
+    got_d1, got_a1 = rs1.rescore(replica, torch.zeros(4, dtype=torch.int32), cand_row, qv[:, None],
+                                 lambda rows: rows // 5, lambda rows: rows % 5,
+                                 lambda qq, lr: ((qq[:, 0] - own[lr]).abs(), torch.full((qq.shape[0],), 7, dtype=torch.int32)))
+    assert torch.equal(got_d1, got_d) and torch.equal(got_a1, got_a) and rs1.stats["rounds"] == 2 and rs1.stats["requested"] == 2
     # empty shard on one rank
     e = shard.allgather_ragged(torch.zeros((0 if rank else 2, 3)))
     assert e.shape == (2, 3)
