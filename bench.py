@@ -103,15 +103,25 @@ def ev_ms(fn, reps=5, warm=2):
 
 
 def valu_roofline(pmc_entry, ms_per_launch, clock_ghz=2.4, simds=256 * 4):
-    """VALU-issue floor of a kernel from its PMC instruction count (SQ_INSTS_VALU per launch, wave instructions): every wave64
-    VALU instruction occupies its SIMD for 4 cycles, so the launch cannot take less than insts x 4 / (SIMDs x clock).  Clock = the
-    2.4 GHz maximum (MI355X_MICROARCH.md), i.e. the most demanding floor; returns None without counters."""
-    n = ((pmc_entry or {}).get("counters") or {}).get("SQ_INSTS_VALU")
+    """VALU-pipe floor of a kernel from its PMC instruction counts.  A wave64 VALU instruction occupies its SIMD for 2 cycles (fp32 add / mul,
+    integer add, logic, moves), 4 (conversions, fract / floor / max, 24- and 32-bit multiplies, shift-adds, every packed-fp32 and fp64 operation)
+    or 8 (rcp / sqrt): measured, profiles/r03_ubench.md.  No counter reports pipe-busy cycles, so the floor is the class-weighted cycle count of
+    tools/pmc_summary.py (`valu_pipe_cycles_est`) / (SIMDs x clock) when the profile has the class counters, and always the two bounds
+    insts x 2 and insts x 4.  Clock = the 2.4 GHz maximum, i.e. the most demanding floor; returns None without counters."""
+    c = (pmc_entry or {}).get("counters") or {}
+    n = c.get("SQ_INSTS_VALU")
     if not n or not ms_per_launch:
         return None
-    floor_ms = float(n) * 4.0 / (simds * clock_ghz * 1e9) * 1e3
-    return {"insts_valu_per_launch": float(n), "floor_ms": floor_ms, "frac": floor_ms / ms_per_launch, "clock_ghz": clock_ghz,
-            "note": "wave VALU instructions x 4 cycles / (1024 SIMDs x clock): the roof this kernel actually sits under"}
+    per = simds * clock_ghz * 1e9 * 1e-3
+    est = (pmc_entry or {}).get("valu_pipe_cycles_est")
+    out = {"insts_valu_per_launch": float(n), "floor_ms_bounds": [float(n) * 2.0 / per, float(n) * 4.0 / per],
+           "frac_bounds": [float(n) * 2.0 / per / ms_per_launch, float(n) * 4.0 / per / ms_per_launch], "clock_ghz": clock_ghz,
+           "note": "wave VALU instructions x cycles per instruction / (1024 SIMDs x clock); cycles per instruction by class, profiles/r03_ubench.md"}
+    if est:
+        out["floor_ms"] = float(est) / per
+        out["frac"] = out["floor_ms"] / ms_per_launch
+        out["mean_cycles_per_inst"] = float(est) / float(n)
+    return out
 
 
 def load_pmc():
@@ -339,6 +349,80 @@ def sweep_legs(device, spec_pool, n_db=10_000):
     return out
 
 
+def build_legs(device, chunks):
+    """Descriptor GENERATION of the other two detectors and the ingest-inclusive RING rate, same synthetic scans:
+      disco_build  : 1024 scans -> polar BEV 40 x 120 x 20 (disco_ros/main.py:112-125) -> DiSCO.forward without the UNet (DiSCO.py:315-334);
+      ringpp_build : 64 scans -> exact kNN k = 30 + eigen features (util.py:123-170, 204-219) -> 9-plane feature BEV -> Radon of the 6 feature
+                     channels -> |FFT along the detector axis| (util.py:220-250);
+      ingest       : 64 raw metric clouds [n, 4] float32 -> voxel_down_sample(0.2) (main_RING.py:257-259, one call per scan like the node) ->
+                     load_pc_infer crop / scale (util.py:91-112, one batched launch) -> fused descriptor kernel."""
+    from mr_slam_amd import disco, pointfeat, preprocess
+    out = {}
+    xyz, offs = chunks[0]
+    B = offs.numel() - 1
+    ms_bev = ev_ms(lambda: bev.polar_bev(xyz, offs, 1, 1, 40, 120, 20), reps=3, warm=1)
+    occ = bev.polar_bev(xyz, offs, 1, 1, 40, 120, 20)
+    ms_desc = ev_ms(lambda: disco.disco_from_bev(occ), reps=3, warm=1)
+    del occ
+    out["disco_build"] = {"scans_per_s": B / (ms_bev + ms_desc) * 1e3, "batch": B, "ms": {"polar_bev_40x120x20": ms_bev, "disco_descriptor": ms_desc},
+                          "note": "polar BEV scatter (HBM: 12 B/point + 384 KB of cells per scan) + 2-D FFT / signature of the 40 x 120 image"}
+    S = min(64, B)
+    pts = make_shard.whole[0, :S].permute(0, 2, 1).reshape(S * N_POINTS, 3).contiguous()      # [S * N, 3] AoS, pre-processed like load_pc_infer
+    h_offs = np.arange(S + 1, dtype=np.int64) * N_POINTS
+    d_offs = torch.from_numpy(h_offs).to(device)
+    ms_feat = ev_ms(lambda: pointfeat.point_features(pts, h_offs, 30, want=("planes",)), reps=2, warm=1)
+    planes = pointfeat.point_features(pts, h_offs, 30, want=("planes",))["planes"]
+    ms_fbev = ev_ms(lambda: bev.feat_bev(planes, d_offs, 9, 1, 1, 120, 120, 1, layout=1), reps=3, warm=1)
+    fb = bev.feat_bev(planes, d_offs, 9, 1, 1, 120, 120, 1, layout=1)
+    plan = ring.ring_plan(torch.device(device).index or 0)
+    imgs = fb.reshape(S * 6, 120, 120)
+    ms_radon = ev_ms(lambda: plan.forward(imgs), reps=3, warm=1)
+    sino, _ = plan.forward(imgs)
+    ms_fft = ev_ms(lambda: ring.forward_row_fft(sino.view(S, 6, 120, 120)), reps=3, warm=1)
+    tot = ms_feat + ms_fbev + ms_radon + ms_fft
+    out["ringpp_build"] = {"scans_per_s": S / tot * 1e3, "batch": S, "k": 30,
+                           "ms": {"knn_k30_features": ms_feat, "feature_bev_9_planes": ms_fbev, "radon_6_channels": ms_radon, "row_fft_magnitude": ms_fft},
+                           "knn_points_per_s": S * N_POINTS / ms_feat * 1e3,
+                           "bound": "k_knn_features: VALU -- exact k = 30 nearest of every point by culled brute force over Morton-ordered LDS tiles "
+                                    "(two passes: the 32 smallest distances by a v_med3_f32 chain, then the indices within the k-th distance), eigenvalues "
+                                    "in fp64; inputs stay L2 / LDS resident (16 B per point in, 36 B per point out), so no HBM or MFMA roof applies"}
+    del planes, fb, sino, imgs
+    # ingest: raw clouds as the ROS message delivers them (x, y, z, intensity), ~130 k points before down-sampling
+    R = min(64, B)
+    raws = []
+    for i in range(R):
+        p = synth.lidar_scan(900 + i % 4, 130_000, metric=True)
+        th = 0.1 * i
+        c, sn = np.float32(np.cos(th)), np.float32(np.sin(th))
+        q = np.empty((p.shape[0], 4), np.float32)
+        q[:, 0] = c * p[:, 0] - sn * p[:, 1]; q[:, 1] = sn * p[:, 0] + c * p[:, 1]; q[:, 2] = p[:, 2]; q[:, 3] = 0.5
+        raws.append(torch.from_numpy(q).to(device))
+
+    def ingest(timing=None):
+        t = [time.perf_counter()]
+        down = [preprocess.voxel_down_sample(r, 0.2) for r in raws]                 # float64 [m, 3] each (the node's open3d call)
+        torch.cuda.synchronize(); t.append(time.perf_counter())
+        cat = torch.cat(down)
+        ro = np.concatenate([[0], np.cumsum([d.shape[0] for d in down])]).astype(np.int64)
+        soa, so = preprocess.load_pc_infer_batch(cat, ro)
+        torch.cuda.synchronize(); t.append(time.perf_counter())
+        ring.ring_descriptors_fused(soa, so, raw=False, normalized=True)
+        torch.cuda.synchronize(); t.append(time.perf_counter())
+        if timing is not None:
+            timing.append((t[1] - t[0], t[2] - t[1], t[3] - t[2], int(ro[-1])))
+    ingest()
+    tm = []
+    for _ in range(3):
+        ingest(tm)
+    v, c, f, kept = [float(np.mean([x[i] for x in tm])) for i in range(4)]
+    out["ingest"] = {"scans_per_s": R / (v + c + f), "batch": R, "raw_points_per_scan": 130_000, "points_after_voxel_0.2": kept / R,
+                     "ms": {"voxel_down_sample_per_scan": 1e3 * v / R, "crop_scale_batch": 1e3 * c, "fused_descriptors": 1e3 * f},
+                     "note": "raw float32 [n, 4] clouds resident in HBM -> open3d-equivalent voxel grid (sort-based, deterministic, one call and one host "
+                             "synchronisation per scan like the ROS callback) -> load_pc_infer -> BEV + Radon + normalise; reported next to `value`, "
+                             "never instead of it"}
+    return out
+
+
 def pipeline_shard_leg(device, spec_pool, gicp_res):
     """BASELINE configs[4], one GPU's share: RING++ database of 50 000 / 8 = 6 250 entries ([6][61][120] complex64,
     2.2 GB) swept by one query, one elevation-map frame (move + 120k points + fuse + features + ray tracing, row N3), and
@@ -432,7 +516,13 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="only the headline step (+ GICP unless --gicp-pairs 0)")
     ap.add_argument("--verify", type=int, default=8, help="after the timed region: this many random outputs of the last fused launch against the "
                     "oracle (N = 1, fused step only; 0 = skip)")
-    ap.add_argument("--verify-exchange", action="store_true", help="N > 1: re-derive the last launch's replica scores from the exact remote entries")
+    ap.add_argument("--verify-exchange", action="store_true", help="N > 1: re-derive the last launch's scores from the exact remote entries")
+    ap.add_argument("--exchange", choices=("fetch", "allgather"), default="fetch", help="N > 1: how candidate rows and the swept database reach a rank. "
+                    "fetch (default): the database stays sharded, a pre-planned all-to-all brings exactly the candidate rows asked for (exact fp32) and "
+                    "the per-launch query goes through a sharded top-k sweep; allgather: fp16 replicas of every new descriptor to every rank "
+                    "(north_star's wording) + owner re-scoring")
+    ap.add_argument("--fused-grid", choices=("auto", "persistent", "per_pair"), default="auto", help="workgroups of the fused descriptor kernel: persistent (one "
+                    "per compute unit) or one per pair of scans; auto = persistent at N = 1, per_pair at N > 1 (lets RCCL's kernels in)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -490,26 +580,52 @@ def main():
     # N > 1: the replicated database of the previous launch's descriptors (fp16 replicas, 29 280 B each; the owner keeps
     # the exact fp32 entry) -- at > 1 M descriptors/s/GPU fp32 spectra would exceed what the xGMI links carry
     gathered = None
-    if dist_on:
+    EXCH = args.exchange if dist_on else None
+    fetch_plans = fetch_q = None
+    if EXCH == "allgather":
         gathered = [torch.empty((NDB, 61, 120, 2), dtype=torch.float16, device=device) for _ in range(DEPTH + 1)]
         for gbuf in gathered:
             gbuf.copy_(torch.view_as_real(spec32[CH - 1]).to(torch.float16).repeat(world, 1, 1, 1))
+    elif EXCH == "fetch":
+        # request phase once, ahead of time (the candidates of every launch are known before the step starts): per launch ONE all-to-all
+        # of exactly the rows asked for, exact fp32, issued FETCH_AHEAD launches early; the swept query of launch c travels after launch c
+        # and its sharded top-1 sweep runs on a side stream while launch c + 1 computes
+        shard_rows = [B] * world
+        fetch_plans = [shard.RowFetchPlan(cand_idx[c].to(torch.int64), shard_rows) for c in range(CH)]
+        fetch_q = {}
+        FETCH_AHEAD = max(1, min(DEPTH, 4))
+        ident_idx = torch.arange(B, dtype=torch.int32, device=device)
+        side = torch.cuda.Stream(device=device)
+        q_all = [torch.empty((world, 61, 120, 2), dtype=torch.float32, device=device) for _ in range(2)]
+        sweep_pending = []                             # (launch, work of the query all-gather, event after the launch's kernels)
+        last_fetched = [None]
     pending = []                                       # (work, source tensor) of the exchanges still in flight, oldest first
     launch_no = [0]
-    rescorer = shard.OwnerRescorer(DIST_THRESHOLD, margin=2e-3, slots=64) if dist_on else None
+    rescorer = shard.OwnerRescorer(DIST_THRESHOLD, margin=2e-3, slots=64) if EXCH == "allgather" else None
     setup_s = time.perf_counter() - t_setup
 
     ev = {k: [] for k in ("bev", "radon", "bev_radon", "corr", "sweep", "wait")}
+    fused_grid = args.fused_grid if args.fused_grid != "auto" else ("per_pair" if dist_on else "persistent")
+
+    def set_fused_grid(mode):
+        # per_pair: one workgroup per pair of scans instead of persistent ones.  A persistent workgroup holds its compute unit's whole
+        # register file (4 waves x 128 VGPRs per SIMD) until the launch ends, so RCCL's kernels could not start before that;
+        # workgroups that retire every ~0.2 ms let the collective's workgroups in between them
+        plan.set_option(plan.OPT_FUSED_GRID, 65535 if mode == "per_pair" else 0)
+        plan.set_option(plan.OPT_FUSED_STAGGER_US, 0 if mode == "per_pair" else 70)
     if FUSE:
-        if dist_on:
-            # one workgroup per pair of scans instead of persistent ones: a persistent workgroup holds its compute unit's whole
-            # register file (4 waves x 128 VGPRs per SIMD) until the launch ends, so RCCL's all-gather kernels could not start
-            # before that; workgroups that retire every ~0.2 ms let the collective's workgroups in between them
-            plan.set_option(plan.OPT_FUSED_GRID, 65535)
-            plan.set_option(plan.OPT_FUSED_STAGGER_US, 0)
+        set_fused_grid(fused_grid)
         whole = make_shard.whole                                   # [CH][B][3][N], one allocation
         norm_group = torch.empty((FUSE * B, 120, 120), dtype=torch.float32, device=device)
         group_offs = torch.arange(FUSE * B + 1, dtype=torch.int64, device=device) * N_POINTS
+
+    def run_sharded_sweep(c, qwork):
+        """(side stream) the queries of launch c, one per rank, against this rank's shard of the database launch c reads; only the
+        best (dist, angle, global row) per query travels back (shard.sharded_topk_sweep, static shapes, one packed collective)"""
+        qwork.wait()
+        qs = torch.view_as_complex(q_all[c % 2])
+        dk, ak, rk = shard.sharded_topk_sweep(qs, spec32[db_slot(c)], ring.corr_sweep_fft, 1, shard_rows=shard_rows, packed=True)
+        sweep_val[c] = dk[rank, 0]; sweep_row[c] = rk[rank, 0]
 
     def step(record):
         def mark():
@@ -536,7 +652,7 @@ def main():
                 e1 = mark() if record else None
                 _, norm = plan.forward(img.view(B, 120, 120), raw=False, normalized=True)
                 e2 = mark() if record else None
-            if dist_on:
+            if EXCH == "allgather":
                 ew0 = mark() if record else None
                 while len(pending) >= DEPTH:           # the compute stream waits for the exchange of launch g - DEPTH
                     pending.pop(0)[0].wait()           # (stream-side wait, the host does not block)
@@ -546,14 +662,41 @@ def main():
                 # correlation with their candidates out of the replicated database, one launch
                 spec, spec16, _, _ = ring.spectrum_corr_pairs_db(norm, db, cand_idx[c], want_f16=True, out=(out_dist[c], out_ang[c]),
                                                                  spec_out=spec32[c])
+            elif EXCH == "fetch":
+                if c == 0:                             # the first fetches of the step read the slots copied at its start
+                    for L in range(min(FETCH_AHEAD, CH)):
+                        fetch_q[L] = fetch_plans[L].fetch(spec32[db_slot(L)], async_op=True)
+                work, finish = fetch_q.pop(c)
+                ew0 = mark() if record else None
+                if work is not None:
+                    work.wait()                        # the compute stream waits for the rows requested FETCH_AHEAD launches ago
+                ew1 = mark() if record else None
+                rows = finish()                        # [B,61,120] complex64: the candidates' exact entries, in request order
+                last_fetched[0] = rows
+                spec, spec16, _, _ = ring.spectrum_corr_pairs_db(norm, rows, ident_idx, out=(out_dist[c], out_ang[c]), spec_out=spec32[c])
+                db = None
             else:
                 db = spec32[db_slot(c)]
                 spec, spec16, _, _ = ring.spectrum_corr_pairs_db(norm, db, cand_idx[c], out=(out_dist[c], out_ang[c]), spec_out=spec32[c])
             e3 = mark() if record else None
-            d, a = ring.corr_sweep_fft(spec[:1], db)   # one new query against the whole (replicated) database
-            torch.min(d, 1, out=(sweep_val[c:c + 1], sweep_row[c:c + 1]))
+            if EXCH == "fetch":
+                # the rows of launch c + FETCH_AHEAD: slot c + FETCH_AHEAD - DEPTH <= c is written on every owner by now
+                L = c + FETCH_AHEAD
+                if L < CH:
+                    fetch_q[L] = fetch_plans[L].fetch(spec32[db_slot(L)], async_op=True)
+                # this launch's query to every rank; the sharded top-1 sweep of the PREVIOUS launch's queries on the side stream
+                done = torch.cuda.Event(); done.record()
+                with torch.cuda.stream(side):
+                    side.wait_event(done)
+                    qw = dist.all_gather_into_tensor(q_all[c % 2], torch.view_as_real(spec32[c, :1]).contiguous(), async_op=True)
+                    sweep_pending.append((c, qw))
+                    if len(sweep_pending) > 1:
+                        run_sharded_sweep(*sweep_pending.pop(0))
+            else:
+                d, a = ring.corr_sweep_fft(spec[:1], db)   # one new query against the whole (replicated) database
+                torch.min(d, 1, out=(sweep_val[c:c + 1], sweep_row[c:c + 1]))
             e4 = mark() if record else None
-            if dist_on:
+            if EXCH == "allgather":
                 pending.append((dist.all_gather_into_tensor(gathered[g % (DEPTH + 1)], spec16, async_op=True), spec16))
             if record:
                 if not FUSE:
@@ -561,7 +704,12 @@ def main():
                 ev["corr"].append((e2, e3)); ev["sweep"].append((e3, e4))
                 if dist_on:
                     ev["wait"].append((ew0, ew1))
-        if dist_on:
+        if EXCH == "fetch":
+            with torch.cuda.stream(side):              # the last launch's sweep; the compute stream joins the side stream at the step's end
+                while sweep_pending:
+                    run_sharded_sweep(*sweep_pending.pop(0))
+            torch.cuda.current_stream().wait_stream(side)
+        if EXCH == "allgather":
             # exact re-scoring of the candidates whose replica score is within 2e-3 of the acceptance threshold: global row r
             # of launch c's database = descriptor r % B of rank r // B, built in launch c - DEPTH
             slot = torch.tensor([db_slot(c) for c in range(CH)], device=device)
@@ -578,6 +726,8 @@ def main():
         if dist_on:
             while pending:
                 pending.pop(0)[0].wait()
+            if EXCH == "fetch":
+                torch.cuda.current_stream().wait_stream(side)
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -611,8 +761,8 @@ def main():
 
     verify = None
     if dist_on and args.verify_exchange:
-        # the last launch scored its new descriptors against fp16 replicas of the descriptors every rank built DEPTH
-        # launches earlier: gather those exact fp32 entries and score the same (query, candidate row) pairs against them
+        # the last launch scored its new descriptors against what the exchange delivered (fp16 replicas / fetched fp32 rows) of the
+        # descriptors every rank built DEPTH launches earlier: gather those exact fp32 entries and score the same pairs against them
         fence()
         c = CH - 1
         exact_db = shard.allgather_ragged(torch.view_as_real(spec32[db_slot(c)]).contiguous())
@@ -621,6 +771,14 @@ def main():
         err = (d_ex - out_dist[c]).abs()
         verify = {"checked": int(err.numel()), "max_abs_dist_error": float(err.max()),
                   "angle_mismatches": int((a_ex != out_ang[c]).sum()), "remote_candidates": int((cand_idx[c] // B != rank).sum())}
+        if EXCH == "fetch":
+            # the fetched rows are the owners' entries bit for bit, and the sharded top-1 sweep equals a sweep over the gathered database
+            verify["fetched_rows_bit_identical"] = bool(torch.equal(torch.view_as_real(last_fetched[0]),
+                                                                    torch.view_as_real(exact_db[cand_idx[c].long()])))
+            d_full, _ = ring.corr_sweep_fft(spec32[c, :1].contiguous(), exact_db)
+            v_full, r_full = torch.min(d_full, 1)
+            verify["sweep_value_equal"] = bool(float(v_full[0]) == float(sweep_val[c]))
+            verify["sweep_row_equal"] = bool(int(r_full[0]) == int(sweep_row[c]))
 
     topk_cmp = None
     if dist_on:
@@ -674,8 +832,12 @@ def main():
                        "pairs_per_rank_per_step": B * CH, "pairs_per_launch": B, "launches_per_step": CH,
                        "database_rows_swept_per_launch": NDB,      # grows with the world size: the replicated database is world x B rows
                        "resident_scan_bytes_per_rank": B * CH * 12 * N_POINTS, "points_per_scan": N_POINTS,
-                       "parallelism": f"scan-sharded x{world}" + (" + RCCL all-gather of fp16 descriptor replicas, candidates and "
-                                                                  "sweeps read the replicated database, owner re-scoring" if dist_on else "")},
+                       "parallelism": f"scan-sharded x{world}" + ("" if not dist_on else
+                                                                  " + RCCL all-gather of fp16 descriptor replicas, candidates and sweeps read the "
+                                                                  "replicated database, owner re-scoring" if EXCH == "allgather" else
+                                                                  " + database kept sharded: RCCL all-to-all of the candidate rows asked for (exact "
+                                                                  "fp32, pre-planned), per-launch query all-gathered for a sharded top-1 sweep"),
+                       "exchange": EXCH, "fused_grid": fused_grid if FUSE else None},
             "timed_region_s": elapsed,
             "setup_s": setup_s,
             "kernel_ms": kern_ms,
@@ -706,13 +868,27 @@ def main():
                                             "ms": kern_ms["bev_standalone"], "traffic": pmc.get("k_cart_lds", {}).get("hbm_bytes"),
                                             "algorithmic_bytes_per_launch": bev_bytes}
         if dist_on:
-            per_launch = (world - 1) * B * 29280
-            line["exchange"] = {"format": "fp16 half spectra, 29 280 B per descriptor", "allgather_bytes_in_per_rank_per_launch": per_launch,
-                                "allgather_bytes_in_per_rank_per_step": per_launch * CH,
-                                "inbound_gbs_needed_at_this_rate": per_launch * CH / (1e-3 * line["ms_per_step"]) / 1e9,
+            # bytes a rank receives per launch under either design, and the inbound rate each would need at the measured step time
+            ag_launch = (world - 1) * B * 29280
+            if EXCH == "fetch":
+                fetch_launch = float(np.mean([pl.bytes_in(58560) for pl in fetch_plans]))
+            else:
+                fetch_launch = (world - 1) / world * B * 58560                    # expected for uniformly drawn candidates
+            sweep_launch = (world - 1) * (58560 + world * 16)                     # the other ranks' queries + their packed top-1 answers
+            step_s = 1e-3 * line["ms_per_step"]
+            line["exchange"] = {"design": EXCH,
+                                "allgather": {"format": "fp16 half spectra, 29 280 B per descriptor, every descriptor to every rank",
+                                              "bytes_in_per_rank_per_launch": ag_launch,
+                                              "inbound_gbs_needed_at_this_rate": ag_launch * CH / step_s / 1e9},
+                                "fetch": {"format": "exact fp32 half spectra, 58 560 B per candidate row actually asked for (pre-planned all-to-all) + one "
+                                                    "query per rank and launch all-gathered for the sharded top-1 sweep",
+                                          "bytes_in_per_rank_per_launch": fetch_launch + sweep_launch,
+                                          "rows_bytes_in_per_rank_per_launch": fetch_launch, "sweep_bytes_in_per_rank_per_launch": sweep_launch,
+                                          "inbound_gbs_needed_at_this_rate": (fetch_launch + sweep_launch) * CH / step_s / 1e9,
+                                          "launches_ahead": FETCH_AHEAD if EXCH == "fetch" else None},
                                 "compute_stream_wait_ms_per_launch": kern_ms.get("wait"),
                                 "compute_stream_wait_ms_per_step": kern_ms.get("wait", 0.0) * CH,
-                                "rescore": rescorer.stats, "designs": topk_cmp, "verify": verify}
+                                "rescore": rescorer.stats if rescorer else None, "designs": topk_cmp, "verify": verify}
         if not args.no_extra_legs:
             # polar BEV (the rasteriser north_star names), DiSCO layout 40 x 120 x 20, same scans
             xyz0, offs0 = chunks[0]
@@ -741,12 +917,22 @@ def main():
             line["roofline_polar"]["frac_of_measured_copy"] = line["roofline_polar"]["achieved"] / copy_gbs
             line["sweeps"] = sweep_legs(device, spec32[:CH].reshape(-1, 61, 120))
             line["pipeline_shard"] = pipeline_shard_leg(device, spec32[:CH].reshape(-1, 61, 120), gicp_res)
+            line["builds"] = build_legs(device, chunks)
             line["dropin_latency"] = dropin_latency_leg(host_scans(chunks[0][0], 1)[0])
         if FUSE and not dist_on and args.verify > 0:
             # the outputs of the timed loop's last fused launch are still in norm_group / out_dist / out_ang
             last = ((CH - 1) // FUSE) * FUSE
             line["verify"] = verify_timed_outputs(args.verify, make_shard.whole, norm_group[:(CH - last) * B], last, out_dist, out_ang, cand_idx,
                                                   lambda c: c - DEPTH if c >= DEPTH else CH - DEPTH + c)
+        if FUSE and not args.no_extra_legs:
+            # the other workgroup shape of the fused kernel on the same scans (N > 1 runs per_pair so that RCCL's kernels get in): measured, not assumed
+            other = "per_pair" if fused_grid == "persistent" else "persistent"
+            ng = min(FUSE, CH)
+            set_fused_grid(other)
+            ms_other = ev_ms(lambda: ring.ring_descriptors_fused(make_shard.whole[:ng].view(-1), group_offs[:ng * B + 1], raw=False, normalized=True,
+                                                                 out_norm=norm_group[:ng * B]), reps=3, warm=1) / ng
+            set_fused_grid(fused_grid)
+            line["roofline"]["fused_grid_ms_per_launch"] = {fused_grid: kern_ms["bev_radon"], other: ms_other}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(host_scans(chunks[0][0], min(args.cpu_sample, B)))
     else:

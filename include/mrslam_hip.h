@@ -171,8 +171,9 @@ int mrs_ring_descriptors_batch(mrs_radon_plan* plan, const float* d_xyz, const i
 /* Tuning knobs of mrs_ring_descriptors_batch (results do not depend on them). */
 enum mrs_radon_option {
     MRS_RADON_OPT_FUSED_STAGGER_US = 1, /* odd workgroups start this many microseconds late (default 70, 0 = off) */
-    MRS_RADON_OPT_FUSED_PREFETCH = 2,   /* 16-byte load triplets in flight per lane while rasterising: 2 (default) or 4 */
-    MRS_RADON_OPT_FUSED_GRID = 3        /* persistent workgroups (0 = one per compute unit)                      */
+    MRS_RADON_OPT_FUSED_PREFETCH = 2,   /* 16-byte load triplets in flight per lane while rasterising: 2, 4 or 6 */
+    MRS_RADON_OPT_FUSED_GRID = 3,       /* persistent workgroups (0 = one per compute unit)                      */
+    MRS_RADON_OPT_FUSED_VARIANT = 4     /* 1: rays dealt to lanes by length (slot tables), rolled ray loop; 0: (angle, detector) order */
 };
 int mrs_radon_plan_set_option(mrs_radon_plan* plan, int32_t option, int32_t value);
 

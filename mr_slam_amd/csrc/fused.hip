@@ -19,6 +19,7 @@
 #include "radon_device.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -205,11 +206,151 @@ __global__ __launch_bounds__(kRadonWG) void k_bev_radon2(const float* __restrict
     }
 }
 
+// Variant with slot tables (radon_device.hpp: mrs_radon_plan::d_slot): lane slot s = k * 1024 + lane marches ray slot_ray[s].  The rays of a
+// wave have (almost) the same length, the ray loop is a real loop (one 16-byte table entry per ray, the next one requested while the current
+// ray is marched) and the raw sums go to the output buffer instead of 30 registers: the normalisation re-reads them after a barrier in the
+// library-wide lane <-> ray order (threadIdx.x + k * 1024), so every reduction runs in the order of normalize_store / k_normalize and the
+// bits do not change.  The registers this frees pay for deeper point prefetch in the rasteriser stage (PF quads x 2 stages per lane).
+struct SlotP {
+    const int4* slot;
+    const float* nrm;
+    const int* ray;
+};
+
+template <int MAX_RAYS_PER_LANE, int STRIDE, int PF>
+__global__ __launch_bounds__(kRadonWG) void k_bev_radon3(const float* __restrict__ xyz, const int64_t* __restrict__ offs, CartP cp, RadonP p, SlotP sp,
+                                                         int batch, float* __restrict__ bev_out, float* __restrict__ sino_raw,
+                                                         float* __restrict__ sino_norm, float* __restrict__ park, int* __restrict__ degenerate,
+                                                         unsigned* __restrict__ next_pair, unsigned stagger_ticks,
+                                                         unsigned long long* __restrict__ prof, int dev_skip)
+{
+    // dev_skip (development aid, MRS_FUSED_SKIP): 1 = no rasterising, 2 = no ray march (results are then meaningless)
+    // prof (development aid, MRS_FUSED_PROF=1): 100 MHz ticks per phase summed over workgroups and rounds: clear, rasterise, march, normalise
+    unsigned long long tp = 0;
+    auto stamp = [&](int phase) {
+        if (prof && threadIdx.x == 0) {
+            const unsigned long long now = wall_clock64();
+            if (phase >= 0) atomicAdd(prof + phase, now - tp);
+            tp = now;
+        }
+    };
+    extern __shared__ __attribute__((aligned(16))) int lds_i[];   // [rows][stride] cells of (A, B) texels, as ints while rasterising
+    __shared__ double red[2][16];
+    __shared__ unsigned s_next;
+    const v2f* cells = reinterpret_cast<const v2f*>(lds_i);
+    const int pairs = (batch + 1) >> 1;
+    const int rows = p.H + 2 * kPad;
+    const int rays = p.A * p.D;
+    const int hw = p.H * p.W;
+    const unsigned tile0 = (unsigned)(uintptr_t)(lds_cptr)reinterpret_cast<const char*>(cells);
+    if (stagger_ticks != 0u && (blockIdx.x & 1u)) {
+        const unsigned long long t0 = wall_clock64();   // constant-rate counter (100 MHz)
+        while (wall_clock64() - t0 < (unsigned long long)stagger_ticks) __builtin_amdgcn_s_sleep(64);
+    }
+    unsigned pair = blockIdx.x;
+    while (pair < (unsigned)pairs) {
+        // opaque copy of the lane id: per-round addresses derived from it stay inside the persistent loop instead of being hoisted into
+        // (and spilled from) dozens of registers
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int b0 = 2 * (int)pair, b1 = b0 + 1;
+        const bool two = b1 < batch;
+        int2* z2 = reinterpret_cast<int2*>(lds_i);
+        stamp(-1);
+        for (int i = threadIdx.x; i < rows * p.stride; i += kRadonWG) z2[i] = make_int2(0, 0);
+        __syncthreads();
+        stamp(0);
+        if (!(dev_skip & 1)) {
+            const int64_t o = offs[b0];
+            const int n = (int)(offs[b0 + 1] - o);
+            const float* px = xyz + 3 * o;
+            rasterise_scan<PF>(lds_i, 0, px, px + n, px + 2 * (size_t)n, n, cp, p.stride);
+        }
+        if (two && !(dev_skip & 1)) {
+            const int64_t o = offs[b1];
+            const int n = (int)(offs[b1 + 1] - o);
+            const float* px = xyz + 3 * o;
+            rasterise_scan<PF>(lds_i, 1, px, px + n, px + 2 * (size_t)n, n, cp, p.stride);
+        }
+        __syncthreads();
+        stamp(1);
+        if (bev_out) {   // the COMPACT layout of mrs_bev_cart_batch: [b][ix][iy]
+            for (int i = threadIdx.x; i < hw; i += kRadonWG) {
+                const int y = i / p.W, x = i - y * p.W;
+                const int2 c = z2[(y + kPad) * p.stride + x + kPad];
+                bev_out[(size_t)b0 * hw + i] = __int_as_float(c.x);
+                if (two) bev_out[(size_t)b1 * hw + i] = __int_as_float(c.y);
+            }
+        }
+        // raw sums are parked where the normalisation will read them: the normalised output itself (overwritten in place), else the
+        // raw output, else this workgroup's scratch rows
+        float* const dA = sino_norm ? sino_norm + (size_t)b0 * rays : sino_raw ? sino_raw + (size_t)b0 * rays : park + (size_t)blockIdx.x * 2 * rays;
+        float* const dB = sino_norm ? sino_norm + (size_t)b1 * rays : sino_raw ? sino_raw + (size_t)b1 * rays : dA + rays;
+        float* const rA = sino_norm && sino_raw ? sino_raw + (size_t)b0 * rays : nullptr;      // both outputs wanted: raw goes there as well
+        int4 e = sp.slot[tid];
+        float nrm = sp.nrm[tid];
+        int ray = sp.ray[tid];
+#pragma nounroll
+        for (int k = 0; k < MAX_RAYS_PER_LANE; ++k) {
+            const int4 ce = e;
+            const float cn = nrm;
+            const int cr = ray;
+            if (k + 1 < MAX_RAYS_PER_LANE) {        // the next ray's table entry travels while this one is marched
+                const int s = tid + (k + 1) * kRadonWG;
+                e = sp.slot[s]; nrm = sp.nrm[s]; ray = sp.ray[s];
+            }
+            const int n_steps = (dev_skip & 2) ? 0 : (ce.x & 0xffff);
+            if (cr >= 0) {
+                float a = 0.0f, b = 0.0f;
+                if (n_steps > 0) {
+                    const unsigned tile = tile0 + 2u * (unsigned)ce.y;
+                    const float q = __int_as_float(ce.z), vm = __int_as_float(ce.w);
+                    if (ce.x >> 16) march2<true, STRIDE>(tile, q, vm, n_steps, p.stride, a, b);
+                    else march2<false, STRIDE>(tile, q, vm, n_steps, p.stride, a, b);
+                    a *= cn; b *= cn;
+                }
+                dA[cr] = a;
+                if (two) dB[cr] = b;
+                if (rA) {
+                    rA[cr] = a;
+                    if (two) rA[rays + cr] = b;
+                }
+            }
+        }
+        __syncthreads();   // every ray's raw sum is in place (stores of this workgroup are visible to it after the barrier); the tile is free
+        stamp(2);
+        if (sino_norm) {
+            float va[MAX_RAYS_PER_LANE], vb[MAX_RAYS_PER_LANE];
+#pragma unroll
+            for (int k = 0; k < MAX_RAYS_PER_LANE; ++k) {
+                const int r = tid + k * kRadonWG;
+                va[k] = r < rays ? dA[r] : 0.0f;
+                vb[k] = (two && r < rays) ? dB[r] : 0.0f;
+            }
+            normalize_store<MAX_RAYS_PER_LANE>(va, rays, red, dA, degenerate, tid);
+            if (two) normalize_store<MAX_RAYS_PER_LANE>(vb, rays, red, dB, degenerate, tid);
+            __syncthreads();   // red is reused by the next round
+        }
+        if (threadIdx.x == 0) s_next = gridDim.x + atomicAdd(next_pair, 1u);
+        __syncthreads();
+        stamp(3);
+        pair = s_next;
+    }
+}
+
 template <int M, int S>
 void* fused_kernel(int pf)
 {
     // `pf` load triplets in flight per lane = two register stages of pf / 2 quads each
     return pf >= 4 ? reinterpret_cast<void*>(k_bev_radon2<M, S, 2>) : reinterpret_cast<void*>(k_bev_radon2<M, S, 1>);
+}
+
+template <int M, int S>
+void* fused_kernel_slots(int pf)
+{
+    return pf >= 6   ? reinterpret_cast<void*>(k_bev_radon3<M, S, 3>)
+           : pf >= 4 ? reinterpret_cast<void*>(k_bev_radon3<M, S, 2>)
+                     : reinterpret_cast<void*>(k_bev_radon3<M, S, 1>);
 }
 
 }  // namespace
@@ -225,12 +366,17 @@ int mrs_radon_plan_set_option(mrs_radon_plan* plan, int32_t option, int32_t valu
             plan->fused_stagger_us = value;
             return MRS_OK;
         case MRS_RADON_OPT_FUSED_PREFETCH:
-            MRS_REQUIRE(value == 2 || value == 4, "prefetch depth must be 2 or 4");
+            MRS_REQUIRE(value == 2 || value == 4 || value == 6, "prefetch depth must be 2, 4 or 6");
             plan->fused_prefetch = value;
             return MRS_OK;
         case MRS_RADON_OPT_FUSED_GRID:
             MRS_REQUIRE(value >= 0 && value <= 65535, "workgroup count must be within [0, 65535]");
             plan->fused_grid = value;
+            return MRS_OK;
+        case MRS_RADON_OPT_FUSED_VARIANT:
+            MRS_REQUIRE(value == 0 || value == 1, "variant must be 0 (ray-order table, unrolled) or 1 (slot tables)");
+            MRS_REQUIRE(value == 0 || plan->d_slot, "this plan has no slot tables");
+            plan->fused_variant = value;
             return MRS_OK;
         default:
             mrs::set_error("unknown plan option %d", (int)option);
@@ -270,14 +416,47 @@ int mrs_ring_descriptors_batch(mrs_radon_plan* plan, const float* d_xyz, const i
     if ((st = ctr.alloc(256, s)) != MRS_OK) return st;
     MRS_HIP_TRY(hipMemsetAsync(ctr.p, 0, sizeof(unsigned), s));
     const int pf = plan->fused_prefetch;
-    void* kern = per_lane <= 15 ? (p.stride == 125 ? fused_kernel<15, 125>(pf) : fused_kernel<15, 0>(pf)) : fused_kernel<16, 0>(pf);
-    if (lds > 48 * 1024) MRS_HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int pairs = (batch + 1) / 2;
     const int grid = std::min(pairs, plan->fused_grid > 0 ? plan->fused_grid : std::max(plan->ctx->num_cu, 1));
     unsigned stagger_ticks = (unsigned)plan->fused_stagger_us * 100u;   // wall_clock64 ticks at 100 MHz
     if (pairs <= grid) stagger_ticks = 0;   // a single round: nothing to phase-shift, the delay would only add latency
     unsigned* d_ctr = ctr.as<unsigned>();
     int* d_deg = plan->d_degenerate;
+    if (plan->fused_variant == 1 && plan->d_slot && plan->slot_per_lane == per_lane) {
+        void* kern = per_lane <= 15 ? (p.stride == 125 ? fused_kernel_slots<15, 125>(pf) : fused_kernel_slots<15, 0>(pf)) : fused_kernel_slots<16, 0>(pf);
+        if (lds > 48 * 1024) MRS_HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SlotP sp;
+        sp.slot = plan->d_slot; sp.nrm = plan->d_slot_nrm; sp.ray = plan->d_slot_ray;
+        mrs::Scratch parkbuf;          // only a BEV-only call has no output to park the raw sums in (they are then never read)
+        float* d_park = nullptr;
+        if (!d_sino && !d_sino_norm) {
+            if ((st = parkbuf.alloc((size_t)grid * 2 * rays * sizeof(float), s)) != MRS_OK) return st;
+            d_park = parkbuf.as<float>();
+        }
+        static const bool want_prof = getenv("MRS_FUSED_PROF") != nullptr;     // development aid: phase times on stderr (synchronises)
+        static const int dev_skip_env = getenv("MRS_FUSED_SKIP") ? atoi(getenv("MRS_FUSED_SKIP")) : 0;
+        int dev_skip = dev_skip_env;
+        unsigned long long* d_prof = nullptr;
+        if (want_prof) {
+            MRS_HIP_TRY(hipMalloc(&d_prof, 4 * sizeof(unsigned long long)));
+            MRS_HIP_TRY(hipMemsetAsync(d_prof, 0, 4 * sizeof(unsigned long long), s));
+        }
+        void* args[] = {(void*)&d_xyz, (void*)&d_offsets, (void*)&cp, (void*)&p, (void*)&sp, (void*)&batch, (void*)&d_bev, (void*)&d_sino,
+                        (void*)&d_sino_norm, (void*)&d_park, (void*)&d_deg, (void*)&d_ctr, (void*)&stagger_ticks, (void*)&d_prof, (void*)&dev_skip};
+        MRS_HIP_TRY(hipLaunchKernel(kern, dim3(grid), dim3(kRadonWG), args, lds, s));
+        if (want_prof) {
+            unsigned long long h[4];
+            MRS_HIP_TRY(hipStreamSynchronize(s));
+            MRS_HIP_TRY(hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost));
+            (void)hipFree(d_prof);
+            const double per = 0.01 / (double)pairs;     // 100 MHz ticks -> microseconds per pair of scans
+            fprintf(stderr, "[fused prof] %d scans, grid %d, pf %d: clear %.1f us, rasterise %.1f us, march %.1f us, normalise + next %.1f us per pair\n", batch,
+                    grid, pf, h[0] * per, h[1] * per, h[2] * per, h[3] * per);
+        }
+        return MRS_OK;
+    }
+    void* kern = per_lane <= 15 ? (p.stride == 125 ? fused_kernel<15, 125>(pf) : fused_kernel<15, 0>(pf)) : fused_kernel<16, 0>(pf);
+    if (lds > 48 * 1024) MRS_HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     void* args[] = {(void*)&d_xyz, (void*)&d_offsets, (void*)&cp, (void*)&p, (void*)&batch, (void*)&d_bev, (void*)&d_sino,
                     (void*)&d_sino_norm, (void*)&d_deg, (void*)&d_ctr, (void*)&stagger_ticks};
     MRS_HIP_TRY(hipLaunchKernel(kern, dim3(grid), dim3(kRadonWG), args, lds, s));

@@ -34,6 +34,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cfloat>
+#include <cstdlib>
 #include <cmath>
 
 #include "common.hpp"
@@ -545,6 +546,142 @@ __device__ __forceinline__ int knn_seed_home(const float4* __restrict__ pts, int
     return home;
 }
 
+// ---- exact k nearest neighbours in two passes ----------------------------------------------------------------------------------
+// A sorted insertion that carries the index costs ~20 VALU cycles per slot (compares + selects) and, in SIMT, every lane of a wave pays
+// for every lane's insertions: with 16 (32) slots the insertions were most of k_knn_cov (k_knn_features).  Here the scan keeps only the
+// KMAX smallest DISTANCES, sorted, by a chain of v_med3_f32 (dk[s] = med3(dk[s-1], d, dk[s]): one 4-cycle instruction per slot, no
+// predicate: a distance beyond the list leaves it unchanged).  That yields the exact k-th distance tau; a second scan with the fixed
+// bound tau (it revisits only the few sub-tiles within tau) appends the index of every candidate with d <= tau to a per-lane list in
+// the LDS, and the <= KMAX + 8 collected candidates are then put in (distance, index) order by the old insertion -- a couple of dozen
+// insertions per query instead of one per candidate that beat any lane's bound.  Exactly equal distances resolve to the smaller
+// (Morton-space) index.  The whole workgroup must call it together.
+constexpr int kKnnSpare = 8;      // list slots beyond KMAX: room for candidates tied with the k-th distance
+// development counters (MRS_KNN_DBG=1 prints them): per wave and round -- tiles staged / candidate groups of 8 visited in pass 1 and 2, groups
+// where some lane's list changed, selection steps, query waves
+__device__ unsigned long long g_knn_dbg[8];
+
+template <int KMAX>
+__device__ __forceinline__ void dist_insert(float (&dk)[KMAX], float d)
+{
+#pragma unroll
+    for (int s = KMAX - 1; s > 0; --s) dk[s] = __builtin_amdgcn_fmed3f(dk[s - 1], d, dk[s]);
+    dk[0] = fminf(dk[0], d);
+}
+
+// (distance, index) ordered insertion of the final selection
+template <int KMAX>
+__device__ __forceinline__ void knn_insert_tie(float (&dk)[KMAX], int (&ik)[KMAX], float d, int j)
+{
+#pragma unroll
+    for (int s = KMAX - 1; s > 0; --s) {
+        const bool up = dk[s - 1] > d || (dk[s - 1] == d && ik[s - 1] > j);
+        const bool here = !up && (dk[s] > d || (dk[s] == d && ik[s] > j));
+        dk[s] = up ? dk[s - 1] : (here ? d : dk[s]);
+        ik[s] = up ? ik[s - 1] : (here ? j : ik[s]);
+    }
+    if (dk[0] > d || (dk[0] == d && ik[0] > j)) { dk[0] = d; ik[0] = j; }
+}
+
+// visits every candidate group of 8 whose boxes lie within `bound` (re-read through the callable: it may shrink during the scan) of the
+// lane's query, in the workgroup's tile order (sh.order, set by order_tiles), and hands the 8 distances to `visit(t0 + 8 g, dd)`
+template <class Bound, class Visit>
+__device__ __forceinline__ void knn_visit(ScanShared& sh, const float4* __restrict__ pts, int n, const TileBoxes& tb, bool live, const float4& q,
+                                          Bound bound, Visit visit, int& n_tiles, int& n_groups)
+{
+    for (int kk = 0; kk < tb.ntiles; ++kk) {
+        const int t = kk < kMaxOrder ? (int)sh.order[kk] : kk;
+        const bool need = live && box_point_d2(tb.lo[t], tb.hi[t], q.x, q.y, q.z) * 0.9999f <= bound();
+        if (!__syncthreads_or(need)) continue;
+        const int t0 = t * kTile;
+        const int cnt = min(kTile, n - t0);
+        stage_tile(sh, pts, t0, cnt);
+        ++n_tiles;
+        for (int sb = 0; sb < kSubs && sb * kSub < cnt; ++sb) {
+            float4 slo, shi;   // wave-level culling against the sub-tile's box (this wave: 64 consecutive Morton points)
+            sub_box(sh, sb, slo, shi);
+            if (!__any(live && box_point_d2(slo, shi, q.x, q.y, q.z) * 0.9999f <= bound())) continue;
+            const int g_end = min((sb + 1) * (kSub / 8), (cnt + 7) >> 3);
+            for (int g = sb * (kSub / 8); g < g_end; ++g) {
+                if ((g & 1) == 0) {   // third level: the 16 candidates of groups g, g + 1
+                    const int mi = g >> 1;
+                    float4 mlo, mhi;
+                    mlo.x = sh.mini[mi][0]; mlo.y = sh.mini[mi][1]; mlo.z = sh.mini[mi][2];
+                    mhi.x = sh.mini[mi][3]; mhi.y = sh.mini[mi][4]; mhi.z = sh.mini[mi][5];
+                    if (!__any(live && box_point_d2(mlo, mhi, q.x, q.y, q.z) * 0.9999f <= bound())) { ++g; continue; }
+                }
+                float dd[8];   // padding candidates sit at +inf
+#pragma unroll
+                for (int u = 0; u < 8; ++u) dd[u] = dist2(q.x, q.y, q.z, sh.tile[8 * g + u]);
+                ++n_groups;
+                visit(t0 + 8 * g, dd);
+            }
+        }
+    }
+}
+
+// dk / ik: the k nearest of point i (itself included), ascending in (distance, index); slots >= the number found hold +inf / -1.
+// list: kNNThreads x (KMAX + kKnnSpare) ints of LDS, slot-major.
+template <int KMAX>
+__device__ __forceinline__ void knn_two_pass(ScanShared& sh, int* __restrict__ list, const float4* __restrict__ pts, int n, const TileBoxes& tb,
+                                             int i, bool live, const float4& q, int k, float (&dk)[KMAX], int (&ik)[KMAX])
+{
+    constexpr int CAP = KMAX + kKnnSpare;
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) dk[s] = INFINITY;
+    // pass 1: the KMAX smallest distances.  Seed: the 64 neighbours along the Morton curve (the bound is close to final before the
+    // first tile is staged); the tile scan skips exactly that index range.
+    const int home = max(0, min(i - kHome / 2, n - kHome));
+    for (int u = 0; u < kHome; ++u) {
+        const int j = home + u;
+        if (j >= n) break;             // n < kHome: wave-uniform
+        const float d = dist2(q.x, q.y, q.z, pts[live ? j : 0]);
+        dist_insert<KMAX>(dk, (live && d == d) ? d : INFINITY);
+    }
+    float lo[3] = {live ? q.x : INFINITY, live ? q.y : INFINITY, live ? q.z : INFINITY};
+    float hi[3] = {live ? q.x : -INFINITY, live ? q.y : -INFINITY, live ? q.z : -INFINITY};
+    __syncthreads();  // previous round done with sh
+    order_tiles(sh, tb, INFINITY, lo, hi);
+    int c_t1 = 0, c_g1 = 0, c_ins = 0, c_t2 = 0, c_g2 = 0;
+    knn_visit(sh, pts, n, tb, live, q, [&]() { return dk[KMAX - 1]; }, [&](int j0, const float (&dd)[8]) {
+        const float mn = fminf(fminf(fminf(dd[0], dd[1]), fminf(dd[2], dd[3])), fminf(fminf(dd[4], dd[5]), fminf(dd[6], dd[7])));
+        if (!__any(live && mn < dk[KMAX - 1])) return;
+        ++c_ins;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool use = live && (unsigned)(j0 + u - home) >= (unsigned)kHome && dd[u] == dd[u];
+            dist_insert<KMAX>(dk, use ? dd[u] : INFINITY);
+        }
+    }, c_t1, c_g1);
+    // pass 2: every candidate within the k-th distance, home range included
+    const float tau = live ? dk[(k < KMAX ? k : KMAX) - 1] : -1.0f;
+    int cnt = 0;
+    knn_visit(sh, pts, n, tb, live, q, [&]() { return tau; }, [&](int j0, const float (&dd)[8]) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (dd[u] <= tau && cnt < CAP) {
+                list[cnt * kNNThreads + (int)threadIdx.x] = j0 + u;
+                ++cnt;
+            }
+    }, c_t2, c_g2);
+    // selection: (distance, index) order
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) { dk[s] = INFINITY; ik[s] = -1; }
+    int most = cnt;
+    for (int o = 32; o > 0; o >>= 1) most = max(most, __shfl_xor(most, o, 64));
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&g_knn_dbg[0], (unsigned long long)c_t1); atomicAdd(&g_knn_dbg[1], (unsigned long long)c_g1);
+        atomicAdd(&g_knn_dbg[2], (unsigned long long)c_ins); atomicAdd(&g_knn_dbg[3], (unsigned long long)c_t2);
+        atomicAdd(&g_knn_dbg[4], (unsigned long long)c_g2); atomicAdd(&g_knn_dbg[5], (unsigned long long)most);
+        atomicAdd(&g_knn_dbg[6], 1ull);
+    }
+    for (int c = 0; c < most; ++c) {
+        const bool have = c < cnt;
+        const int j = have ? list[c * kNNThreads + (int)threadIdx.x] : 0;
+        const float d = dist2(q.x, q.y, q.z, pts[j]);
+        if (have) knn_insert_tie<KMAX>(dk, ik, d, j);
+    }
+}
+
 // G2: exact kNN (KMAX slots, the first k are used) + covariance + PLANE regularisation, on the
 // Morton-ordered cloud with tile culling (bound = the lane's current KMAX-th distance).
 // grid = (blocks, clouds); cloud c spans pts[offs[c] .. offs[c+1]).
@@ -557,6 +694,7 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_cov(const float4* __restrict
                                                         int k, double* __restrict__ cov_all, int* __restrict__ knn_out)
 {
     __shared__ ScanShared sh;
+    __shared__ int knn_list[(KMAX + kKnnSpare) * kNNThreads];
     const int c = blockIdx.y;
     const int64_t o = offs[c];
     const int n = (int)(offs[c + 1] - o);
@@ -571,48 +709,7 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_cov(const float4* __restrict
         const float4 q = pts[live ? i : 0];
         float dk[KMAX];
         int ik[KMAX];
-#pragma unroll
-        for (int s = 0; s < KMAX; ++s) { dk[s] = INFINITY; ik[s] = -1; }
-        const int home = knn_seed_home<KMAX>(pts, n, i, live, q, dk, ik);
-        float lo[3] = {live ? q.x : INFINITY, live ? q.y : INFINITY, live ? q.z : INFINITY};
-        float hi[3] = {live ? q.x : -INFINITY, live ? q.y : -INFINITY, live ? q.z : -INFINITY};
-        __syncthreads();  // previous round done with sh
-        order_tiles(sh, tb, INFINITY, lo, hi);
-        for (int kk = 0; kk < tb.ntiles; ++kk) {
-            const int t = kk < kMaxOrder ? (int)sh.order[kk] : kk;
-            const bool need = live && box_point_d2(tb.lo[t], tb.hi[t], q.x, q.y, q.z) * 0.9999f <= dk[KMAX - 1];
-            if (!__syncthreads_or(need)) continue;
-            const int t0 = t * kTile;
-            const int cnt = min(kTile, n - t0);
-            stage_tile(sh, pts, t0, cnt);
-            for (int sb = 0; sb < kSubs && sb * kSub < cnt; ++sb) {
-              float4 slo, shi;   // wave-level culling against the sub-tile's box (this wave: 64 consecutive Morton points)
-              sub_box(sh, sb, slo, shi);
-              if (!__any(live && box_point_d2(slo, shi, q.x, q.y, q.z) * 0.9999f <= dk[KMAX - 1])) continue;
-              // 8 candidates at a time (padding candidates sit at +inf): one test per group once the list has warmed up
-              const int g_end = min((sb + 1) * (kSub / 8), (cnt + 7) >> 3);
-              for (int g = sb * (kSub / 8); g < g_end; ++g) {
-                if ((g & 1) == 0) {   // third level: the 16 candidates of groups g, g + 1
-                    const int mi = g >> 1;
-                    float4 mlo, mhi;
-                    mlo.x = sh.mini[mi][0]; mlo.y = sh.mini[mi][1]; mlo.z = sh.mini[mi][2];
-                    mhi.x = sh.mini[mi][3]; mhi.y = sh.mini[mi][4]; mhi.z = sh.mini[mi][5];
-                    if (!__any(live && box_point_d2(mlo, mhi, q.x, q.y, q.z) * 0.9999f <= dk[KMAX - 1])) { ++g; continue; }
-                }
-                float dd[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) dd[u] = dist2(q.x, q.y, q.z, sh.tile[8 * g + u]);
-                const float mn = fminf(fminf(fminf(dd[0], dd[1]), fminf(dd[2], dd[3])), fminf(fminf(dd[4], dd[5]), fminf(dd[6], dd[7])));
-                if (!(mn < dk[KMAX - 1])) continue;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                  const float d = dd[u];
-                  const int j = t0 + 8 * g + u;
-                  if (d < dk[KMAX - 1] && (unsigned)(j - home) >= (unsigned)kHome) knn_insert<KMAX>(dk, ik, d, j);
-                }
-              }
-            }
-        }
+        knn_two_pass<KMAX>(sh, knn_list, pts, n, tb, i, live, q, k, dk, ik);
         if (!live) continue;
         double mean[3] = {0, 0, 0};
         int cnt = 0;
@@ -755,6 +852,7 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_features(const float4* __res
                                                              float* __restrict__ feat_out, float* __restrict__ feat_planes)
 {
     __shared__ ScanShared sh;
+    __shared__ int knn_list[(KMAX + kKnnSpare) * kNNThreads];
     const int c = blockIdx.y;
     const int64_t o = offs[c];
     const int n = (int)(offs[c + 1] - o);
@@ -769,48 +867,7 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_features(const float4* __res
         const float4 q = pts[live ? i : 0];
         float dk[KMAX];
         int ik[KMAX];
-#pragma unroll
-        for (int s = 0; s < KMAX; ++s) { dk[s] = INFINITY; ik[s] = -1; }
-        const int home = knn_seed_home<KMAX>(pts, n, i, live, q, dk, ik);
-        float lo[3] = {live ? q.x : INFINITY, live ? q.y : INFINITY, live ? q.z : INFINITY};
-        float hi[3] = {live ? q.x : -INFINITY, live ? q.y : -INFINITY, live ? q.z : -INFINITY};
-        __syncthreads();
-        order_tiles(sh, tb, INFINITY, lo, hi);
-        for (int kk = 0; kk < tb.ntiles; ++kk) {
-            const int t = kk < kMaxOrder ? (int)sh.order[kk] : kk;
-            const bool need = live && box_point_d2(tb.lo[t], tb.hi[t], q.x, q.y, q.z) * 0.9999f <= dk[KMAX - 1];
-            if (!__syncthreads_or(need)) continue;
-            const int t0 = t * kTile;
-            const int cnt = min(kTile, n - t0);
-            stage_tile(sh, pts, t0, cnt);
-            for (int sb = 0; sb < kSubs && sb * kSub < cnt; ++sb) {
-              float4 slo, shi;   // wave-level culling against the sub-tile's box
-              sub_box(sh, sb, slo, shi);
-              if (!__any(live && box_point_d2(slo, shi, q.x, q.y, q.z) * 0.9999f <= dk[KMAX - 1])) continue;
-              // 8 candidates at a time (padding candidates sit at +inf): one test per group once the list has warmed up
-              const int g_end = min((sb + 1) * (kSub / 8), (cnt + 7) >> 3);
-              for (int g = sb * (kSub / 8); g < g_end; ++g) {
-                if ((g & 1) == 0) {   // third level: the 16 candidates of groups g, g + 1
-                    const int mi = g >> 1;
-                    float4 mlo, mhi;
-                    mlo.x = sh.mini[mi][0]; mlo.y = sh.mini[mi][1]; mlo.z = sh.mini[mi][2];
-                    mhi.x = sh.mini[mi][3]; mhi.y = sh.mini[mi][4]; mhi.z = sh.mini[mi][5];
-                    if (!__any(live && box_point_d2(mlo, mhi, q.x, q.y, q.z) * 0.9999f <= dk[KMAX - 1])) { ++g; continue; }
-                }
-                float dd[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) dd[u] = dist2(q.x, q.y, q.z, sh.tile[8 * g + u]);
-                const float mn = fminf(fminf(fminf(dd[0], dd[1]), fminf(dd[2], dd[3])), fminf(fminf(dd[4], dd[5]), fminf(dd[6], dd[7])));
-                if (!(mn < dk[KMAX - 1])) continue;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                  const float d = dd[u];
-                  const int j = t0 + 8 * g + u;
-                  if (d < dk[KMAX - 1] && (unsigned)(j - home) >= (unsigned)kHome) knn_insert<KMAX>(dk, ik, d, j);
-                }
-              }
-            }
-        }
+        knn_two_pass<KMAX>(sh, knn_list, pts, n, tb, i, live, q, k, dk, ik);
         if (!live) continue;
         const int oi = __float_as_int(q.w);
         double mean[3] = {0, 0, 0};
@@ -1741,6 +1798,16 @@ int mrs_gicp_batch_compute_covariances(mrs_gicp_batch* h, int32_t which, int32_t
         hipLaunchKernelGGL(k_knn_cov<32>, grid, dim3(kNNThreads), 0, s, h->d_pts[which], h->d_offs[which], h->d_tile_base[which],
                            h->d_tlo[which], h->d_thi[which], k, h->d_cov[which], d_knn_out);
     MRS_HIP_TRY(hipGetLastError());
+    if (getenv("MRS_KNN_DBG")) {
+        unsigned long long c[8];
+        MRS_HIP_TRY(hipStreamSynchronize(s));
+        MRS_HIP_TRY(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_knn_dbg), sizeof(c)));
+        const double w = (double)(c[6] ? c[6] : 1);
+        fprintf(stderr, "[knn dbg] per query wave: pass 1 tiles %.1f groups %.1f (list changed in %.1f), pass 2 tiles %.1f groups %.1f, selection steps %.1f; %llu waves\n",
+                c[0] / w, c[1] / w, c[2] / w, c[3] / w, c[4] / w, c[5] / w, c[6]);
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        MRS_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_knn_dbg), z, sizeof(z)));
+    }
     h->cov_valid[which] = true;
     if (which == 1) h->vox_res_built = 0.0;
     return MRS_OK;

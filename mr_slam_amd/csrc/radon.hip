@@ -416,6 +416,38 @@ int mrs_radon_plan_create(mrs_ctx* ctx, const float* h_angles, int32_t n_angles,
         delete pl;
         return MRS_ERR_HIP;
     }
+    // slot tables (two-image kernels): rays sorted by (orientation, step count, ray id), 64 consecutive slots per wave and round
+    const int per_lane = (int)((rays + kRadonWG - 1) / kRadonWG);
+    if (pl->two_in_lds && per_lane <= 16) {
+        std::vector<int> order(rays);
+        for (size_t i = 0; i < rays; ++i) order[i] = (int)i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+            const int ya = meta[a] >> 16, yb = meta[b] >> 16, na = meta[a] & 0xffff, nb = meta[b] & 0xffff;
+            return ya != yb ? ya > yb : na > nb;
+        });
+        const size_t slots = (size_t)per_lane * kRadonWG;
+        std::vector<int4> h_slot(slots, make_int4(0, 0, 0, 0));
+        std::vector<float> h_nrm(slots, 0.0f);
+        std::vector<int> h_ray(slots, -1);
+        for (size_t i = 0; i < rays; ++i) {
+            const int r = order[i];
+            int qb, vb;
+            memcpy(&qb, &q[r], 4); memcpy(&vb, &vm[r], 4);
+            h_slot[i] = make_int4(meta[r], base[r], qb, vb);
+            h_nrm[i] = nrm[r];
+            h_ray[i] = r;
+        }
+        if (hipMalloc(&pl->d_slot, slots * sizeof(int4)) != hipSuccess || hipMalloc(&pl->d_slot_nrm, slots * sizeof(float)) != hipSuccess ||
+            hipMalloc(&pl->d_slot_ray, slots * sizeof(int)) != hipSuccess ||
+            hipMemcpy(pl->d_slot, h_slot.data(), slots * sizeof(int4), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(pl->d_slot_nrm, h_nrm.data(), slots * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(pl->d_slot_ray, h_ray.data(), slots * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+            mrs::set_error("could not upload the slot tables");
+            mrs_radon_plan_destroy(pl);
+            return MRS_ERR_HIP;
+        }
+        pl->slot_per_lane = per_lane;
+    }
     *out_plan = pl;
     return MRS_OK;
 }
@@ -424,6 +456,9 @@ int mrs_radon_plan_destroy(mrs_radon_plan* plan)
 {
     if (!plan) return MRS_OK;
     (void)hipSetDevice(plan->ctx->device);
+    if (plan->d_slot) (void)hipFree(plan->d_slot);
+    if (plan->d_slot_nrm) (void)hipFree(plan->d_slot_nrm);
+    if (plan->d_slot_ray) (void)hipFree(plan->d_slot_ray);
     if (plan->d_meta) (void)hipFree(plan->d_meta);
     if (plan->d_degenerate) (void)hipFree(plan->d_degenerate);
     delete plan;

@@ -15,6 +15,14 @@ struct mrs_radon_plan {
     int fused_stagger_us = 70;  // odd workgroups start this many microseconds late (phase-shifts the HBM-bound and the VALU-bound halves)
     int fused_prefetch = 2;     // 16-byte load triplets in flight per lane while rasterising (2 or 4)
     int fused_grid = 0;         // persistent workgroups (0 = one per compute unit)
+    int fused_variant = 1;      // 1: slot tables (rays sorted by orientation and length) + rolled ray loop; 0: the table in ray order, 15 rays unrolled
+    // slot tables of the two-image kernels: lane slot s = k * 1024 + lane carries ray slot_ray[s] (-1: idle).  Rays are sorted by
+    // (orientation, step count), so that the 64 lanes of a wave march rays of (almost) the same length: a wave executes the longest
+    // of its rays, and in (angle, detector) order 16 % of the lane-steps were idle
+    int4* d_slot = nullptr;     // {n_steps | ydom << 16, LDS byte offset of the first texel line (single-image units), q bits, vm bits}
+    float* d_slot_nrm = nullptr;
+    int* d_slot_ray = nullptr;
+    int slot_per_lane = 0;
 };
 
 namespace {
@@ -120,13 +128,15 @@ __device__ __forceinline__ double wave_sum(double v)
 // output is written as zeros and *degenerate is counted up so that the host mirror can raise the same error.
 template <int N>
 __device__ __forceinline__ void normalize_store(const float (&val)[N], int rays, double (&red)[2][16], float* __restrict__ dst,
-                                                int* __restrict__ degenerate)
+                                                int* __restrict__ degenerate, int tid = -1)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // tid: the caller's (possibly opaque) copy of threadIdx.x, so that a persistent kernel's per-round addresses are not hoisted out of its loop
+    if (tid < 0) tid = (int)threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
     double s1 = 0.0;
 #pragma unroll
     for (int k = 0; k < N; ++k)
-        if (threadIdx.x + k * kRadonWG < rays) s1 += (double)val[k];
+        if (tid + k * kRadonWG < rays) s1 += (double)val[k];
     s1 = wave_sum(s1);
     __syncthreads();
     if (lane == 0) red[0][wave] = s1;
@@ -138,7 +148,7 @@ __device__ __forceinline__ void normalize_store(const float (&val)[N], int rays,
     double s2 = 0.0;
 #pragma unroll
     for (int k = 0; k < N; ++k)
-        if (threadIdx.x + k * kRadonWG < rays) {
+        if (tid + k * kRadonWG < rays) {
             const double dlt = (double)val[k] - mean_d;
             s2 += dlt * dlt;
         }
@@ -149,10 +159,10 @@ __device__ __forceinline__ void normalize_store(const float (&val)[N], int rays,
     for (int w = 0; w < kRadonWG / 64; ++w) tot2 += red[1][w];
     const float sd = (float)sqrt(tot2 / (double)(rays - 1));
     const bool ok = sd > 0.0f && sd < INFINITY;
-    if (!ok && threadIdx.x == 0 && degenerate) atomicAdd(degenerate, 1);
+    if (!ok && tid == 0 && degenerate) atomicAdd(degenerate, 1);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        const int ray = threadIdx.x + k * kRadonWG;
+        const int ray = tid + k * kRadonWG;
         if (ray < rays) dst[ray] = ok ? (val[k] - mean) / sd : 0.0f;
     }
 }

@@ -49,7 +49,7 @@ class RadonPlan:
         _lib.check(_lib.load().mrs_radon_plan_degenerate_count(self._h, int(bool(reset)), C.byref(n)))
         return n.value
 
-    OPT_FUSED_STAGGER_US, OPT_FUSED_PREFETCH, OPT_FUSED_GRID = 1, 2, 3
+    OPT_FUSED_STAGGER_US, OPT_FUSED_PREFETCH, OPT_FUSED_GRID, OPT_FUSED_VARIANT = 1, 2, 3, 4
 
     def set_option(self, option, value):
         """Tuning knobs of the fused descriptor kernel (mrs_radon_plan_set_option); results do not depend on them."""

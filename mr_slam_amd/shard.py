@@ -72,17 +72,23 @@ def _rank(group=None):
     return dist.get_rank(group) if (dist.is_available() and dist.is_initialized()) else 0
 
 
-def sharded_topk_sweep(queries, local_db, sweep_fn, k, group=None):
+def sharded_topk_sweep(queries, local_db, sweep_fn, k, group=None, shard_rows=None, packed=False):
     """The low-traffic alternative to replicating the database: the database stays sharded, the
     queries are the same on every rank (all-gather them first if they are not), every rank scores them against ITS rows
     and only the k best (dist, angle, global row) per query travel.  Rows are numbered in rank order (rank r owns
     [sum of the earlier shards, ...)).  Returns (dist [Q,k], angle [Q,k], row [Q,k]) sorted by ascending dist, identical
-    on every rank; ties resolve to the smaller global row, like a single-rank sweep followed by a stable sort."""
+    on every rank; ties resolve to the smaller global row, like a single-rank sweep followed by a stable sort.
+    shard_rows (rows per rank, the same list on every rank) skips the exchange of the shard sizes and its host
+    synchronisation: every shape is then static and the call only enqueues work (timed loops).  packed=True sends the three
+    result arrays as ONE collective (an int64 view of (dist bits, angle) + the row)."""
     world, rank = _world(group), _rank(group)
     Q = queries.shape[0]
     dev = queries.device
     n_local = torch.tensor([local_db.shape[0]], dtype=torch.int64, device=dev)
-    if world > 1:
+    if shard_rows is not None:
+        counts = [int(c) for c in shard_rows]
+        assert len(counts) == world and counts[rank] == local_db.shape[0]
+    elif world > 1:
         counts = [torch.zeros_like(n_local) for _ in range(world)]
         dist.all_gather(counts, n_local, group=group)
         counts = [int(c.item()) for c in counts]
@@ -102,7 +108,20 @@ def sharded_topk_sweep(queries, local_db, sweep_fn, k, group=None):
     pd = torch.full((Q, k), float("inf"), dtype=torch.float32, device=dev); pd[:, :kk] = d[:, :kk]
     pa = torch.zeros((Q, k), dtype=torch.int32, device=dev); pa[:, :kk] = a[:, :kk]
     pr = torch.full((Q, k), -1, dtype=torch.int64, device=dev); pr[:, :kk] = row[:, :kk]
-    if world > 1:
+    if world > 1 and packed:
+        buf = torch.empty((Q, k, 2), dtype=torch.int64, device=dev)          # per slot: int32 angle | float32 dist | int64 row
+        b32 = buf.view(torch.int32)                                          # [Q, k, 4]
+        b32[..., 0] = pa
+        b32[..., 1] = pd.contiguous().view(torch.int32)
+        buf[..., 1] = pr
+        gb = torch.empty((world * Q, k, 2), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(gb, buf, group=group)
+        gb = gb.view(world, Q, k, 2).permute(1, 0, 2, 3).reshape(Q, world * k, 2).contiguous()
+        g32 = gb.view(torch.int32)                                           # [Q, world * k, 4]
+        pa = g32[..., 0].contiguous()
+        pd = g32[..., 1].contiguous().view(torch.float32)
+        pr = gb[..., 1].contiguous()
+    elif world > 1:
         gd = torch.empty((world * Q, k), dtype=torch.float32, device=dev)    # concatenation along dim 0 (gloo and RCCL alike)
         ga = torch.empty((world * Q, k), dtype=torch.int32, device=dev)
         gr = torch.empty((world * Q, k), dtype=torch.int64, device=dev)
@@ -150,6 +169,68 @@ def fetch_rows(local_db, global_rows, shard_rows, group=None):
     out = torch.empty_like(got)
     out[order] = got                                                            # back to request order
     return out
+
+
+class RowFetchPlan:
+    """fetch_rows with the request phase done ahead of time.  Candidate rows are usually known long before the entries are needed
+    (they come out of a coarse search), so the two request collectives (counts, row indices) and their host synchronisation run
+    once, here; fetch() is then ONE all-to-all of exactly the requested rows with static split sizes and no host synchronisation,
+    which can be issued launches ahead (async_op=True) and waited for on the consuming stream.
+    rank r owns global rows [sum(shard_rows[:r]), sum(shard_rows[:r + 1]))."""
+
+    def __init__(self, global_rows, shard_rows, group=None):
+        self.group = group
+        world, rank = _world(group), _rank(group)
+        dev = global_rows.device
+        rows = global_rows.to(torch.int64).reshape(-1)
+        bounds = torch.tensor([0] + list(shard_rows), dtype=torch.int64, device=dev).cumsum(0)
+        assert len(shard_rows) == world and int(bounds[-1]) > 0
+        if rows.numel():
+            assert int(rows.min()) >= 0 and int(rows.max()) < int(bounds[-1]), "row outside the database"
+        self.n = int(rows.numel())
+        self.base = int(bounds[rank])
+        self.local_rows = int(shard_rows[rank])
+        if world == 1:
+            self.want, self.order, self.sc, self.rc = rows, None, [self.n], [self.n]
+            return
+        owner = torch.bucketize(rows, bounds[1:], right=True)
+        self.order = torch.argsort(owner, stable=True)                    # requests grouped by owner, original order within
+        send_idx = rows[self.order].contiguous()
+        send_counts = torch.bincount(owner, minlength=world).to(torch.int64)
+        recv_counts = torch.empty_like(send_counts)
+        dist.all_to_all_single(recv_counts, send_counts, group=group)
+        self.sc, self.rc = send_counts.tolist(), recv_counts.tolist()
+        want = torch.empty(int(sum(self.rc)), dtype=torch.int64, device=dev)
+        dist.all_to_all_single(want, send_idx, output_split_sizes=self.rc, input_split_sizes=self.sc, group=group)
+        self.want = want - self.base                                       # local indices of the rows my peers asked for, in their order
+        self.inv = torch.empty_like(self.order)
+        self.inv[self.order] = torch.arange(self.n, device=dev)            # request i sits at position inv[i] of the received block
+
+    def bytes_in(self, row_bytes, rank_local_too=False):
+        """payload bytes this rank receives per fetch (rows it owns itself do not cross a link)"""
+        rank = _rank(self.group)
+        return row_bytes * (self.n if rank_local_too else self.n - int(self.sc[rank] if len(self.sc) > 1 else self.n))
+
+    def fetch(self, local_db, async_op=False):
+        """-> (rows in request order) or, with async_op, (work, finish) where finish() returns them once work.wait() was called."""
+        assert local_db.shape[0] == self.local_rows
+        if self.order is None:                                             # single rank: a local gather
+            out = local_db[self.want]
+            return (None, lambda: out) if async_op else out
+        payload = local_db[self.want].contiguous()
+        cplx = payload.is_complex()
+        real = torch.view_as_real(payload) if cplx else payload
+        got = torch.empty((self.n,) + tuple(real.shape[1:]), dtype=real.dtype, device=real.device)
+        work = dist.all_to_all_single(got, real.contiguous(), output_split_sizes=self.sc, input_split_sizes=self.rc, group=self.group,
+                                      async_op=async_op)
+
+        def finish():
+            g = torch.view_as_complex(got) if cplx else got
+            return g[self.inv]
+        if async_op:
+            self._keep = (payload, real)                                   # alive until the collective has run
+            return work, finish
+        return finish()
 
 
 class OwnerRescorer:

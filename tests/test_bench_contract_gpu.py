@@ -59,33 +59,52 @@ def test_bench_line_two_kernel_step():
 
 
 def test_bench_collective_path_on_one_gpu():
-    """MRS_BENCH_FORCE_DIST=1: the N > 1 code path (process group, fp16 replicas, asynchronous RCCL all-gather, max over
-    ranks) with world size 1."""
+    """MRS_BENCH_FORCE_DIST=1: the N > 1 code paths (process group, asynchronous RCCL collectives, max over ranks) with world size 1, both
+    exchange designs: the default (database kept sharded, pre-planned all-to-all of the candidate rows, sharded top-1 sweep on a side stream)
+    and --exchange allgather (fp16 replicas to every rank + owner re-scoring)."""
     d = _run({"MRS_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"})
-    assert d["n_gpus"] == 1 and d["value"] > 0 and "all-gather" in d["config"]["parallelism"]
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["exchange"] == "fetch" and "all-to-all" in d["config"]["parallelism"]
+    assert d["config"]["fused_grid"] == "per_pair" and set(d["roofline"]["fused_grid_ms_per_launch"]) == {"per_pair", "persistent"}
     x = d["exchange"]
-    assert x["allgather_bytes_in_per_rank_per_launch"] == 0 and x["compute_stream_wait_ms_per_launch"] >= 0      # world size 1: nothing inbound
+    assert x["design"] == "fetch" and x["fetch"]["rows_bytes_in_per_rank_per_launch"] == 0 and x["compute_stream_wait_ms_per_launch"] >= 0
+    assert x["rescore"] is None and x["designs"]["sharded_topk_ms"] > 0 and x["fetch"]["launches_ahead"] >= 1
+    d = _run({"MRS_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29534"}, ("--exchange", "allgather", "--no-extra-legs"))
+    assert d["config"]["exchange"] == "allgather" and "all-gather" in d["config"]["parallelism"]
+    x = d["exchange"]
+    assert x["allgather"]["bytes_in_per_rank_per_launch"] == 0 and x["compute_stream_wait_ms_per_launch"] >= 0      # world size 1: nothing inbound
     assert x["rescore"]["calls"] == 4 and x["rescore"]["rounds"] >= 4 and x["designs"]["sharded_topk_ms"] > 0
 
 
-def test_bench_two_ranks_share_one_gpu_over_gloo():
-    """The N = 2 control flow on real kernels: two ranks on ONE GPU (RCCL refuses that, so the collectives run over gloo,
-    staged through the host): replicated database, candidates by index out of the other rank's rows, owner re-scoring,
-    the top-k design, max-over-ranks timing, one JSON line from rank 0.  Correctness of the exchange is checked inside:
-    with --verify-exchange every rank recomputes a sample of its replica scores against the exact remote entries."""
+def _two_ranks(port, extra):
     env = dict(os.environ)
     env.update({"MRS_BENCH_BACKEND": "gloo", "MRS_BENCH_SHARE_GPU": "1"})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "32",
-           "--chunks", "3", "--gicp-pairs", "2", "--gicp-iters", "4", "--no-extra-legs", "--verify-exchange"]
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "32",
+           "--chunks", "3", "--gicp-pairs", "2", "--gicp-iters", "4", "--no-extra-legs", "--verify-exchange", *extra]
     p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
-    d = json.loads(lines[-1])
-    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["pairs_per_rank_per_step"] == 96
+    return json.loads(lines[-1])
+
+
+def test_bench_two_ranks_share_one_gpu_over_gloo():
+    """The N = 2 control flow on real kernels: two ranks on ONE GPU (RCCL refuses that, so the collectives run over gloo, staged through the
+    host), max-over-ranks timing, one JSON line from rank 0.  Correctness of each exchange design is checked inside (--verify-exchange):
+      fetch     : the fetched candidate rows are the owners' fp32 entries bit for bit, the scores equal those against the gathered exact
+                  database, the sharded top-1 sweep equals a single-rank sweep over the gathered database (value and row);
+      allgather : replica scores within 2e-3 of the exact ones, owner re-scoring, the top-k design."""
+    d = _two_ranks(29541, ())
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["pairs_per_rank_per_step"] == 96 and d["config"]["exchange"] == "fetch"
     x = d["exchange"]
-    assert x["allgather_bytes_in_per_rank_per_launch"] == 32 * 29280 and x["rescore"]["calls"] == 3
+    assert 0 < x["fetch"]["rows_bytes_in_per_rank_per_launch"] <= 32 * 58560 and x["fetch"]["bytes_in_per_rank_per_launch"] < x["allgather"]["bytes_in_per_rank_per_launch"] * 2
+    v = x["verify"]
+    assert v["checked"] == 32 and v["remote_candidates"] > 0 and v["fetched_rows_bit_identical"] and v["sweep_value_equal"] and v["sweep_row_equal"]
+    assert v["max_abs_dist_error"] < 1e-6 and v["angle_mismatches"] == 0
+    assert d["gicp"]["pairs"] == 4
+    d = _two_ranks(29542, ("--exchange", "allgather"))
+    assert d["n_gpus"] == 2 and d["config"]["exchange"] == "allgather"
+    x = d["exchange"]
+    assert x["allgather"]["bytes_in_per_rank_per_launch"] == 32 * 29280 and x["rescore"]["calls"] == 3
     v = x["verify"]
     assert v["checked"] == 32 and v["remote_candidates"] > 0 and v["max_abs_dist_error"] < 2e-3
     assert v["angle_mismatches"] <= 3          # fp16 replicas may move the peak of a flat correlation (unrelated scans)
-    assert d["gicp"]["pairs"] == 4

@@ -88,9 +88,11 @@ def test_fused_blank_scan_counts_as_degenerate(dev):
     assert torch.isfinite(norm).all()
 
 
-@pytest.mark.parametrize("opts", [dict(), dict(stagger=70), dict(prefetch=4), dict(grid=7), dict(stagger=25, prefetch=4, grid=64)])
+@pytest.mark.parametrize("opts", [dict(), dict(stagger=70), dict(prefetch=4), dict(prefetch=6), dict(grid=7), dict(stagger=25, prefetch=4, grid=64),
+                                  dict(variant=0), dict(variant=0, prefetch=4, grid=7), dict(variant=1, prefetch=6, grid=3)])
 def test_fused_persistent_rounds_and_tuning_knobs(dev, opts):
-    """more pairs than workgroups (rounds handed out by the global counter), with every tuning knob: same bits"""
+    """more pairs than workgroups (rounds handed out by the global counter), with every tuning knob -- incl. the lane <-> ray dealing
+    (variant 1: slot tables, rays sorted by length; variant 0: (angle, detector) order): same bits"""
     import torch
     from mr_slam_amd import bev, ring, synth
     base = [synth.lidar_scan(20 + s, 6000) for s in range(3)]
@@ -110,12 +112,14 @@ def test_fused_persistent_rounds_and_tuning_knobs(dev, opts):
         plan.set_option(plan.OPT_FUSED_STAGGER_US, opts.get("stagger", 0))
         plan.set_option(plan.OPT_FUSED_PREFETCH, opts.get("prefetch", 2))
         plan.set_option(plan.OPT_FUSED_GRID, opts.get("grid", 0))
+        plan.set_option(plan.OPT_FUSED_VARIANT, opts.get("variant", 1))
         a, b = _both(xyz, offs)
         _same(a, b)
         b2 = ring.ring_descriptors(xyz, offs, want_bev=True, fused=True)        # run to run: the same bits (order-free max, fixed sums)
         _same(b, b2)
     finally:
         plan.set_option(plan.OPT_FUSED_STAGGER_US, 70); plan.set_option(plan.OPT_FUSED_PREFETCH, 2); plan.set_option(plan.OPT_FUSED_GRID, 0)
+        plan.set_option(plan.OPT_FUSED_VARIANT, 1)
 
 
 def test_fused_rejects_what_it_cannot_do(dev):

@@ -57,6 +57,10 @@ def _worker(rank, world, port, out_dir):
     order = torch.argsort(d_full, dim=1, stable=True)[:, :3]
     assert torch.equal(dk, torch.gather(d_full, 1, order)) and torch.equal(ak, torch.gather(a_full, 1, order))
     assert torch.equal(rk, order)
+    # static-shape form (no exchange of the shard sizes, one packed collective): the same numbers
+    sizes_now = [int(v) for v in shard.allgather_ragged(torch.tensor([local.shape[0]]))]
+    dkp, akp, rkp = shard.sharded_topk_sweep(torch.from_numpy(q), local, sweep, 3, shard_rows=sizes_now, packed=True)
+    assert torch.equal(dkp, dk) and torch.equal(akp, ak) and torch.equal(rkp, rk)
     dk9, _, rk9 = shard.sharded_topk_sweep(torch.from_numpy(q), local, sweep, 9)     # k larger than the database
     assert torch.isinf(dk9[:, n_db:]).all() and (rk9[:, n_db:] == -1).all() and torch.equal(rk9[:, :n_db], torch.argsort(d_full, dim=1, stable=True))
     # owner re-scoring: replicas are a lossy copy; results within the margin of the threshold are recomputed by the
@@ -115,6 +119,16 @@ def _fetch_worker(rank, world, port, out_dir):
     assert got.shape == (want.numel(), 3, 2) and torch.equal(got, db[want])
     cgot = shard.fetch_rows(clocal, want, sizes)
     assert cgot.dtype == torch.complex64 and torch.equal(torch.view_as_real(cgot), torch.view_as_real(cdb[want]))
+    # the same with the request phase done ahead of time: one all-to-all per fetch, also asynchronously, plan reused
+    plan = shard.RowFetchPlan(want, sizes)
+    assert torch.equal(plan.fetch(local), db[want])
+    work, finish = plan.fetch(clocal, async_op=True)
+    if work is not None:
+        work.wait()
+    assert torch.equal(torch.view_as_real(finish()), torch.view_as_real(cdb[want]))
+    assert torch.equal(plan.fetch(local * 2), db[want] * 2)
+    own = int(((want >= lo) & (want < lo + sizes[rank])).sum())
+    assert plan.bytes_in(24) == 24 * (want.numel() - own)
     # a rank that asks for nothing still takes part in the collectives
     none = shard.fetch_rows(local, torch.zeros(0, dtype=torch.int64) if rank == 0 else want[:2], sizes)
     assert none.shape[0] == (0 if rank == 0 else 2) and (rank == 0 or torch.equal(none, db[want[:2]]))

@@ -54,15 +54,24 @@ print("bit identical:", res["bit_identical"], flush=True)
 ms_sep = bench.ev_ms(lambda: separate(1), reps=5, warm=2)
 res["separate_ms_per_1024"] = ms_sep * 1024 / B
 print(f"separate kernels: {ms_sep:.4f} ms per launch of {B}", flush=True)
-for nch in sorted({1, min(8, CH), CH}):
-    for stagger in (0, 70, 90, 110):
-        for pf in (2, 4):
-            plan.set_option(plan.OPT_FUSED_STAGGER_US, stagger)
-            plan.set_option(plan.OPT_FUSED_PREFETCH, pf)
-            ms = bench.ev_ms(lambda: fused(nch, buf[:nch * B]), reps=4, warm=1)
-            row = {"launch_scans": nch * B, "stagger_us": stagger, "prefetch": pf, "ms_per_1024": ms / nch * 1024 / B}
-            res["rows"].append(row)
-            print(row, flush=True)
+for variant in (0, 1):
+    plan.set_option(plan.OPT_FUSED_VARIANT, variant)
+    plan.set_option(plan.OPT_FUSED_STAGGER_US, 70); plan.set_option(plan.OPT_FUSED_PREFETCH, 2)
+    got = fused(CH, buf)
+    torch.cuda.synchronize()
+    same = bool(torch.equal(ref.view(torch.int32), got.view(torch.int32)))
+    res[f"bit_identical_variant{variant}"] = same
+    print(f"variant {variant} bit identical: {same}", flush=True)
+    for nch in sorted({1, min(16, CH), CH}):
+        for stagger in (0, 70) if nch > 1 else (0,):
+            for pf in (2, 4, 6) if variant == 1 else (2, 4):
+                plan.set_option(plan.OPT_FUSED_STAGGER_US, stagger)
+                plan.set_option(plan.OPT_FUSED_PREFETCH, pf)
+                ms = bench.ev_ms(lambda: fused(nch, buf[:nch * B]), reps=4, warm=1)
+                row = {"variant": variant, "launch_scans": nch * B, "stagger_us": stagger, "prefetch": pf, "ms_per_1024": ms / nch * 1024 / B}
+                res["rows"].append(row)
+                print(row, flush=True)
+plan.set_option(plan.OPT_FUSED_VARIANT, 1)
 for grid in (240, 512):     # fewer / more persistent workgroups than compute units
     plan.set_option(plan.OPT_FUSED_STAGGER_US, 0); plan.set_option(plan.OPT_FUSED_PREFETCH, 2); plan.set_option(plan.OPT_FUSED_GRID, grid)
     ms = bench.ev_ms(lambda: fused(CH, buf), reps=3, warm=1)

@@ -1,8 +1,10 @@
 """Condenses the rocprofv3 --pmc passes over tools/pmc_targets.py (gpurun_out/<tag>/pmc_<group>/...) into
 profiles/<tag>_pmc.json + .md.  HBM bytes: FETCH_SIZE / WRITE_SIZE in KB, FETCH_SIZE doubled on gfx950 (64 B counted per
-128-B request) as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes.  VALU issue fraction = SQ_INSTS_VALU x 4
-cycles / (256 CUs x 4 SIMDs x active cycles per XCD); LDS busy = SQ_LDS_IDX_ACTIVE / (256 CUs x active cycles per XCD);
-active cycles per XCD = GRBM_GUI_ACTIVE / 8."""
+128-B request) as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes.  VALU-pipe busy fraction: no SQ counter measures it on
+gfx950 (profiles/r03_ubench.md), so it is built from the instruction mix: SQ_INSTS_VALU_{ADD,MUL}_F32 x 2 cycles, _FMA_F32 x 4 (the kernels here issue
+their FMAs packed), _CVT x 4, _INT32 x 3, _TRANS_F32 x 8, the unclassified rest (fract / floor / max / compare / select / move / logic) x 3 -- the measured
+cost of each class (tools/ubench/valu.hip) -- divided by (256 CUs x 4 SIMDs x active cycles per XCD); without the class counters the bounds
+SQ_INSTS_VALU x 2 and x 4 are given instead.  LDS busy = SQ_LDS_IDX_ACTIVE / (256 CUs x active cycles per XCD); active cycles per XCD = GRBM_GUI_ACTIVE / 8."""
 import collections
 import csv
 import glob
@@ -21,7 +23,20 @@ def newest(paths):
             by_dir[d] = f
     return sorted(by_dir.values())
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+CLASS_CYCLES = {"SQ_INSTS_VALU_ADD_F32": 2.0, "SQ_INSTS_VALU_MUL_F32": 2.0, "SQ_INSTS_VALU_FMA_F32": 4.0, "SQ_INSTS_VALU_CVT": 4.0,
+                "SQ_INSTS_VALU_INT32": 3.0, "SQ_INSTS_VALU_TRANS_F32": 8.0}
+REST_CYCLES = 3.0
+
+
+def valu_cycles(mean):
+    """VALU-pipe cycles of a launch from its instruction classes (None without the class counters)"""
+    if "SQ_INSTS_VALU" not in mean or not all(k in mean for k in CLASS_CYCLES):
+        return None
+    known = sum(mean[k] for k in CLASS_CYCLES)
+    return sum(mean[k] * c for k, c in CLASS_CYCLES.items()) + max(mean["SQ_INSTS_VALU"] - known, 0.0) * REST_CYCLES
+
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
 KEYS = {"k_cart_lds": "k_cart_lds", "k_polar_lds": "k_polar_lds", "k_radon2": "k_radon2", "k_bev_radon2": "k_bev_radon2", "k_ring_spec_corr_pairs": "k_ring_spec_corr_pairs",
@@ -48,7 +63,10 @@ for k, c in sorted(acc.items()):
         cyc = mean["GRBM_GUI_ACTIVE"] / 8.0
         e["active_cycles_per_xcd"] = cyc
         if "SQ_INSTS_VALU" in mean:
-            e["valu_issue_frac"] = mean["SQ_INSTS_VALU"] * 4.0 / (256 * 4 * cyc)
+            e["valu_busy_frac_bounds"] = [mean["SQ_INSTS_VALU"] * 2.0 / (256 * 4 * cyc), mean["SQ_INSTS_VALU"] * 4.0 / (256 * 4 * cyc)]
+            e["valu_pipe_cycles_est"] = valu_cycles(mean)
+            if e["valu_pipe_cycles_est"]:
+                e["valu_issue_frac"] = e["valu_pipe_cycles_est"] / (256 * 4 * cyc)
         if "SQ_LDS_IDX_ACTIVE" in mean:
             e["lds_busy_frac"] = mean["SQ_LDS_IDX_ACTIVE"] / (256 * cyc)
         if "SQ_LDS_BANK_CONFLICT" in mean and mean.get("SQ_LDS_IDX_ACTIVE"):

@@ -12,6 +12,7 @@
 #include "radon_device.hpp"
 
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 
@@ -215,6 +216,133 @@ __global__ __launch_bounds__(kRadonWG) void k_rolled(const float* __restrict__ i
     if (two) normalize_inplace(dB, rays, per_lane, red, degenerate);
 }
 
+// ---- ablations of the base structure (timing only: results differ on purpose) ------------------------------------------------
+//   ABL 1: both taps read ONE fixed cell (same address in every lane: broadcast, no bank conflicts)   -> what the conflicts cost
+//   ABL 2: no tail loop (n_steps rounded down to whole chunks)                                         -> what the per-step tails cost
+//   ABL 3: no FMAs (loaded cells xor-ed into a dummy)                                                   -> what the packed FMAs cost
+//   ABL 4: no LDS reads at all (cells = the weights)                                                    -> VALU-only time
+//   ABL 5: every lane's ray forced to 120 steps of its own geometry is not possible; instead all lanes march ray 60 of their angle
+template <bool YDOM, int STRIDE, int ABL>
+__device__ __forceinline__ void march2a(unsigned off, float q, float vm, int n_steps, float& outA, float& outB)
+{
+    constexpr int unit = (YDOM ? 1 : STRIDE) * 8;
+    constexpr int lstep = (YDOM ? STRIDE : 1) * 8;
+    constexpr int U = 6;
+    v2f acc0 = {0.0f, 0.0f}, acc1 = {0.0f, 0.0f};
+    const unsigned fixed = off;
+    int j = 0;
+#pragma nounroll
+    for (; j + U <= n_steps; j += U) {
+        v2f t0[U], t1[U];
+        float w0[U], w1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float fr = __builtin_amdgcn_fractf(q);
+            unsigned a = off + (unsigned)(YDOM ? (int)q * 8 : __mul24((int)q, unit));
+            if (ABL == 1) { asm volatile("" : "+v"(a)); a = fixed; }
+            if (ABL == 4) {
+                const v2f c = {fr, __int_as_float(a)};
+                t0[u] = c; t1[u] = c;
+            } else {
+                t0[u] = lds_cell(a + u * lstep);
+                t1[u] = lds_cell(a + u * lstep + unit);
+            }
+            w0[u] = 1.0f - fr;
+            w1[u] = fr;
+            q += vm;
+        }
+        off += U * lstep;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (ABL == 3) {
+                acc0.x = __int_as_float(__float_as_int(acc0.x) ^ __float_as_int(t0[u].x) ^ __float_as_int(t1[u].y) ^ __float_as_int(w0[u]));
+                acc1.y = __int_as_float(__float_as_int(acc1.y) ^ __float_as_int(t0[u].y) ^ __float_as_int(t1[u].x) ^ __float_as_int(w1[u]));
+            } else {
+                const v2f W0 = {w0[u], w0[u]}, W1 = {w1[u], w1[u]};
+                acc0 = __builtin_elementwise_fma(t0[u], W0, acc0);
+                acc1 = __builtin_elementwise_fma(t1[u], W1, acc1);
+            }
+        }
+    }
+    if (ABL != 2)
+        for (; j < n_steps; ++j) {
+            const float fr = __builtin_amdgcn_fractf(q);
+            const unsigned a = off + (unsigned)(YDOM ? (int)q * 8 : __mul24((int)q, unit));
+            const v2f t0 = lds_cell(a), t1 = lds_cell(a + unit);
+            const float w0 = 1.0f - fr;
+            const v2f W0 = {w0, w0}, W1 = {fr, fr};
+            acc0 = __builtin_elementwise_fma(t0, W0, acc0);
+            acc1 = __builtin_elementwise_fma(t1, W1, acc1);
+            q += vm;
+            off += lstep;
+        }
+    outA = acc0.x + acc1.x;
+    outB = acc0.y + acc1.y;
+}
+
+template <int STRIDE, int ABL>
+__global__ __launch_bounds__(kRadonWG) void k_abl(const float* __restrict__ img, RadonP p, int batch, float* __restrict__ sino_norm,
+                                                  int* __restrict__ degenerate)
+{
+    extern __shared__ __attribute__((aligned(16))) v2f cells[];
+    __shared__ double red[2][16];
+    const int b0 = 2 * blockIdx.x, b1 = b0 + 1;
+    const bool two = b1 < batch;
+    stage_pair(cells, img, p, b0, two);
+    const int rays = p.A * p.D;
+    float va[15], vb[15];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) {
+        int ray = threadIdx.x + k * kRadonWG;
+        float a = 0.0f, b = 0.0f;
+        if (ray < rays) {
+            if (ABL == 5) ray = (ray / p.D) * p.D + p.D / 2;      // every lane the central ray of its angle: no divergence in n_steps
+            const int meta = p.meta[ray];
+            const int n_steps = meta & 0xffff;
+            if (n_steps > 0) {
+                const float q = p.q[ray], vm = p.vm[ray], n = p.nrm[ray];
+                const unsigned tile = (unsigned)(uintptr_t)(lds_cptr)reinterpret_cast<const char*>(cells) + 2u * (unsigned)p.base[ray];
+                if (meta >> 16) march2a<true, STRIDE, ABL>(tile, q, vm, n_steps, a, b);
+                else march2a<false, STRIDE, ABL>(tile, q, vm, n_steps, a, b);
+                a *= n; b *= n;
+            }
+        }
+        va[k] = a; vb[k] = b;
+    }
+    normalize_store<15>(va, rays, red, sino_norm + (size_t)b0 * rays, degenerate);
+    if (two) normalize_store<15>(vb, rays, red, sino_norm + (size_t)b1 * rays, degenerate);
+}
+
+// ---- rays re-assigned to lanes: slot s = k * 1024 + wave * 64 + lane carries ray rayid[s] (-1: idle), tables in slot order ----
+template <int STRIDE, int PER_LANE>
+__global__ __launch_bounds__(kRadonWG) void k_slots(const float* __restrict__ img, RadonP p, const int* __restrict__ rayid, int batch,
+                                                    float* __restrict__ sino_norm, int* __restrict__ degenerate)
+{
+    extern __shared__ __attribute__((aligned(16))) v2f cells[];
+    __shared__ double red[2][16];
+    const int b0 = 2 * blockIdx.x, b1 = b0 + 1;
+    const bool two = b1 < batch;
+    stage_pair(cells, img, p, b0, two);
+    const int rays = p.A * p.D;
+    float* dA = sino_norm + (size_t)b0 * rays;
+    float* dB = sino_norm + (size_t)(two ? b1 : b0) * rays;
+#pragma unroll
+    for (int k = 0; k < PER_LANE; ++k) {
+        const int slot = threadIdx.x + k * kRadonWG;
+        const int ray = rayid[slot];
+        if (ray >= 0) {
+            float a, b;
+            trace_ray2<STRIDE>(cells, p, slot, a, b);      // the tables are in slot order
+            dA[ray] = a;
+            if (two) dB[ray] = b;
+        }
+    }
+    __syncthreads();     // raw sums of every ray are in place (same workgroup: visible after the barrier)
+    const int per_lane = (rays + kRadonWG - 1) / kRadonWG;
+    normalize_inplace(dA, rays, per_lane, red, degenerate);
+    if (two) normalize_inplace(dB, rays, per_lane, red, degenerate);
+}
+
 struct Variant {
     const char* name;
     void* fn;
@@ -263,6 +391,12 @@ int main(int argc, char** argv)
         {"rolled pipe U=4", (void*)k_rolled<125, 4, true>},
         {"rolled pipe U=6", (void*)k_rolled<125, 6, true>},
         {"rolled pipe U=8", (void*)k_rolled<125, 8, true>},
+        {"ablation 0 (= base, own copy)", (void*)k_abl<125, 0>},
+        {"ablation 1: all taps one fixed cell (no bank conflicts)", (void*)k_abl<125, 1>},
+        {"ablation 2: no tail loop", (void*)k_abl<125, 2>},
+        {"ablation 3: no FMAs", (void*)k_abl<125, 3>},
+        {"ablation 4: no LDS reads", (void*)k_abl<125, 4>},
+        {"ablation 5: every lane the central ray of its angle (120 steps, no divergence; 1.18x the samples)", (void*)k_abl<125, 5>},
     };
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -293,6 +427,85 @@ int main(int argc, char** argv)
         printf("%s  {\"name\": \"%s\", \"ms_per_1024\": %.4f, \"mismatching_values\": %zu, \"vgprs\": %d, \"scratch_bytes\": %zu}", first ? "" : ",\n", v.name,
                ms / 5 * 1024 / B, bad, fa.numRegs, (size_t)fa.localSizeBytes);
         first = false;
+    }
+    // ---- slot tables: rays sorted by (orientation, n_steps) in chunks of 64, chunks dealt to the 16 waves longest first ----------
+    {
+        std::vector<int> meta(nr), base(nr);
+        std::vector<float> q(nr), vm(nr), nrm(nr);
+        CHECK(hipMemcpy(meta.data(), p.meta, nr * 4, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(base.data(), p.base, nr * 4, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(q.data(), p.q, nr * 4, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(vm.data(), p.vm, nr * 4, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(nrm.data(), p.nrm, nr * 4, hipMemcpyDeviceToHost));
+        for (int mode = 0; mode < 3; ++mode) {
+            constexpr int PL = 15;
+            const int slots = PL * kRadonWG;
+            std::vector<int> order(nr);
+            for (size_t i = 0; i < nr; ++i) order[i] = (int)i;
+            if (mode >= 1)
+                std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+                    const int ya = meta[a] >> 16, yb = meta[b] >> 16, na = meta[a] & 0xffff, nb = meta[b] & 0xffff;
+                    if (ya != yb) return ya > yb;
+                    return na > nb;
+                });
+            const int chunks = (int)((nr + 63) / 64);
+            std::vector<int> chunk_slot(chunks);           // chunk -> (k, wave) position
+            if (mode == 2) {                               // longest chunk first onto the least loaded wave (at most PL chunks per wave)
+                std::vector<long> load(16, 0);
+                std::vector<int> cnt(16, 0);
+                std::vector<int> cost(chunks), idx(chunks);
+                for (int c = 0; c < chunks; ++c) {
+                    int m = 0;
+                    for (int l = 0; l < 64 && (size_t)(c * 64 + l) < nr; ++l) m = std::max(m, meta[order[c * 64 + l]] & 0xffff);
+                    cost[c] = m; idx[c] = c;
+                }
+                std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+                for (int c : idx) {
+                    int w = -1;
+                    for (int i = 0; i < 16; ++i) if (cnt[i] < PL && (w < 0 || load[i] < load[w])) w = i;
+                    chunk_slot[c] = cnt[w] * 16 + w;
+                    cnt[w]++; load[w] += cost[c];
+                }
+            } else {
+                for (int c = 0; c < chunks; ++c) chunk_slot[c] = c;      // k = c / 16, wave = c % 16: the library's dealing
+            }
+            std::vector<int> s_meta(slots, 0), s_base(slots, 0), s_ray(slots, -1);
+            std::vector<float> s_q(slots, 0.0f), s_vm(slots, 0.0f), s_nrm(slots, 0.0f);
+            for (int c = 0; c < chunks; ++c)
+                for (int l = 0; l < 64 && (size_t)(c * 64 + l) < nr; ++l) {
+                    const int r = order[c * 64 + l];
+                    const int k = chunk_slot[c] / 16, w = chunk_slot[c] % 16;
+                    const int sl = k * kRadonWG + w * 64 + l;
+                    s_meta[sl] = meta[r]; s_base[sl] = base[r]; s_q[sl] = q[r]; s_vm[sl] = vm[r]; s_nrm[sl] = nrm[r]; s_ray[sl] = r;
+                }
+            int* d_tab; int* d_ray;
+            CHECK(hipMalloc(&d_tab, (size_t)slots * 5 * 4)); CHECK(hipMalloc(&d_ray, (size_t)slots * 4));
+            CHECK(hipMemcpy(d_tab, s_meta.data(), slots * 4, hipMemcpyHostToDevice));
+            CHECK(hipMemcpy(d_tab + slots, s_base.data(), slots * 4, hipMemcpyHostToDevice));
+            CHECK(hipMemcpy(d_tab + 2 * slots, s_q.data(), slots * 4, hipMemcpyHostToDevice));
+            CHECK(hipMemcpy(d_tab + 3 * slots, s_vm.data(), slots * 4, hipMemcpyHostToDevice));
+            CHECK(hipMemcpy(d_tab + 4 * slots, s_nrm.data(), slots * 4, hipMemcpyHostToDevice));
+            CHECK(hipMemcpy(d_ray, s_ray.data(), slots * 4, hipMemcpyHostToDevice));
+            RadonP ps = p;
+            ps.meta = d_tab; ps.base = d_tab + slots;
+            ps.q = reinterpret_cast<const float*>(d_tab + 2 * slots); ps.vm = ps.q + slots; ps.nrm = ps.vm + slots;
+            void* fn = (void*)k_slots<125, PL>;
+            CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            void* args[] = {(void*)&d_img, (void*)&ps, (void*)&d_ray, (void*)&batch, (void*)&d_out, (void*)&d_deg};
+            CHECK(hipMemset(d_out, 0xff, obytes));
+            for (int i = 0; i < 2; ++i) CHECK(hipLaunchKernel(fn, dim3((B + 1) / 2), dim3(kRadonWG), args, lds, 0));
+            CHECK(hipEventRecord(e0));
+            for (int i = 0; i < 5; ++i) CHECK(hipLaunchKernel(fn, dim3((B + 1) / 2), dim3(kRadonWG), args, lds, 0));
+            CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            CHECK(hipMemcpy(out.data(), d_out, obytes, hipMemcpyDeviceToHost));
+            size_t bad = 0;
+            for (size_t i = 0; i < out.size(); ++i) bad += memcmp(&out[i], &ref[i], 4) != 0;
+            const char* names[] = {"slot tables, natural order (in-place normalisation)", "slot tables, rays sorted by (orientation, n_steps)",
+                                   "slot tables, sorted + chunks dealt longest-first to the 16 waves"};
+            printf(",\n  {\"name\": \"%s\", \"ms_per_1024\": %.4f, \"mismatching_values\": %zu}", names[mode], ms / 5 * 1024 / B, bad);
+            CHECK(hipFree(d_tab)); CHECK(hipFree(d_ray));
+        }
     }
     printf("\n]}\n");
     return 0;

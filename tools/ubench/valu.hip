@@ -32,11 +32,13 @@ constexpr int kPerBlock = 256;  // instructions per block (8 chains x 32 repeats
         float r0 = s + threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6,    \
               r7 = r0 + 7;                                                                                            \
         float a = s * 0.999f, b = s * 1e-3f;                                                                          \
+        asm volatile("s_mov_b32 s20, 0x55555555\n s_mov_b32 s21, 0x55555555" ::: "s20", "s21");                                     \
         const unsigned long long t0 = __builtin_readcyclecounter();                                                   \
         for (int i = 0; i < kBlocks; ++i)                                                                             \
             asm volatile(".rept 32\n" TEXT(0) TEXT(1) TEXT(2) TEXT(3) TEXT(4) TEXT(5) TEXT(6) TEXT(7) ".endr" \
                          : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)             \
-                         : "v"(a), "v"(b));                                                                           \
+                         : "v"(a), "v"(b)                                                                             \
+                         : "vcc", "s20", "s21");                                                                      \
         const unsigned long long t1 = __builtin_readcyclecounter();                                                   \
         if ((threadIdx.x & 63) == 0) t[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;                                \
         if (r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 == 12345.678f) sink[0] = r0;                                        \
@@ -78,6 +80,21 @@ constexpr int kPerBlock = 256;  // instructions per block (8 chains x 32 repeats
 #define T_RCP(R) "v_rcp_f32 %" #R ", %" #R "\n"
 #define T_SQRT(R) "v_sqrt_f32 %" #R ", %" #R "\n"
 #define T_MOV(R) "v_mov_b32 %" #R ", %8\n"
+#define T_CMP(R) "v_cmp_lt_f32 vcc, %8, %" #R "\n"
+#define T_CMP64(R) "v_cmp_lt_f32 s[20:21], %8, %" #R "\n"
+#define T_CMPCND(R) "v_cmp_lt_f32 vcc, %8, %" #R "\n s_nop 1\n v_cndmask_b32 %" #R ", %9, %" #R ", vcc\n"
+#define T_CMPCND64(R) "v_cmp_lt_f32 s[20:21], %8, %" #R "\n s_nop 1\n v_cndmask_b32 %" #R ", %9, %" #R ", s[20:21]\n"
+#define T_CNDS(R) "v_cndmask_b32 %" #R ", %8, %" #R ", s[20:21]\n"
+#define T_MED3(R) "v_med3_f32 %" #R ", %8, %" #R ", %9\n"
+#define T_MIN(R) "v_min_f32 %" #R ", %8, %" #R "\n"
+#define T_MAX3(R) "v_max3_f32 %" #R ", %8, %" #R ", %9\n"
+#define T_SUB(R) "v_sub_f32 %" #R ", %8, %" #R "\n"
+#define T_XOR(R) "v_xor_b32 %" #R ", %8, %" #R "\n"
+#define T_LSHL(R) "v_lshlrev_b32 %" #R ", 3, %" #R "\n"
+#define T_BFE(R) "v_bfe_u32 %" #R ", %" #R ", 3, 9\n"
+#define T_ADD3(R) "v_add3_u32 %" #R ", %8, %" #R ", %9\n"
+#define T_DPP(R) "v_mov_b32_dpp %" #R ", %" #R " row_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define T_BPERM(R) "ds_bpermute_b32 %" #R ", %8, %" #R "\n s_waitcnt lgkmcnt(0)\n"
 #define T_PKFMA(R) "v_pk_fma_f32 %" #R ", %8, %" #R ", %9\n"
 #define T_PKADD(R) "v_pk_add_f32 %" #R ", %8, %" #R "\n"
 #define T_PKMUL(R) "v_pk_mul_f32 %" #R ", %8, %" #R "\n"
@@ -103,6 +120,21 @@ KERNEL32(k_cndmask, T_CNDMASK)
 KERNEL32(k_rcp, T_RCP)
 KERNEL32(k_sqrt, T_SQRT)
 KERNEL32(k_mov, T_MOV)
+KERNEL32(k_cmp_vcc, T_CMP)
+KERNEL32(k_cmp_sgpr, T_CMP64)
+KERNEL32(k_cmp_cndmask_vcc, T_CMPCND)
+KERNEL32(k_cmp_cndmask_sgpr, T_CMPCND64)
+KERNEL32(k_cndmask_sgpr, T_CNDS)
+KERNEL32(k_med3, T_MED3)
+KERNEL32(k_min, T_MIN)
+KERNEL32(k_max3, T_MAX3)
+KERNEL32(k_sub, T_SUB)
+KERNEL32(k_xor, T_XOR)
+KERNEL32(k_lshl, T_LSHL)
+KERNEL32(k_bfe, T_BFE)
+KERNEL32(k_add3, T_ADD3)
+KERNEL32(k_dpp, T_DPP)
+KERNEL32(k_bperm, T_BPERM)
 KERNEL64(k_pk_fma, T_PKFMA)
 KERNEL64(k_pk_add, T_PKADD)
 KERNEL64(k_pk_mul, T_PKMUL)
@@ -167,6 +199,12 @@ int main()
         {"v_floor_f32", k_floor}, {"v_cvt_i32_f32", k_cvt_i32_f32}, {"v_cvt_f32_i32", k_cvt_f32_i32}, {"v_mul_u32_u24", k_mul_u32_u24},
         {"v_mad_u32_u24", k_mad_u32_u24}, {"v_mul_lo_u32", k_mul_lo_u32}, {"v_lshl_add_u32", k_lshl_add_u32}, {"v_add_u32", k_add_u32},
         {"v_and_b32", k_and_b32}, {"v_cndmask_b32", k_cndmask}, {"v_rcp_f32", k_rcp}, {"v_sqrt_f32", k_sqrt}, {"v_mov_b32", k_mov},
+        {"v_cmp_lt_f32 -> vcc", k_cmp_vcc}, {"v_cmp_lt_f32 -> sgpr pair", k_cmp_sgpr},
+        {"v_cmp(vcc) + s_nop 1 + v_cndmask(vcc) [2 VALU]", k_cmp_cndmask_vcc},
+        {"v_cmp(sgpr) + s_nop 1 + v_cndmask(sgpr) [2 VALU]", k_cmp_cndmask_sgpr}, {"v_cndmask_b32 (sgpr pair mask)", k_cndmask_sgpr},
+        {"v_med3_f32", k_med3}, {"v_min_f32", k_min}, {"v_max3_f32", k_max3}, {"v_sub_f32", k_sub}, {"v_xor_b32", k_xor},
+        {"v_lshlrev_b32", k_lshl}, {"v_bfe_u32", k_bfe}, {"v_add3_u32", k_add3}, {"v_mov_b32 dpp row_shr:1", k_dpp},
+        {"ds_bpermute_b32 + wait", k_bperm},
         {"v_pk_fma_f32", k_pk_fma}, {"v_pk_add_f32", k_pk_add}, {"v_pk_mul_f32", k_pk_mul}, {"v_fma_f64", k_fma_f64},
         {"v_add_f64", k_add_f64}, {"v_mul_f64", k_mul_f64}};
     const long insts = (long)kBlocks * kPerBlock;
