@@ -45,7 +45,6 @@ constexpr int kTile = 1024;      // target points per LDS tile
 constexpr int kNNThreads = 256;  // lanes per workgroup
 constexpr int kPts = 4;          // source points per lane
 constexpr int kTerms = 28;       // 21 (H upper) + 6 (b) + 1 (error)
-constexpr int kMaxOrder = 512;   // tiles per cloud that get distance-ordered traversal (512k points)
 
 struct LmState {
     double x[16];      // accepted pose (row-major 4x4) = linearisation pose of the current outer iteration
@@ -94,23 +93,14 @@ __device__ __forceinline__ float dist2(float qx, float qy, float qz, const float
     return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
 }
 
-struct TileBoxes {
-    const float4* lo;  // [ntiles] min corner of tile t (points [1024 t, 1024 t + 1024) of the cloud)
-    const float4* hi;
+// Bounding boxes of the Morton-ordered cloud at two granularities, in global memory (built once per set_clouds by k_boxes):
+//   tile t  = points [1024 t, 1024 t + 1024),  mini 64 t + m = points [1024 t + 16 m, + 16)   (slots past the cloud: empty boxes, lo = +inf, hi = -inf)
+struct Hier {
+    const float4* tlo;  // [ntiles]
+    const float4* thi;
+    const float4* mlo;  // [64 * ntiles]
+    const float4* mhi;
     int ntiles;
-};
-
-constexpr int kSub = 128;                 // candidates per sub-tile (wave-level culling granularity inside a staged tile)
-constexpr int kSubs = kTile / kSub;
-
-struct ScanShared {
-    float4 tile[kTile];
-    float lb[kMaxOrder];
-    short order[kMaxOrder];
-    float qlo[4][3], qhi[4][3];
-    float sub[kSubs][2][6];               // per sub-tile and per half (one wave each): min xyz, max xyz
-    float mini[kTile / 16][6];            // per 16 consecutive candidates: min xyz, max xyz (third culling level)
-    float wbest[4];                       // per wave: largest current search radius^2 of its live queries
 };
 
 __device__ __forceinline__ float box_point_d2(const float4& lo, const float4& hi, float x, float y, float z)
@@ -121,106 +111,92 @@ __device__ __forceinline__ float box_point_d2(const float4& lo, const float4& hi
     return dx * dx + dy * dy + dz * dz;
 }
 
-// Orders the target tiles of one cloud by their distance to the bounding box of the workgroup's
-// live queries (sh.order / sh.lb, ascending; tiles beyond `maxc2` get lb = +inf and sort last).
-// (lo, hi): this lane's own query bounds (+inf / -inf when it has no live query).
-__device__ __forceinline__ void order_tiles(ScanShared& sh, const TileBoxes& tb, float maxc2, float lo[3], float hi[3])
+// lower bound of the squared distance between any point of box (lo, hi) and any point of box (qlo, qhi)
+__device__ __forceinline__ float box_box_d2(const float4& lo, const float4& hi, const float (&qlo)[3], const float (&qhi)[3])
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float dx = fmaxf(fmaxf(lo.x - qhi[0], qlo[0] - hi.x), 0.0f);
+    const float dy = fmaxf(fmaxf(lo.y - qhi[1], qlo[1] - hi.y), 0.0f);
+    const float dz = fmaxf(fmaxf(lo.z - qhi[2], qlo[2] - hi.z), 0.0f);
+    return dx * dx + dy * dy + dz * dz;
+}
+
+// bounding box of a wave's live queries (every lane returns the same values; +inf / -inf without live queries)
+__device__ __forceinline__ void wave_bbox(float (&lo)[3], float (&hi)[3])
+{
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
+    for (int a = 0; a < 3; ++a)
         for (int o = 32; o > 0; o >>= 1) {
             lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64));
             hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64));
         }
-        if (lane == 0) { sh.qlo[wave][a] = lo[a]; sh.qhi[wave][a] = hi[a]; }
-    }
-    __syncthreads();
-    float blo[3], bhi[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        blo[a] = fminf(fminf(sh.qlo[0][a], sh.qlo[1][a]), fminf(sh.qlo[2][a], sh.qlo[3][a]));
-        bhi[a] = fmaxf(fmaxf(sh.qhi[0][a], sh.qhi[1][a]), fmaxf(sh.qhi[2][a], sh.qhi[3][a]));
-    }
-    const int nt = min(tb.ntiles, kMaxOrder);
-    for (int t = threadIdx.x; t < nt; t += kNNThreads) {
-        const float4 l = tb.lo[t], h = tb.hi[t];
-        const float dx = fmaxf(fmaxf(l.x - bhi[0], blo[0] - h.x), 0.0f);
-        const float dy = fmaxf(fmaxf(l.y - bhi[1], blo[1] - h.y), 0.0f);
-        const float dz = fmaxf(fmaxf(l.z - bhi[2], blo[2] - h.z), 0.0f);
-        const float d = dx * dx + dy * dy + dz * dz;
-        sh.lb[t] = d * 0.9999f > maxc2 ? INFINITY : d;
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < nt; t += kNNThreads) {  // rank sort (ntiles is ~120 for a 120k cloud)
-        const float mine = sh.lb[t];
-        int rank = 0;
-        for (int u = 0; u < nt; ++u) {
-            const float o = sh.lb[u];
-            rank += (o < mine || (o == mine && u < t)) ? 1 : 0;
-        }
-        sh.order[rank] = (short)t;
-    }
-    __syncthreads();
 }
 
-// Stage target tile [t0, t0 + cnt) into LDS together with the bounding boxes of its 8 sub-tiles of 128 candidates
-// (load j of wave w covers candidates [256 j + 64 w, +64): half (w & 1) of sub-tile 2 j + (w >> 1)).
-// Ends with a barrier; the caller's next barrier protects sh.tile / sh.sub against early overwriting.
-__device__ __forceinline__ void stage_tile(ScanShared& sh, const float4* __restrict__ tgt, int t0, int cnt)
+__device__ __forceinline__ float wave_max(float v)
 {
-    static_assert(kNNThreads == 256 && kTile == 1024 && kSub == 128, "staging layout assumes 4 waves x 4 loads");
-    const int wave = threadIdx.x >> 6;
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// The traversal every nearest-neighbour query of this file runs on.  No LDS tile, no workgroup barrier: a WAVE (its queries are 64
+// consecutive Morton-ordered points, i.e. spatially compact) walks the hierarchy on its own.  The earlier design staged 1024-point tiles
+// through the LDS for the whole workgroup; counters showed a wave staging 9 tiles (9 216 candidates, box reductions and barriers
+// included) to evaluate ~670 of them, so that staging cost more than scanning.  Here:
+//   * tiles: lane l tests tile (64 r + l) against the wave's query box widened by `reach` (the largest bound of any lane, fixed at
+//     entry: bounds only shrink) -> one ballot per 64 tiles;
+//   * minis of a hit tile: lane l tests mini l the same way -> one ballot per tile;
+//   * a hit mini is then tested exactly (`need`: any lane whose own ball touches the box, current bounds) and its 16 candidates are
+//     read with wave-uniform addresses (scalar / broadcast loads out of L2) as two groups of 8 squared distances handed to `visit`.
+// Conservative at every level (0.9999 slack on the box distances), so the neighbours found are the exact ones.
+template <class Need, class Visit>
+__device__ __forceinline__ void hier_visit(const float4* __restrict__ pts, int n, const Hier& H, const float (&wlo)[3], const float (&whi)[3],
+                                           float reach, float qx, float qy, float qz, Need need, Visit visit)
+{
+    const int lane = threadIdx.x & 63;
+    for (int tb = 0; tb < H.ntiles; tb += 64) {
+        const int t = tb + lane;
+        bool hit = false;
+        if (t < H.ntiles) hit = box_box_d2(H.tlo[t], H.thi[t], wlo, whi) * 0.9999f <= reach;
+        unsigned long long tmask = __ballot(hit);
+        while (tmask) {
+            const int tt = tb + (int)__builtin_ctzll(tmask);
+            tmask &= tmask - 1;
+            const bool mhit = box_box_d2(H.mlo[tt * 64 + lane], H.mhi[tt * 64 + lane], wlo, whi) * 0.9999f <= reach;
+            unsigned long long mmask = __ballot(mhit);
+            while (mmask) {
+                const int m = (int)__builtin_ctzll(mmask);
+                mmask &= mmask - 1;
+                const float4 lo = H.mlo[tt * 64 + m], hi = H.mhi[tt * 64 + m];
+                if (!__any(need(lo, hi))) continue;
+                const int j0 = tt * kTile + m * 16;
+                float4 c[16];          // all 16 candidates requested before the first use (wave-uniform addresses: scalar loads)
 #pragma unroll
-    for (int j = 0; j < kTile / kNNThreads; ++j) {
-        const int i = j * kNNThreads + threadIdx.x;
-        const bool in = i < cnt;
-        const float4 c = in ? tgt[t0 + i] : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
-        sh.tile[i] = c;
-        float b[6] = {c.x, c.y, c.z, in ? c.x : -INFINITY, in ? c.y : -INFINITY, in ? c.z : -INFINITY};
+                for (int u = 0; u < 16; ++u) c[u] = j0 + u < n ? pts[j0 + u] : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
-            for (int o = 1; o < 16; o <<= 1) {
-                b[a] = fminf(b[a], __shfl_xor(b[a], o, 64));
-                b[3 + a] = fmaxf(b[3 + a], __shfl_xor(b[3 + a], o, 64));
+                for (int h = 0; h < 2; ++h) {
+                    float dd[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float dx = qx - c[8 * h + u].x, dy = qy - c[8 * h + u].y, dz = qz - c[8 * h + u].z;
+                        dd[u] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                    }
+                    visit(j0 + 8 * h, dd);
+                }
             }
-        if ((threadIdx.x & 15) == 0) {
-#pragma unroll
-            for (int a = 0; a < 6; ++a) sh.mini[i >> 4][a] = b[a];
-        }
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-            for (int o = 16; o < 64; o <<= 1) {
-                b[a] = fminf(b[a], __shfl_xor(b[a], o, 64));
-                b[3 + a] = fmaxf(b[3 + a], __shfl_xor(b[3 + a], o, 64));
-            }
-        if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-            for (int a = 0; a < 6; ++a) sh.sub[2 * j + (wave >> 1)][wave & 1][a] = b[a];
         }
     }
-    __syncthreads();
 }
 
-__device__ __forceinline__ void sub_box(const ScanShared& sh, int sb, float4& slo, float4& shi)
-{
-    slo.x = fminf(sh.sub[sb][0][0], sh.sub[sb][1][0]); slo.y = fminf(sh.sub[sb][0][1], sh.sub[sb][1][1]);
-    slo.z = fminf(sh.sub[sb][0][2], sh.sub[sb][1][2]);
-    shi.x = fmaxf(sh.sub[sb][0][3], sh.sub[sb][1][3]); shi.y = fmaxf(sh.sub[sb][0][4], sh.sub[sb][1][4]);
-    shi.z = fmaxf(sh.sub[sb][0][5], sh.sub[sb][1][5]);
-}
-
-// Exact 1-NN of P query points per lane over the Morton-ordered cloud tgt[0..m): squared distance
-// and (sorted-space) index.  Tiles are culled conservatively with their bounding boxes; `maxc2` is
-// the rejection radius (inf = none).  The whole workgroup must call it together.
+// Exact 1-NN of P query points per lane over the Morton-ordered cloud tgt[0..m): squared distance and (sorted-space) index; `maxc2` is
+// the rejection radius (inf = none).  seed: any valid target index per query (last pass's neighbour, or the Morton seed of a cold
+// start): its distance is the initial bound.  Waves are independent (no barrier inside).
 template <int P>
-__device__ __forceinline__ void nn_scan(const float4* __restrict__ tgt, int m, const TileBoxes& tb, float maxc2,
+__device__ __forceinline__ void nn_scan(const float4* __restrict__ tgt, int m, const Hier& H, float maxc2,
                                         const float (&qx)[P], const float (&qy)[P], const float (&qz)[P],
-                                        const bool (&live)[P], ScanShared& sh, float (&best)[P], int (&bidx)[P],
-                                        const int (&seed)[P])
+                                        const bool (&live)[P], float (&best)[P], int (&bidx)[P], const int (&seed)[P])
 {
     int grp[P];
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float r = 0.0f;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         best[p] = INFINITY; grp[p] = -1;
@@ -230,73 +206,51 @@ __device__ __forceinline__ void nn_scan(const float4* __restrict__ tgt, int m, c
             lo[2] = fminf(lo[2], qz[p]); hi[2] = fmaxf(hi[2], qz[p]);
             // warm start: any target point is an upper bound; last pass's neighbour is nearly always the winner
             if (seed[p] >= 0 && seed[p] < m) { best[p] = dist2(qx[p], qy[p], qz[p], tgt[seed[p]]); grp[p] = seed[p] & ~7; }
+            r = fmaxf(r, fminf(best[p], maxc2));
         }
     }
-    {   // the workgroup's largest search radius (warm-started queries: centimetres; otherwise maxc2): tiles are visited
-        // in ascending box distance, so the first tile beyond it ends the loop without any further barrier
-        float r = 0.0f;
+    wave_bbox(lo, hi);
+    const float reach = wave_max(r);
+    // the P queries of a lane share one traversal: `need` / `visit` loop over them
+    auto need = [&](const float4& blo, const float4& bhi) {
+        bool w = false;
 #pragma unroll
-        for (int p = 0; p < P; ++p) r = fmaxf(r, live[p] ? fminf(best[p], maxc2) : 0.0f);
-        for (int o = 32; o > 0; o >>= 1) r = fmaxf(r, __shfl_xor(r, o, 64));
-        if ((threadIdx.x & 63) == 0) sh.wbest[threadIdx.x >> 6] = r;
-    }
-    order_tiles(sh, tb, maxc2, lo, hi);
-    const float reach = fmaxf(fmaxf(sh.wbest[0], sh.wbest[1]), fmaxf(sh.wbest[2], sh.wbest[3]));
-    for (int k = 0; k < tb.ntiles; ++k) {
-        const int t = k < kMaxOrder ? (int)sh.order[k] : k;
-        if (k < kMaxOrder && !(sh.lb[t] * 0.9999f <= reach)) {  // this and every later ORDERED tile: out of reach
-            if (tb.ntiles <= kMaxOrder) break;
-            k = kMaxOrder - 1;  // clouds beyond kMaxOrder tiles: the tail is not ordered, test every tile of it
-            continue;
-        }
-        const float4 blo = tb.lo[t], bhi = tb.hi[t];
-        bool need = false;
+        for (int p = 0; p < P; ++p) w |= live[p] && box_point_d2(blo, bhi, qx[p], qy[p], qz[p]) * 0.9999f <= fminf(best[p], maxc2);
+        return w;
+    };
+    const int lane = threadIdx.x & 63;
+    for (int tb = 0; tb < H.ntiles; tb += 64) {
+        const int t = tb + lane;
+        bool hit = false;
+        if (t < H.ntiles) hit = box_box_d2(H.tlo[t], H.thi[t], lo, hi) * 0.9999f <= reach;
+        unsigned long long tmask = __ballot(hit);
+        while (tmask) {
+            const int tt = tb + (int)__builtin_ctzll(tmask);
+            tmask &= tmask - 1;
+            const bool mhit = box_box_d2(H.mlo[tt * 64 + lane], H.mhi[tt * 64 + lane], lo, hi) * 0.9999f <= reach;
+            unsigned long long mmask = __ballot(mhit);
+            while (mmask) {
+                const int mm = (int)__builtin_ctzll(mmask);
+                mmask &= mmask - 1;
+                if (!__any(need(H.mlo[tt * 64 + mm], H.mhi[tt * 64 + mm]))) continue;
+                const int j0 = tt * kTile + mm * 16;
+                float4 c16[16];        // all 16 candidates requested before the first use (wave-uniform addresses: scalar loads)
 #pragma unroll
-        for (int p = 0; p < P; ++p)
-            need |= live[p] && box_point_d2(blo, bhi, qx[p], qy[p], qz[p]) * 0.9999f <= fminf(best[p], maxc2);
-        if (!__syncthreads_or(need)) continue;
-        const int t0 = t * kTile;
-        const int cnt = min(kTile, m - t0);
-        stage_tile(sh, tgt, t0, cnt);
-        for (int sb = 0; sb < kSubs; ++sb) {
-            if (sb * kSub >= cnt) break;
-            // wave-level culling: this wave's queries (4 x 64 consecutive Morton-ordered points) vs the sub-tile's box
-            float4 slo, shi;
-            sub_box(sh, sb, slo, shi);
-            bool wneed = false;
-#pragma unroll
-            for (int p = 0; p < P; ++p)
-                wneed |= live[p] && box_point_d2(slo, shi, qx[p], qy[p], qz[p]) * 0.9999f <= fminf(best[p], maxc2);
-            if (!__any(wneed)) continue;
-            const int mi_end = min((sb + 1) * (kSub / 16), (cnt + 15) >> 4);
-            for (int mi = sb * (kSub / 16); mi < mi_end; ++mi) {
-                // third level: 16 consecutive candidates against this wave's queries
-                float4 mlo, mhi;
-                mlo.x = sh.mini[mi][0]; mlo.y = sh.mini[mi][1]; mlo.z = sh.mini[mi][2];
-                mhi.x = sh.mini[mi][3]; mhi.y = sh.mini[mi][4]; mhi.z = sh.mini[mi][5];
-                bool mneed = false;
-#pragma unroll
-                for (int p = 0; p < P; ++p)
-                    mneed |= live[p] && box_point_d2(mlo, mhi, qx[p], qy[p], qz[p]) * 0.9999f <= fminf(best[p], maxc2);
-                if (!__any(mneed)) continue;
+                for (int u = 0; u < 16; ++u) c16[u] = j0 + u < m ? tgt[j0 + u] : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const int g = 2 * mi + h;
-                    float4 c[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) c[u] = sh.tile[8 * g + u];
+                    const float4* c = c16 + 8 * h;
 #pragma unroll
                     for (int p = 0; p < P; ++p) {
                         float d[8];
 #pragma unroll
                         for (int u = 0; u < 8; ++u) d[u] = dist2(qx[p], qy[p], qz[p], c[u]);
                         const float mn = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])), fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
-                        if (mn < best[p]) { best[p] = mn; grp[p] = t0 + 8 * g; }
+                        if (mn < best[p]) { best[p] = mn; grp[p] = j0 + 8 * h; }
                     }
                 }
             }
         }
-        // the next __syncthreads_or also protects sh.tile / sh.sub against early overwriting
     }
     // resolve the index inside the winning group of 8
 #pragma unroll
@@ -433,10 +387,10 @@ __global__ void k_gather_sorted(const float* __restrict__ src, int stride, const
     }
 }
 
-// bounding box of every 1024-point tile; tile_base[c] = first tile of cloud c
-__global__ __launch_bounds__(256) void k_tile_boxes(const float4* __restrict__ pts, const int64_t* __restrict__ offs,
-                                                    const int* __restrict__ tile_base, float4* __restrict__ tlo,
-                                                    float4* __restrict__ thi)
+// bounding boxes of every 1024-point tile and of its 64 minis of 16 points; tile_base[c] = first tile of cloud c (minis: 64 x that)
+__global__ __launch_bounds__(256) void k_boxes(const float4* __restrict__ pts, const int64_t* __restrict__ offs, const int* __restrict__ tile_base,
+                                               float4* __restrict__ tlo, float4* __restrict__ thi, float4* __restrict__ mlo,
+                                               float4* __restrict__ mhi)
 {
     __shared__ float red[4][6];
     const int c = blockIdx.y;
@@ -444,12 +398,27 @@ __global__ __launch_bounds__(256) void k_tile_boxes(const float4* __restrict__ p
     const int n = (int)(offs[c + 1] - o);
     const int t = blockIdx.x;
     if (t * kTile >= n) return;
+    const size_t tile = (size_t)tile_base[c] + t;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = t * kTile + threadIdx.x; i < min(n, (t + 1) * kTile); i += 256) {
-        const float4 p = pts[o + i];
-        lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
-        lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
-        lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
+#pragma unroll
+    for (int j = 0; j < kTile / 256; ++j) {
+        const int i = t * kTile + j * 256 + (int)threadIdx.x;      // 16 consecutive lanes = one mini
+        const bool in = i < n;
+        const float4 p = pts[o + (in ? i : 0)];
+        float b[6] = {in ? p.x : INFINITY, in ? p.y : INFINITY, in ? p.z : INFINITY, in ? p.x : -INFINITY, in ? p.y : -INFINITY, in ? p.z : -INFINITY};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            for (int s = 1; s < 16; s <<= 1) {
+                b[a] = fminf(b[a], __shfl_xor(b[a], s, 64));
+                b[3 + a] = fmaxf(b[3 + a], __shfl_xor(b[3 + a], s, 64));
+            }
+        if ((threadIdx.x & 15) == 0) {
+            const size_t mi = tile * 64 + (size_t)((j * 256 + (int)threadIdx.x) >> 4);
+            mlo[mi] = make_float4(b[0], b[1], b[2], 0.f);
+            mhi[mi] = make_float4(b[3], b[4], b[5], 0.f);
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], b[a]); hi[a] = fmaxf(hi[a], b[3 + a]); }
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -466,8 +435,8 @@ __global__ __launch_bounds__(256) void k_tile_boxes(const float4* __restrict__ p
             l[a] = fminf(fminf(red[0][a], red[1][a]), fminf(red[2][a], red[3][a]));
             h[a] = fmaxf(fmaxf(red[0][3 + a], red[1][3 + a]), fmaxf(red[2][3 + a], red[3][3 + a]));
         }
-        tlo[tile_base[c] + t] = make_float4(l[0], l[1], l[2], 0.f);
-        thi[tile_base[c] + t] = make_float4(h[0], h[1], h[2], 0.f);
+        tlo[tile] = make_float4(l[0], l[1], l[2], 0.f);
+        thi[tile] = make_float4(h[0], h[1], h[2], 0.f);
     }
 }
 
@@ -551,7 +520,7 @@ __device__ __forceinline__ int knn_seed_home(const float4* __restrict__ pts, int
 // for every lane's insertions: with 16 (32) slots the insertions were most of k_knn_cov (k_knn_features).  Here the scan keeps only the
 // KMAX smallest DISTANCES, sorted, by a chain of v_med3_f32 (dk[s] = med3(dk[s-1], d, dk[s]): one 4-cycle instruction per slot, no
 // predicate: a distance beyond the list leaves it unchanged).  That yields the exact k-th distance tau; a second scan with the fixed
-// bound tau (it revisits only the few sub-tiles within tau) appends the index of every candidate with d <= tau to a per-lane list in
+// bound tau (it revisits only the few minis within tau) appends the index of every candidate with d <= tau to a per-lane list in
 // the LDS, and the <= KMAX + 8 collected candidates are then put in (distance, index) order by the old insertion -- a couple of dozen
 // insertions per query instead of one per candidate that beat any lane's bound.  Exactly equal distances resolve to the smaller
 // (Morton-space) index.  The whole workgroup must call it together.
@@ -559,6 +528,7 @@ constexpr int kKnnSpare = 8;      // list slots beyond KMAX: room for candidates
 // development counters (MRS_KNN_DBG=1 prints them): per wave and round -- tiles staged / candidate groups of 8 visited in pass 1 and 2, groups
 // where some lane's list changed, selection steps, query waves
 __device__ unsigned long long g_knn_dbg[8];
+__device__ int g_knn_dbg_on;       // set by the host when MRS_KNN_DBG is in the environment
 
 template <int KMAX>
 __device__ __forceinline__ void dist_insert(float (&dk)[KMAX], float d)
@@ -582,54 +552,17 @@ __device__ __forceinline__ void knn_insert_tie(float (&dk)[KMAX], int (&ik)[KMAX
     if (dk[0] > d || (dk[0] == d && ik[0] > j)) { dk[0] = d; ik[0] = j; }
 }
 
-// visits every candidate group of 8 whose boxes lie within `bound` (re-read through the callable: it may shrink during the scan) of the
-// lane's query, in the workgroup's tile order (sh.order, set by order_tiles), and hands the 8 distances to `visit(t0 + 8 g, dd)`
-template <class Bound, class Visit>
-__device__ __forceinline__ void knn_visit(ScanShared& sh, const float4* __restrict__ pts, int n, const TileBoxes& tb, bool live, const float4& q,
-                                          Bound bound, Visit visit, int& n_tiles, int& n_groups)
-{
-    for (int kk = 0; kk < tb.ntiles; ++kk) {
-        const int t = kk < kMaxOrder ? (int)sh.order[kk] : kk;
-        const bool need = live && box_point_d2(tb.lo[t], tb.hi[t], q.x, q.y, q.z) * 0.9999f <= bound();
-        if (!__syncthreads_or(need)) continue;
-        const int t0 = t * kTile;
-        const int cnt = min(kTile, n - t0);
-        stage_tile(sh, pts, t0, cnt);
-        ++n_tiles;
-        for (int sb = 0; sb < kSubs && sb * kSub < cnt; ++sb) {
-            float4 slo, shi;   // wave-level culling against the sub-tile's box (this wave: 64 consecutive Morton points)
-            sub_box(sh, sb, slo, shi);
-            if (!__any(live && box_point_d2(slo, shi, q.x, q.y, q.z) * 0.9999f <= bound())) continue;
-            const int g_end = min((sb + 1) * (kSub / 8), (cnt + 7) >> 3);
-            for (int g = sb * (kSub / 8); g < g_end; ++g) {
-                if ((g & 1) == 0) {   // third level: the 16 candidates of groups g, g + 1
-                    const int mi = g >> 1;
-                    float4 mlo, mhi;
-                    mlo.x = sh.mini[mi][0]; mlo.y = sh.mini[mi][1]; mlo.z = sh.mini[mi][2];
-                    mhi.x = sh.mini[mi][3]; mhi.y = sh.mini[mi][4]; mhi.z = sh.mini[mi][5];
-                    if (!__any(live && box_point_d2(mlo, mhi, q.x, q.y, q.z) * 0.9999f <= bound())) { ++g; continue; }
-                }
-                float dd[8];   // padding candidates sit at +inf
-#pragma unroll
-                for (int u = 0; u < 8; ++u) dd[u] = dist2(q.x, q.y, q.z, sh.tile[8 * g + u]);
-                ++n_groups;
-                visit(t0 + 8 * g, dd);
-            }
-        }
-    }
-}
-
 // dk / ik: the k nearest of point i (itself included), ascending in (distance, index); slots >= the number found hold +inf / -1.
 // list: kNNThreads x (KMAX + kKnnSpare) ints of LDS, slot-major.
 template <int KMAX>
-__device__ __forceinline__ void knn_two_pass(ScanShared& sh, int* __restrict__ list, const float4* __restrict__ pts, int n, const TileBoxes& tb,
+__device__ __forceinline__ void knn_two_pass(int* __restrict__ list, const float4* __restrict__ pts, int n, const Hier& H,
                                              int i, bool live, const float4& q, int k, float (&dk)[KMAX], int (&ik)[KMAX])
 {
     constexpr int CAP = KMAX + kKnnSpare;
 #pragma unroll
     for (int s = 0; s < KMAX; ++s) dk[s] = INFINITY;
     // pass 1: the KMAX smallest distances.  Seed: the 64 neighbours along the Morton curve (the bound is close to final before the
-    // first tile is staged); the tile scan skips exactly that index range.
+    // hierarchy is walked); the walk skips exactly that index range.
     const int home = max(0, min(i - kHome / 2, n - kHome));
     for (int u = 0; u < kHome; ++u) {
         const int j = home + u;
@@ -639,38 +572,42 @@ __device__ __forceinline__ void knn_two_pass(ScanShared& sh, int* __restrict__ l
     }
     float lo[3] = {live ? q.x : INFINITY, live ? q.y : INFINITY, live ? q.z : INFINITY};
     float hi[3] = {live ? q.x : -INFINITY, live ? q.y : -INFINITY, live ? q.z : -INFINITY};
-    __syncthreads();  // previous round done with sh
-    order_tiles(sh, tb, INFINITY, lo, hi);
-    int c_t1 = 0, c_g1 = 0, c_ins = 0, c_t2 = 0, c_g2 = 0;
-    knn_visit(sh, pts, n, tb, live, q, [&]() { return dk[KMAX - 1]; }, [&](int j0, const float (&dd)[8]) {
-        const float mn = fminf(fminf(fminf(dd[0], dd[1]), fminf(dd[2], dd[3])), fminf(fminf(dd[4], dd[5]), fminf(dd[6], dd[7])));
-        if (!__any(live && mn < dk[KMAX - 1])) return;
-        ++c_ins;
+    wave_bbox(lo, hi);
+    int c_g1 = 0, c_ins = 0, c_g2 = 0;
+    hier_visit(pts, n, H, lo, hi, wave_max(live ? dk[KMAX - 1] : 0.0f), q.x, q.y, q.z,
+               [&](const float4& blo, const float4& bhi) { return live && box_point_d2(blo, bhi, q.x, q.y, q.z) * 0.9999f <= dk[KMAX - 1]; },
+               [&](int j0, const float (&dd)[8]) {
+                   ++c_g1;
+                   const float mn = fminf(fminf(fminf(dd[0], dd[1]), fminf(dd[2], dd[3])), fminf(fminf(dd[4], dd[5]), fminf(dd[6], dd[7])));
+                   if (!__any(live && mn < dk[KMAX - 1])) return;
+                   ++c_ins;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const bool use = live && (unsigned)(j0 + u - home) >= (unsigned)kHome && dd[u] == dd[u];
-            dist_insert<KMAX>(dk, use ? dd[u] : INFINITY);
-        }
-    }, c_t1, c_g1);
+                   for (int u = 0; u < 8; ++u) {
+                       const bool use = live && (unsigned)(j0 + u - home) >= (unsigned)kHome && dd[u] == dd[u];
+                       dist_insert<KMAX>(dk, use ? dd[u] : INFINITY);
+                   }
+               });
     // pass 2: every candidate within the k-th distance, home range included
     const float tau = live ? dk[(k < KMAX ? k : KMAX) - 1] : -1.0f;
     int cnt = 0;
-    knn_visit(sh, pts, n, tb, live, q, [&]() { return tau; }, [&](int j0, const float (&dd)[8]) {
+    hier_visit(pts, n, H, lo, hi, wave_max(tau), q.x, q.y, q.z,
+               [&](const float4& blo, const float4& bhi) { return live && box_point_d2(blo, bhi, q.x, q.y, q.z) * 0.9999f <= tau; },
+               [&](int j0, const float (&dd)[8]) {
+                   ++c_g2;
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (dd[u] <= tau && cnt < CAP) {
-                list[cnt * kNNThreads + (int)threadIdx.x] = j0 + u;
-                ++cnt;
-            }
-    }, c_t2, c_g2);
+                   for (int u = 0; u < 8; ++u)
+                       if (dd[u] <= tau && cnt < CAP) {
+                           list[cnt * kNNThreads + (int)threadIdx.x] = j0 + u;
+                           ++cnt;
+                       }
+               });
     // selection: (distance, index) order
 #pragma unroll
     for (int s = 0; s < KMAX; ++s) { dk[s] = INFINITY; ik[s] = -1; }
     int most = cnt;
     for (int o = 32; o > 0; o >>= 1) most = max(most, __shfl_xor(most, o, 64));
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&g_knn_dbg[0], (unsigned long long)c_t1); atomicAdd(&g_knn_dbg[1], (unsigned long long)c_g1);
-        atomicAdd(&g_knn_dbg[2], (unsigned long long)c_ins); atomicAdd(&g_knn_dbg[3], (unsigned long long)c_t2);
+    if (g_knn_dbg_on && (threadIdx.x & 63) == 0) {
+        atomicAdd(&g_knn_dbg[1], (unsigned long long)c_g1); atomicAdd(&g_knn_dbg[2], (unsigned long long)c_ins);
         atomicAdd(&g_knn_dbg[4], (unsigned long long)c_g2); atomicAdd(&g_knn_dbg[5], (unsigned long long)most);
         atomicAdd(&g_knn_dbg[6], 1ull);
     }
@@ -691,25 +628,25 @@ template <int KMAX>
 __global__ __launch_bounds__(kNNThreads) void k_knn_cov(const float4* __restrict__ pts_all,
                                                         const int64_t* __restrict__ offs, const int* __restrict__ tile_base,
                                                         const float4* __restrict__ tlo, const float4* __restrict__ thi,
+        const float4* __restrict__ mlo, const float4* __restrict__ mhi,
                                                         int k, double* __restrict__ cov_all, int* __restrict__ knn_out)
 {
-    __shared__ ScanShared sh;
     __shared__ int knn_list[(KMAX + kKnnSpare) * kNNThreads];
     const int c = blockIdx.y;
     const int64_t o = offs[c];
     const int n = (int)(offs[c + 1] - o);
     const float4* pts = pts_all + o;
-    TileBoxes tb;
-    tb.lo = tlo + tile_base[c];
-    tb.hi = thi + tile_base[c];
-    tb.ntiles = (n + kTile - 1) / kTile;
+    Hier H;
+    H.tlo = tlo + tile_base[c]; H.thi = thi + tile_base[c];
+    H.mlo = mlo + (size_t)64 * tile_base[c]; H.mhi = mhi + (size_t)64 * tile_base[c];
+    H.ntiles = (n + kTile - 1) / kTile;
     for (int base = blockIdx.x * kNNThreads; base < n; base += gridDim.x * kNNThreads) {
         const int i = base + threadIdx.x;
         const bool live = i < n;
         const float4 q = pts[live ? i : 0];
         float dk[KMAX];
         int ik[KMAX];
-        knn_two_pass<KMAX>(sh, knn_list, pts, n, tb, i, live, q, k, dk, ik);
+        knn_two_pass<KMAX>(knn_list, pts, n, H, i, live, q, k, dk, ik);
         if (!live) continue;
         double mean[3] = {0, 0, 0};
         int cnt = 0;
@@ -848,26 +785,26 @@ template <int KMAX>
 __global__ __launch_bounds__(kNNThreads) void k_knn_features(const float4* __restrict__ pts_all,
                                                              const int64_t* __restrict__ offs, const int* __restrict__ tile_base,
                                                              const float4* __restrict__ tlo, const float4* __restrict__ thi,
+        const float4* __restrict__ mlo, const float4* __restrict__ mhi,
                                                              int k, int* __restrict__ knn_out, float* __restrict__ eig_out,
                                                              float* __restrict__ feat_out, float* __restrict__ feat_planes)
 {
-    __shared__ ScanShared sh;
     __shared__ int knn_list[(KMAX + kKnnSpare) * kNNThreads];
     const int c = blockIdx.y;
     const int64_t o = offs[c];
     const int n = (int)(offs[c + 1] - o);
     const float4* pts = pts_all + o;
-    TileBoxes tb;
-    tb.lo = tlo + tile_base[c];
-    tb.hi = thi + tile_base[c];
-    tb.ntiles = (n + kTile - 1) / kTile;
+    Hier H;
+    H.tlo = tlo + tile_base[c]; H.thi = thi + tile_base[c];
+    H.mlo = mlo + (size_t)64 * tile_base[c]; H.mhi = mhi + (size_t)64 * tile_base[c];
+    H.ntiles = (n + kTile - 1) / kTile;
     for (int base = blockIdx.x * kNNThreads; base < n; base += gridDim.x * kNNThreads) {
         const int i = base + threadIdx.x;
         const bool live = i < n;
         const float4 q = pts[live ? i : 0];
         float dk[KMAX];
         int ik[KMAX];
-        knn_two_pass<KMAX>(sh, knn_list, pts, n, tb, i, live, q, k, dk, ik);
+        knn_two_pass<KMAX>(knn_list, pts, n, H, i, live, q, k, dk, ik);
         if (!live) continue;
         const int oi = __float_as_int(q.w);
         double mean[3] = {0, 0, 0};
@@ -941,10 +878,10 @@ __global__ __launch_bounds__(kNNThreads) void k_nn_scan(
     const float4* __restrict__ src_all, const int64_t* __restrict__ src_offs,
     const float4* __restrict__ tgt_all, const int64_t* __restrict__ tgt_offs,
     const int* __restrict__ tgt_tile_base, const float4* __restrict__ tlo, const float4* __restrict__ thi,
+        const float4* __restrict__ mlo, const float4* __restrict__ mhi,
     const LmState* __restrict__ st, GicpParams prm, int* __restrict__ corr, int* __restrict__ nn_seed,
     const int* __restrict__ tgt_bbox)
 {
-    __shared__ ScanShared sh;
     const int pair = blockIdx.y;
     const LmState& S = st[pair];
     if (!S.active || S.phase != 0) return;   // LM trials reuse the cached correspondences (upstream compute_error)
@@ -952,10 +889,10 @@ __global__ __launch_bounds__(kNNThreads) void k_nn_scan(
     const int n = (int)(src_offs[pair + 1] - so), m = (int)(tgt_offs[pair + 1] - to);
     const float4* src = src_all + so;
     const float4* tgt = tgt_all + to;
-    TileBoxes tb;
-    tb.lo = tlo + tgt_tile_base[pair];
-    tb.hi = thi + tgt_tile_base[pair];
-    tb.ntiles = (m + kTile - 1) / kTile;
+    Hier H;
+    H.tlo = tlo + tgt_tile_base[pair]; H.thi = thi + tgt_tile_base[pair];
+    H.mlo = mlo + (size_t)64 * tgt_tile_base[pair]; H.mhi = mhi + (size_t)64 * tgt_tile_base[pair];
+    H.ntiles = (m + kTile - 1) / kTile;
     const float maxc2 = prm.max_corr2 < 3.0e38 ? (float)prm.max_corr2 * 1.0001f : INFINITY;
     float Tf[12];
 #pragma unroll
@@ -981,8 +918,7 @@ __global__ __launch_bounds__(kNNThreads) void k_nn_scan(
         }
         float best[P];
         int bidx[P];
-        __syncthreads();
-        nn_scan<P>(tgt, m, tb, maxc2, qx, qy, qz, live, sh, best, bidx, seed);
+        nn_scan<P>(tgt, m, H, maxc2, qx, qy, qz, live, best, bidx, seed);
 #pragma unroll
         for (int p = 0; p < P; ++p)
             if (live[p]) {
@@ -1442,21 +1378,21 @@ __global__ __launch_bounds__(kNNThreads) void k_fitness(const float4* __restrict
                                                         const int64_t* __restrict__ tgt_offs,
                                                         const int* __restrict__ tgt_tile_base,
                                                         const float4* __restrict__ tlo, const float4* __restrict__ thi,
+        const float4* __restrict__ mlo, const float4* __restrict__ mhi,
                                                         const double* __restrict__ poses /* [pairs][16] */,
                                                         double max_range, double* __restrict__ partial, int max_blocks,
                                                         const int* __restrict__ nn_seed /* optional warm start */)
 {
-    __shared__ ScanShared sh;
     __shared__ double red[kNNThreads / 64][2];
     const int pair = blockIdx.y;
     const int64_t so = src_offs[pair], to = tgt_offs[pair];
     const int n = (int)(src_offs[pair + 1] - so), m = (int)(tgt_offs[pair + 1] - to);
     const float4* src = src_all + so;
     const float4* tgt = tgt_all + to;
-    TileBoxes tb;
-    tb.lo = tlo + tgt_tile_base[pair];
-    tb.hi = thi + tgt_tile_base[pair];
-    tb.ntiles = (m + kTile - 1) / kTile;
+    Hier H;
+    H.tlo = tlo + tgt_tile_base[pair]; H.thi = thi + tgt_tile_base[pair];
+    H.mlo = mlo + (size_t)64 * tgt_tile_base[pair]; H.mhi = mhi + (size_t)64 * tgt_tile_base[pair];
+    H.ntiles = (m + kTile - 1) / kTile;
     const float maxc2 = max_range < 3.0e38 ? (float)max_range * 1.0001f : INFINITY;
     float Tf[12];
 #pragma unroll
@@ -1482,8 +1418,7 @@ __global__ __launch_bounds__(kNNThreads) void k_fitness(const float4* __restrict
         int seed[PF];   // the neighbours of the last alignment pass: valid upper bounds at any pose
 #pragma unroll
         for (int p = 0; p < PF; ++p) seed[p] = (nn_seed && live[p]) ? nn_seed[so + si[p]] : -1;
-        __syncthreads();
-        nn_scan<PF>(tgt, m, tb, maxc2, qx, qy, qz, live, sh, best, bidx, seed);
+        nn_scan<PF>(tgt, m, H, maxc2, qx, qy, qz, live, best, bidx, seed);
 #pragma unroll
         for (int p = 0; p < PF; ++p)
             if (live[p] && bidx[p] >= 0 && (double)best[p] <= max_range) { s += (double)best[p]; c += 1.0; }
@@ -1527,6 +1462,8 @@ struct mrs_gicp_batch {
     int* d_tile_base[2] = {nullptr, nullptr};  // [n_pairs] first tile of each cloud
     float4* d_tlo[2] = {nullptr, nullptr};     // tile bounding boxes
     float4* d_thi[2] = {nullptr, nullptr};
+    float4* d_mlo[2] = {nullptr, nullptr};     // boxes of the 64 minis (16 points) of every tile
+    float4* d_mhi[2] = {nullptr, nullptr};
     int max_tiles[2] = {0, 0};                 // tiles of the largest cloud
     int64_t cap_points[2] = {0, 0};            // capacity of d_pts / d_cov (points), d_tlo / d_thi (cap_tiles): buffers are kept
     int cap_tiles[2] = {0, 0};                 // across setInput* calls and only re-allocated when a cloud outgrows them
@@ -1560,6 +1497,9 @@ void free_cloud(mrs_gicp_batch* h, int w)
     if (h->d_bbox[w]) (void)hipFree(h->d_bbox[w]);
     if (h->d_tlo[w]) (void)hipFree(h->d_tlo[w]);
     if (h->d_thi[w]) (void)hipFree(h->d_thi[w]);
+    if (h->d_mlo[w]) (void)hipFree(h->d_mlo[w]);
+    if (h->d_mhi[w]) (void)hipFree(h->d_mhi[w]);
+    h->d_mlo[w] = nullptr; h->d_mhi[w] = nullptr;
     h->d_offs[w] = nullptr; h->d_pts[w] = nullptr; h->d_cov[w] = nullptr;
     h->d_tile_base[w] = nullptr; h->d_tlo[w] = nullptr; h->d_thi[w] = nullptr; h->d_bbox[w] = nullptr;
     h->cov_valid[w] = false;
@@ -1705,6 +1645,8 @@ int mrs_gicp_batch_set_clouds(mrs_gicp_batch* h, int32_t which, const float* d_p
         MRS_HIP_TRY(hipMalloc(&h->d_tile_base[which], h->n_pairs * sizeof(int)));
         MRS_HIP_TRY(hipMalloc(&h->d_tlo[which], (size_t)capt * sizeof(float4)));
         MRS_HIP_TRY(hipMalloc(&h->d_thi[which], (size_t)capt * sizeof(float4)));
+        MRS_HIP_TRY(hipMalloc(&h->d_mlo[which], (size_t)capt * 64 * sizeof(float4)));
+        MRS_HIP_TRY(hipMalloc(&h->d_mhi[which], (size_t)capt * 64 * sizeof(float4)));
         MRS_HIP_TRY(hipMalloc(&h->d_bbox[which], (size_t)h->n_pairs * 6 * sizeof(int)));
         h->cap_points[which] = cap; h->cap_tiles[which] = capt;
         if (which == 0) {
@@ -1752,8 +1694,8 @@ int mrs_gicp_batch_set_clouds(mrs_gicp_batch* h, int32_t which, const float* d_p
                                                    (int)total, 0, key_bits, s));
     hipLaunchKernelGGL(k_gather_sorted, pg, dim3(256), 0, s, d_points, stride_floats, h->d_offs[which], vals_out.as<int>(),
                        h->d_pts[which]);
-    hipLaunchKernelGGL(k_tile_boxes, dim3(longest_tiles, h->n_pairs), dim3(256), 0, s, h->d_pts[which], h->d_offs[which],
-                       h->d_tile_base[which], h->d_tlo[which], h->d_thi[which]);
+    hipLaunchKernelGGL(k_boxes, dim3(longest_tiles, h->n_pairs), dim3(256), 0, s, h->d_pts[which], h->d_offs[which],
+                       h->d_tile_base[which], h->d_tlo[which], h->d_thi[which], h->d_mlo[which], h->d_mhi[which]);
     MRS_HIP_TRY(hipGetLastError());
     MRS_HIP_TRY(hipStreamSynchronize(s));
     return MRS_OK;
@@ -1788,23 +1730,28 @@ int mrs_gicp_batch_compute_covariances(mrs_gicp_batch* h, int32_t which, int32_t
     for (int i = 0; i < h->n_pairs; ++i) longest = std::max(longest, h->offs[which][i + 1] - h->offs[which][i]);
     const dim3 grid((unsigned)((longest + kNNThreads - 1) / kNNThreads), h->n_pairs);
     const int k = h->prm.k;
+    if (getenv("MRS_KNN_DBG")) {
+        const int on = 1;
+        MRS_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_knn_dbg_on), &on, sizeof(on)));
+    }
     if (k <= 16)
         hipLaunchKernelGGL(k_knn_cov<16>, grid, dim3(kNNThreads), 0, s, h->d_pts[which], h->d_offs[which], h->d_tile_base[which],
-                           h->d_tlo[which], h->d_thi[which], k, h->d_cov[which], d_knn_out);
+                           h->d_tlo[which], h->d_thi[which], h->d_mlo[which], h->d_mhi[which], k, h->d_cov[which], d_knn_out);
     else if (k <= 20)
         hipLaunchKernelGGL(k_knn_cov<20>, grid, dim3(kNNThreads), 0, s, h->d_pts[which], h->d_offs[which], h->d_tile_base[which],
-                           h->d_tlo[which], h->d_thi[which], k, h->d_cov[which], d_knn_out);
+                           h->d_tlo[which], h->d_thi[which], h->d_mlo[which], h->d_mhi[which], k, h->d_cov[which], d_knn_out);
     else
         hipLaunchKernelGGL(k_knn_cov<32>, grid, dim3(kNNThreads), 0, s, h->d_pts[which], h->d_offs[which], h->d_tile_base[which],
-                           h->d_tlo[which], h->d_thi[which], k, h->d_cov[which], d_knn_out);
+                           h->d_tlo[which], h->d_thi[which], h->d_mlo[which], h->d_mhi[which], k, h->d_cov[which], d_knn_out);
     MRS_HIP_TRY(hipGetLastError());
-    if (getenv("MRS_KNN_DBG")) {
+    static const bool knn_dbg = getenv("MRS_KNN_DBG") != nullptr;
+    if (knn_dbg) {
         unsigned long long c[8];
         MRS_HIP_TRY(hipStreamSynchronize(s));
         MRS_HIP_TRY(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_knn_dbg), sizeof(c)));
         const double w = (double)(c[6] ? c[6] : 1);
-        fprintf(stderr, "[knn dbg] per query wave: pass 1 tiles %.1f groups %.1f (list changed in %.1f), pass 2 tiles %.1f groups %.1f, selection steps %.1f; %llu waves\n",
-                c[0] / w, c[1] / w, c[2] / w, c[3] / w, c[4] / w, c[5] / w, c[6]);
+        fprintf(stderr, "[knn dbg] per query wave: pass 1 groups of 8 candidates %.1f (list changed in %.1f), pass 2 groups %.1f, selection steps %.1f; %llu waves\n",
+                c[1] / w, c[2] / w, c[4] / w, c[5] / w, c[6]);
         unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         MRS_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_knn_dbg), z, sizeof(z)));
     }
@@ -1946,7 +1893,7 @@ int mrs_gicp_batch_align(mrs_gicp_batch* h, const double* h_guess, double* h_fin
         } else {
             if (next[0] > 0)   // only linearisations search; LM trials score the cached correspondences
                 launch_nn_scan(h->longest_src, h->n_pairs, h->ctx->num_cu, s, h->d_pts[0], h->d_offs[0], h->d_pts[1], h->d_offs[1],
-                               h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_state, h->prm, h->d_corr, h->d_seed, (const int*)h->d_bbox[1]);
+                               h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_mlo[1], h->d_mhi[1], h->d_state, h->prm, h->d_corr, h->d_seed, (const int*)h->d_bbox[1]);
             hipLaunchKernelGGL(k_linearize, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_cov[0],
                                h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->d_corr, h->d_partial, h->max_blocks);
         }
@@ -1998,7 +1945,7 @@ int mrs_gicp_batch_linearize(mrs_gicp_batch* h, const double* h_poses, double* h
                            h->max_blocks);
     } else {
         launch_nn_scan(h->longest_src, h->n_pairs, h->ctx->num_cu, s, h->d_pts[0], h->d_offs[0],
-                       h->d_pts[1], h->d_offs[1], h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_state, h->prm, h->d_corr, h->d_seed, (const int*)h->d_bbox[1]);
+                       h->d_pts[1], h->d_offs[1], h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_mlo[1], h->d_mhi[1], h->d_state, h->prm, h->d_corr, h->d_seed, (const int*)h->d_bbox[1]);
         hipLaunchKernelGGL(k_linearize, dim3(h->max_blocks, h->n_pairs), dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0],
                            h->d_cov[0], h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->d_corr, h->d_partial,
                            h->max_blocks);
@@ -2043,7 +1990,7 @@ int mrs_gicp_batch_fitness(mrs_gicp_batch* h, const double* h_poses, double max_
     MRS_HIP_TRY(hipMemcpy(poses.p, h_poses, (size_t)h->n_pairs * 16 * sizeof(double), hipMemcpyHostToDevice));
     MRS_HIP_TRY(hipMemsetAsync(part.p, 0, (size_t)h->n_pairs * h->max_blocks * 2 * sizeof(double), s));
     hipLaunchKernelGGL(k_fitness, dim3(h->max_blocks, h->n_pairs), dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0],
-                       h->d_pts[1], h->d_offs[1], h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], poses.as<double>(), max_range,
+                       h->d_pts[1], h->d_offs[1], h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_mlo[1], h->d_mhi[1], poses.as<double>(), max_range,
                        part.as<double>(), h->max_blocks, (const int*)h->d_seed);
     MRS_HIP_TRY(hipGetLastError());
     std::vector<double> hp((size_t)h->n_pairs * h->max_blocks * 2);
@@ -2123,7 +2070,7 @@ int mrs_pointfeat_batch(mrs_ctx* ctx, const float* d_points, int32_t stride_floa
         for (int i = 0; i < batch; ++i) longest = std::max(longest, h_offsets[i + 1] - h_offsets[i]);
         const dim3 grid((unsigned)((longest + kNNThreads - 1) / kNNThreads), batch);
         hipLaunchKernelGGL(k_knn_features<32>, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_tile_base[0],
-                           h->d_tlo[0], h->d_thi[0], k, d_knn, d_eigens, d_features, d_feat_planes);
+                           h->d_tlo[0], h->d_thi[0], h->d_mlo[0], h->d_mhi[0], k, d_knn, d_eigens, d_features, d_feat_planes);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
             mrs::set_error("k_knn_features launch failed");
             st = MRS_ERR_HIP;

@@ -22,11 +22,15 @@ import types
 
 import numpy as np
 
-REF = os.environ.get("MRSLAM_REFERENCE", "/root/reference")
-RING_ROS = os.path.join(REF, "LoopDetection", "src", "RING_ros")
-DISCO_ROS = os.path.join(REF, "LoopDetection", "src", "disco_ros")
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
+# the reference tree where it exists (this container); on a GPU box the few Python files staged by tools/stage_reference_py.py
+# (tests/_refpy/, git-ignored scratch, same relative layout) so that the reference's own functions can run through the drop-in there
+REF = os.environ.get("MRSLAM_REFERENCE", "/root/reference")
+if not os.path.isdir(os.path.join(REF, "LoopDetection")) and os.path.isdir(os.path.join(ROOT, "tests", "_refpy", "LoopDetection")):
+    REF = os.path.join(ROOT, "tests", "_refpy")
+RING_ROS = os.path.join(REF, "LoopDetection", "src", "RING_ros")
+DISCO_ROS = os.path.join(REF, "LoopDetection", "src", "disco_ros")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
