@@ -137,7 +137,16 @@ def cpu_baseline(scans):
     fast_corr restatement on torch CPU) on a bounded sample."""
     from oracle import pyoracle as O
     from oracle import corr_oracle as K
-    cores = min(os.cpu_count() or 1, 16)       # tiny FFTs do not scale past a few threads
+    nproc = os.cpu_count() or 1
+    cores = min(nproc, 16)       # tiny FFTs do not scale past a few threads
+    cpu_model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     torch.set_num_threads(cores)
     os.environ["OMP_NUM_THREADS"] = str(cores)
     ang = np.linspace(0, 2 * np.pi, 120).astype(np.float32)
@@ -157,22 +166,29 @@ def cpu_baseline(scans):
     for i in range(len(tir)):
         K.fast_corr(tir[i], tir[(i + 1) % len(tir)])
     t3 = time.perf_counter()
-    out = {"value": len(scans) / (t3 - t0), "unit": "pairs/s", "cores": cores, "kind": "port",
+    out = {"value": len(scans) / (t3 - t0), "unit": "pairs/s", "cores": cores, "nproc": nproc, "cpu_model": cpu_model, "kind": "port",
            "sample": f"{len(scans)} scans x 120k pts: C BEV restatement (1 thread per scan, scans over {cores} threads), "
                      f"C Radon restatement (OpenMP over images), torch-CPU fast_corr ({cores} threads)",
            "ms_per_pair": {"bev": 1e3 * (t1 - t0) / len(scans), "radon": 1e3 * (t2 - t1) / len(scans),
                            "fft_corr": 1e3 * (t3 - t2) / len(scans)}}
     out["gicp"] = cpu_gicp_baseline(cores)
-    if O.ref_polar() is not None:              # the reference's own CPU rasterisers, compiled from its sources
+    # the reference's own CPU rasterisers, compiled from its sources (kind "reference"): one thread, and one scan per thread on every core
+    def ref_rate(fn, label):
+        sample = soas[:128]
         t0 = time.perf_counter()
-        for s in soas[:128]:
-            O.ref_bev_polar(s, 1, 1, 40, 120, 20, 1)
-        out["reference_polar_bev_scans_per_s"] = min(128, len(soas)) / (time.perf_counter() - t0)
+        for s in sample:
+            fn(s)
+        out[f"reference_{label}_bev_scans_per_s"] = len(sample) / (time.perf_counter() - t0)
+        many = (soas * ((4 * nproc + len(soas) - 1) // len(soas)))[:max(4 * nproc, len(sample))]
+        with ThreadPoolExecutor(nproc) as ex:
+            t0 = time.perf_counter()
+            list(ex.map(fn, many))
+            out[f"reference_{label}_bev_scans_per_s_all_cores"] = len(many) / (time.perf_counter() - t0)
+    if O.ref_polar() is not None:
+        ref_rate(lambda s: O.ref_bev_polar(s, 1, 1, 40, 120, 20, 1), "polar")
     if O.ref_lib("cart") is not None:
-        t0 = time.perf_counter()
-        for s in soas[:128]:
-            O.ref_bev_cart(s, 1, 1, 120, 120, 1)
-        out["reference_cart_bev_scans_per_s"] = min(128, len(soas)) / (time.perf_counter() - t0)
+        ref_rate(lambda s: O.ref_bev_cart(s, 1, 1, 120, 120, 1), "cart")
+    out["reference_bev_threads"] = nproc
     return out
 
 

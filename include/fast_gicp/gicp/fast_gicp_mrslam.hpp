@@ -19,6 +19,8 @@
 // definition: mean squared NN distance over d^2 <= max_range).
 #pragma once
 #include <cfloat>
+#include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -30,6 +32,32 @@ namespace fast_gicp {
 
 enum class RegularizationMethod { NONE, MIN_EIG, NORMALIZED_MIN_EIG, PLANE, FROBENIUS };
 enum class NeighborSearchMethod { DIRECT27, DIRECT7, DIRECT1, DIRECT_RADIUS };
+
+namespace detail {
+// One library context per device and process, shared by every registration object (ICPCheck builds a new FastGICP per loop candidate,
+// global_manager.cpp:2016: creating a context there would put a device query on the per-loop path).  Contexts live until the process ends.
+inline mrs_ctx* shared_ctx(int device)
+{
+    static std::mutex mu;
+    static std::map<int, mrs_ctx*> ctxs;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = ctxs.find(device);
+    if (it != ctxs.end()) return it->second;
+    mrs_ctx* c = nullptr;
+    const int st = mrs_ctx_create(device, &c);
+    if (st != MRS_OK) throw std::runtime_error(std::string("mrs_ctx_create: ") + mrs_status_str(st) + ": " + mrs_last_error());
+    ctxs[device] = c;
+    return c;
+}
+// device new registration objects are created on (default 0): fast_gicp::setDevice(i) before constructing them
+inline int& default_device()
+{
+    static int dev = 0;
+    return dev;
+}
+}  // namespace detail
+
+inline void setDevice(int device) { detail::default_device() = device; }
 
 template <typename PointSource, typename PointTarget>
 class FastGICP : public pcl::Registration<PointSource, PointTarget, float> {
@@ -57,14 +85,22 @@ public:
         mrs_gicp_default_params(&prm_);
         this->max_iterations_ = prm_.max_iterations;
         this->transformation_epsilon_ = prm_.transformation_epsilon;
-        check(mrs_ctx_create(0, &ctx_), "mrs_ctx_create");
+        ctx_ = detail::shared_ctx(detail::default_device());
         check(mrs_gicp_batch_create(ctx_, 1, &h_), "mrs_gicp_batch_create");
     }
-    ~FastGICP() override
+    ~FastGICP() override { mrs_gicp_batch_destroy(h_); }
+
+    // moves this object to another GPU of the node (its clouds have to be set again)
+    void setDevice(int device)
     {
+        mrs_ctx* c = detail::shared_ctx(device);
+        if (c == ctx_) return;
         mrs_gicp_batch_destroy(h_);
-        mrs_ctx_destroy(ctx_);
+        h_ = nullptr;
+        ctx_ = c;
+        check(mrs_gicp_batch_create(ctx_, 1, &h_), "mrs_gicp_batch_create");
     }
+    int getDevice() const { return mrs_ctx_device(ctx_); }
     FastGICP(const FastGICP&) = delete;
     FastGICP& operator=(const FastGICP&) = delete;
 

@@ -103,7 +103,15 @@ int main()
         auto finalResult = icp->getFinalTransformation();
         // the GPU score of the derived class (same definition) next to PCL's
         double gpu_fit = -1.0;
-        if (auto g = std::dynamic_pointer_cast<fast_gicp::FastGICP<PointTI, PointTI>>(icp)) gpu_fit = g->getFitnessScore(1.0);
+        if (auto g = std::dynamic_pointer_cast<fast_gicp::FastGICP<PointTI, PointTI>>(icp)) {
+            gpu_fit = g->getFitnessScore(1.0);
+            // one library context per device, shared by every registration object (a new one per loop candidate costs no device query);
+            // setDevice(0) on device 0 keeps the object and its clouds
+            fast_gicp::FastGICP<PointTI, PointTI> other;
+            if (g->getDevice() != 0 || other.getDevice() != 0) all_ok = false;
+            g->setDevice(0);
+            if (std::fabs(g->getFitnessScore(1.0) - gpu_fit) > 0.0) all_ok = false;
+        }
         const double host_fit = icp->getFitnessScore(1.0);
         std::printf("%s converged=%d tx=%.4f ty=%.4f yaw=%.5f fitness(pcl host)=%.6f fitness(gpu)=%.6f aligned=%zu\n", method,
                     (int)icp->hasConverged(), finalResult(0, 3), finalResult(1, 3), std::atan2(finalResult(1, 0), finalResult(0, 0)),

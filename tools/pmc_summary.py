@@ -39,10 +39,12 @@ def valu_cycles(mean):
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
-KEYS = {"k_cart_lds": "k_cart_lds", "k_polar_lds": "k_polar_lds", "k_radon2": "k_radon2", "k_bev_radon2": "k_bev_radon2", "k_ring_spec_corr_pairs": "k_ring_spec_corr_pairs",
-        "k_ring_corr_fft": "k_ring_corr_fft", "k_linearize": "k_linearize", "k_nn_scan": "k_nn_scan", "k_knn_cov": "k_knn_cov"}
+KEYS = {"k_cart_lds": "k_cart_lds", "k_polar_lds": "k_polar_lds", "k_radon2": "k_radon2", "k_bev_radon2": "k_bev_radon2", "k_bev_radon3": "k_bev_radon3",
+        "k_ring_spec_corr_pairs": "k_ring_spec_corr_pairs", "k_ring_corr_fft": "k_ring_corr_fft", "k_linearize": "k_linearize", "k_nn_scan": "k_nn_scan",
+        "k_knn_cov": "k_knn_cov", "k_knn_features": "k_knn_features"}
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in newest(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))):
+files = newest(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))) + sorted(glob.glob(os.path.join(src, "pmc_*.csv")))   # raw passes or slimmed ones
+for f in files:
     for r in csv.DictReader(open(f)):
         m = re.search(r"(k_[a-z_0-9]+)", r["Kernel_Name"])
         if not m or m.group(1) not in KEYS:

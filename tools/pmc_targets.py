@@ -1,6 +1,6 @@
 """Launches the kernels whose hardware counters the bench JSON quotes, at the bench's shapes, a few times each, so that
 `rocprofv3 --pmc <counters> -- python tools/pmc_targets.py` (one pass per counter group, no tracing) sees them.
-tools/pmc_summary.py condenses the CSVs into profiles/r02_pmc.json."""
+tools/pmc_summary.py condenses the CSVs into profiles/<tag>_pmc.json."""
 import os
 import sys
 
@@ -12,16 +12,21 @@ import bench
 from mr_slam_amd import bev, gicp, ring
 
 dev = "cuda:0"
-B = 1024
-(xyz, offs), = bench.make_shard(B, 1, 0, dev)
+B, G = 1024, 16                     # the fused descriptor kernel is profiled at the bench's launch size: 16 x 1024 scans
+shard = bench.make_shard(B, G, 0, dev)
+xyz, offs = shard[0]
 img = torch.empty((B, 1, 120, 120), dtype=torch.float32, device=dev)
 plan = ring.ring_plan(0)
 for _ in range(3):
     bev.cart_bev(xyz, offs, 1, 1, 120, 120, 1, out=img.view(B, -1))
     bev.polar_bev(xyz, offs, 1, 1, 40, 120, 20)
     _, norm = plan.forward(img.view(B, 120, 120), raw=False, normalized=True)
-for _ in range(3):      # the single-launch form of the three kernels above (k_bev_radon2)
-    ring.ring_descriptors_fused(xyz, offs, raw=False, normalized=True)
+whole = bench.make_shard.whole
+goffs = torch.arange(G * B + 1, dtype=torch.int64, device=dev) * bench.N_POINTS
+gout = torch.empty((G * B, 120, 120), dtype=torch.float32, device=dev)
+for _ in range(3):      # the single-launch form of the three kernels above (k_bev_radon3 / k_bev_radon2), 16 384 scans per launch
+    ring.ring_descriptors_fused(whole.view(-1), goffs, raw=False, normalized=True, out_norm=gout)
+del gout
 spec = ring.half_spectrum(norm)
 db = spec[torch.arange(10000, device=dev) % B].contiguous()
 for nq in (1, 4):
@@ -35,5 +40,8 @@ g = gicp.GicpBatch(16, 0)
 g.set_params(k_correspondences=15, max_correspondence_distance=5.0, force_iterations=3)
 g.set_sources(srcs); g.set_targets(tgts)
 g.align()
+from mr_slam_amd import pointfeat
+pts = whole[0, :8].permute(0, 2, 1).reshape(8 * bench.N_POINTS, 3).contiguous()
+pointfeat.point_features(pts, np.arange(9, dtype=np.int64) * bench.N_POINTS, 30, want=("planes",))      # k_knn_features (RING++ front end)
 torch.cuda.synchronize()
 print("pmc targets done")

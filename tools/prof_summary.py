@@ -20,7 +20,7 @@ def newest(paths):
             by_dir[d] = f
     return sorted(by_dir.values())
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
@@ -33,7 +33,7 @@ def short(name):
 
 
 rows = []
-for f in newest(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))):
+for f in newest(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))) + glob.glob(os.path.join(src, "kernel_stats.csv")):
     for r in csv.DictReader(open(f)):
         rows.append((short(r["Name"]), int(r["Calls"]), float(r["TotalDurationNs"]), float(r["AverageNs"]),
                      float(r["MinNs"]), float(r["MaxNs"]), float(r["Percentage"])))
@@ -45,7 +45,7 @@ with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as o:
 
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 for sub in ("pmc_fetch", "pmc_write"):
-    for f in newest(glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))):
+    for f in newest(glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))) + glob.glob(os.path.join(src, sub + ".csv")):
         for r in csv.DictReader(open(f)):
             if "k_" in r["Kernel_Name"]:
                 pmc[(short(r["Kernel_Name"]), int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -60,7 +60,7 @@ json.dump(traffic, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), inde
 
 with open(os.path.join(dst, f"{tag}_summary.md"), "w") as o:
     o.write(f"# rocprofv3 summary, round tag `{tag}`\n\n")
-    o.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs` (tools/run_profiles.sh; "
+    o.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs --verify 0` (tools/run_profiles.sh; "
             "1 x MI355X, 48 launches x 1024 scan pairs per step, BEV + Radon + normalisation of 16 launches per fused kernel call, GICP leg 256 pairs x 120k: 5 cold + 20 forced iterations + a run to convergence).\n"
             "PMC passes (separate runs over tools/pmc_targets.py, `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, no tracing; more counters in " + tag + "_pmc.md).\n\n")
     o.write("| kernel | calls | avg us | min us | max us | % of GPU time |\n|---|---|---|---|---|---|\n")
