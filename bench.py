@@ -187,7 +187,13 @@ def cpu_baseline(scans):
     if O.ref_polar() is not None:
         ref_rate(lambda s: O.ref_bev_polar(s, 1, 1, 40, 120, 20, 1), "polar")
     if O.ref_lib("cart") is not None:
-        ref_rate(lambda s: O.ref_bev_cart(s, 1, 1, 120, 120, 1), "cart")
+        # one thread only: the host build of the reference's CUDA rasteriser goes through a cudaMalloc / cudaMemcpy stand-in with process-wide
+        # state (oracle/ref_cuda_host), which serialises and thrashes under threads (39 scans/s on 256 threads against 785 on one)
+        sample = soas[:128]
+        t0 = time.perf_counter()
+        for s in sample:
+            O.ref_bev_cart(s, 1, 1, 120, 120, 1)
+        out["reference_cart_bev_scans_per_s"] = len(sample) / (time.perf_counter() - t0)
     out["reference_bev_threads"] = nproc
     return out
 
@@ -866,10 +872,14 @@ def main():
         if FUSE:
             # one kernel with an HBM-bound half (rasteriser) and a VALU-bound half (Radon march) per workgroup, overlapped across
             # compute units: its time is bounded below by max(HBM time of the points, VALU time of the rays), not by either alone
-            r = pmc.get("k_bev_radon2", {})
+            r = pmc.get("k_bev_radon3") or pmc.get("k_bev_radon2", {})
+            if r.get("hbm_bytes"):        # the PMC pass profiles the kernel at 16 x 1024 scans per launch: per 1024 scans like everything else here
+                per = (r.get("launch_scans") or 1024) / 1024.0
+                r = dict(r, hbm_bytes=r["hbm_bytes"] / per, valu_pipe_cycles_est=(r.get("valu_pipe_cycles_est") or 0) / per or None,
+                         counters={k: v / per for k, v in (r.get("counters") or {}).items()})
             sa = bev_bytes / (kern_ms["bev_standalone"] * 1e-3) / 1e9
             line["config"]["fused_launches"] = FUSE
-            line["roofline"] = {"kernel": f"k_bev_radon2 (BEV scatter + Radon + normalise, {FUSE} x {B} scans per launch)", "bound": "hbm",
+            line["roofline"] = {"kernel": f"k_bev_radon3 (BEV scatter + Radon + normalise, {FUSE} x {B} scans per launch)", "bound": "hbm",
                                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                 "traffic": r.get("hbm_bytes"), "algorithmic_bytes_per_launch": bev_bytes,
                                 "traffic_source": PMC_NAME if r else None,

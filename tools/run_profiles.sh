@@ -8,10 +8,12 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+if [ -z "$PMC_ONLY" ]; then
 (cd $R && python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs --verify 0 > $OUT/stats.log 2>&1
 for f in $(find $OUT/stats -name '*kernel_stats.csv'); do cp $f $OUT/kernel_stats.csv; done; rm -rf $OUT/stats
-slim() { d=$1; for f in $(find $d -name '*counter_collection.csv'); do (head -1 $f; grep -E '"k_[a-z_0-9]+' $f) > $d.csv; done; rm -rf $d; }
+fi
+slim() { d=$1; for f in $(find $d -name '*counter_collection.csv'); do (head -1 $f; grep -E 'k_[a-z_0-9]+[<(]' $f) > $d.csv; done; rm -rf $d; }
 pass() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$name -- python $R/tools/pmc_targets.py > $OUT/pmc_$name.log 2>&1; slim $OUT/pmc_$name; }
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
