@@ -420,28 +420,41 @@ def build_legs(device, chunks):
         q[:, 0] = c * p[:, 0] - sn * p[:, 1]; q[:, 1] = sn * p[:, 0] + c * p[:, 1]; q[:, 2] = p[:, 2]; q[:, 3] = 0.5
         raws.append(torch.from_numpy(q).to(device))
 
-    def ingest(timing=None):
+    raw_cat = torch.cat(raws)
+    raw_offs = np.concatenate([[0], np.cumsum([r.shape[0] for r in raws])]).astype(np.int64)
+
+    def ingest(batched, timing=None):
         t = [time.perf_counter()]
-        down = [preprocess.voxel_down_sample(r, 0.2) for r in raws]                 # float64 [m, 3] each (the node's open3d call)
+        if batched:                    # one set of launches for the whole batch (hash grid), centroids stay on the device with their offsets
+            cat, doffs = preprocess.voxel_down_sample_batch(raw_cat, raw_offs, 0.2)
+            ro = doffs.cpu().numpy()
+        else:                          # one call and one host synchronisation per scan, like the node's open3d call
+            down = [preprocess.voxel_down_sample(r, 0.2) for r in raws]
+            cat = torch.cat(down)
+            ro = np.concatenate([[0], np.cumsum([d.shape[0] for d in down])]).astype(np.int64)
         torch.cuda.synchronize(); t.append(time.perf_counter())
-        cat = torch.cat(down)
-        ro = np.concatenate([[0], np.cumsum([d.shape[0] for d in down])]).astype(np.int64)
         soa, so = preprocess.load_pc_infer_batch(cat, ro)
         torch.cuda.synchronize(); t.append(time.perf_counter())
         ring.ring_descriptors_fused(soa, so, raw=False, normalized=True)
         torch.cuda.synchronize(); t.append(time.perf_counter())
         if timing is not None:
             timing.append((t[1] - t[0], t[2] - t[1], t[3] - t[2], int(ro[-1])))
-    ingest()
-    tm = []
-    for _ in range(3):
-        ingest(tm)
-    v, c, f, kept = [float(np.mean([x[i] for x in tm])) for i in range(4)]
-    out["ingest"] = {"scans_per_s": R / (v + c + f), "batch": R, "raw_points_per_scan": 130_000, "points_after_voxel_0.2": kept / R,
-                     "ms": {"voxel_down_sample_per_scan": 1e3 * v / R, "crop_scale_batch": 1e3 * c, "fused_descriptors": 1e3 * f},
-                     "note": "raw float32 [n, 4] clouds resident in HBM -> open3d-equivalent voxel grid (sort-based, deterministic, one call and one host "
-                             "synchronisation per scan like the ROS callback) -> load_pc_infer -> BEV + Radon + normalise; reported next to `value`, "
-                             "never instead of it"}
+    res = {}
+    for batched in (True, False):
+        ingest(batched)
+        tm = []
+        for _ in range(3):
+            ingest(batched, tm)
+        v, c, f, kept = [float(np.mean([x[i] for x in tm])) for i in range(4)]
+        res[batched] = {"scans_per_s": R / (v + c + f), "ms": {"voxel_down_sample_per_scan": 1e3 * v / R, "crop_scale_batch": 1e3 * c, "fused_descriptors": 1e3 * f},
+                        "points_after_voxel_0.2": kept / R}
+    out["ingest"] = {"scans_per_s": res[True]["scans_per_s"], "batch": R, "raw_points_per_scan": 130_000,
+                     "points_after_voxel_0.2": res[True]["points_after_voxel_0.2"], "ms": res[True]["ms"],
+                     "per_scan_calls": res[False],
+                     "note": "raw float32 [n, 4] clouds resident in HBM -> open3d-equivalent voxel grid 0.2 m (mrs_voxel_downsample_batch: hash grid, "
+                             "fixed-point sums, one host synchronisation per batch; `per_scan_calls`: the sort-based single-scan call with one host "
+                             "synchronisation per scan, the ROS callback's shape) -> load_pc_infer -> BEV + Radon + normalise; reported next to "
+                             "`value`, never instead of it"}
     return out
 
 
@@ -544,7 +557,8 @@ def main():
                     "the per-launch query goes through a sharded top-k sweep; allgather: fp16 replicas of every new descriptor to every rank "
                     "(north_star's wording) + owner re-scoring")
     ap.add_argument("--fused-grid", choices=("auto", "persistent", "per_pair"), default="auto", help="workgroups of the fused descriptor kernel: persistent (one "
-                    "per compute unit) or one per pair of scans; auto = persistent at N = 1, per_pair at N > 1 (lets RCCL's kernels in)")
+                    "per compute unit) or one per pair of scans; auto = per_pair only with --exchange allgather at N > 1 (lets RCCL's kernels in "
+                    "while the descriptor kernel runs), persistent otherwise")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -627,7 +641,10 @@ def main():
     setup_s = time.perf_counter() - t_setup
 
     ev = {k: [] for k in ("bev", "radon", "bev_radon", "corr", "sweep", "wait")}
-    fused_grid = args.fused_grid if args.fused_grid != "auto" else ("per_pair" if dist_on else "persistent")
+    # auto: persistent workgroups unless the exchange needs RCCL's kernels to run WHILE the descriptor kernel does.  allgather issues a group's
+    # exchanges in a burst that hides behind the next group's descriptor kernel (persistent workgroups would keep RCCL out until the launch
+    # ends); fetch moves its rows between the small per-launch kernels, 4 launches ahead, so nothing waits behind the descriptor kernel
+    fused_grid = args.fused_grid if args.fused_grid != "auto" else ("per_pair" if EXCH == "allgather" else "persistent")
 
     def set_fused_grid(mode):
         # per_pair: one workgroup per pair of scans instead of persistent ones.  A persistent workgroup holds its compute unit's whole

@@ -434,6 +434,14 @@ int mrs_ring_corr_fft_sweep_f16(mrs_ctx* ctx, const float* d_query_spec, int32_t
 int mrs_voxel_downsample(mrs_ctx* ctx, const void* d_points, int32_t is_double, int32_t stride, int32_t n,
                          double voxel_size, double* d_out, int32_t* h_count, mrs_stream stream);
 
+/* The same filter for a batch of scans in one set of launches (hash grid instead of a sort, one host synchronisation per call instead of per
+ * scan): d_points [total][stride], d_raw_offsets / h_raw_offsets int64[batch + 1] (device and host copies of the same offsets, starting at 0).
+ * d_out double[<= total][3] receives the centroids scan after scan, each scan's voxels in order of FIRST OCCURRENCE (open3d's own order is
+ * unspecified), d_out_offsets int64[batch + 1] (device) their extents.  Centroids are within 1e-13 m of mrs_voxel_downsample's. */
+int mrs_voxel_downsample_batch(mrs_ctx* ctx, const void* d_points, int32_t is_double, int32_t stride, const int64_t* d_raw_offsets,
+                               const int64_t* h_raw_offsets, int32_t batch, double voxel_size, double* d_out, int64_t* d_out_offsets,
+                               mrs_stream stream);
+
 /* G1: pygicp.downsample(points, resolution) (RING_ros/main_RING.py:84-85, disco_ros/main.py:177-178, main_SC.py:111-112)
  * = pcl::ApproximateVoxelGrid<pcl::PointXYZ> with leaf (r, r, r): points narrowed to float, a 512-entry direct-mapped
  * history streamed in input order (a voxel evicted by a colliding one and met again yields another output point),

@@ -1517,7 +1517,8 @@ void launch_nn_scan(int longest_src, int n_pairs, int num_cu, hipStream_t s, Arg
 {
     const int cus = num_cu > 0 ? num_cu : 256;
     auto wgs = [&](int P) { return (long)n_pairs * ((longest_src + kNNThreads * P - 1) / (kNNThreads * P)); };
-    if (wgs(2) >= 3L * cus)
+    static const int force_p = getenv("MRS_NN_P") ? atoi(getenv("MRS_NN_P")) : 0;     // development aid: 1 or 2 source points per lane
+    if (force_p == 2 || (force_p != 1 && wgs(2) >= 3L * cus))
         hipLaunchKernelGGL(k_nn_scan<2>, dim3((unsigned)(wgs(2) / n_pairs), n_pairs), dim3(kNNThreads), 0, s, args...);
     else
         hipLaunchKernelGGL(k_nn_scan<1>, dim3((unsigned)(wgs(1) / n_pairs), n_pairs), dim3(kNNThreads), 0, s, args...);

@@ -22,6 +22,24 @@ def voxel_down_sample(points, voxel_size):
     return out[: cnt.value]
 
 
+def voxel_down_sample_batch(points, raw_offsets, voxel_size):
+    """voxel_down_sample for a batch of clouds in one set of launches (hash grid; each scan's voxels in order of first occurrence).
+    points: device tensor [N, s>=3] float32/float64, raw_offsets: host int64 [B+1] starting at 0.
+    Returns (centroids float64 device [M,3], offsets int64 device [B+1])."""
+    assert points.is_cuda and points.dtype in (torch.float32, torch.float64)
+    d = points.device.index or 0
+    p = points.contiguous()
+    h_off = np.ascontiguousarray(raw_offsets, dtype=np.int64)
+    d_off = torch.from_numpy(h_off).to(p.device)
+    B = h_off.size - 1
+    out = torch.empty((int(h_off[-1]), 3), dtype=torch.float64, device=p.device)
+    offs = torch.empty(B + 1, dtype=torch.int64, device=p.device)
+    _lib.check(_lib.load().mrs_voxel_downsample_batch(_lib.ctx(d), _lib.ptr(p), int(p.dtype == torch.float64), int(p.shape[1]), _lib.ptr(d_off),
+                                                      _lib.ptr(h_off), B, C.c_double(voxel_size), _lib.ptr(out), _lib.ptr(offs),
+                                                      _lib.current_stream(d)))
+    return out[: int(offs[-1])], offs
+
+
 def approx_voxel_grid(points, leaf_size):
     """pcl::ApproximateVoxelGrid as pygicp.downsample(points, leaf) applies it (main_RING.py:84-85; row G1): points device
     tensor [n, s>=3] float32/float64 -> float64 device tensor [m,3] (float-precision centroids in the filter's flush

@@ -64,12 +64,12 @@ def test_bench_collective_path_on_one_gpu():
     and --exchange allgather (fp16 replicas to every rank + owner re-scoring)."""
     d = _run({"MRS_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"})
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["exchange"] == "fetch" and "all-to-all" in d["config"]["parallelism"]
-    assert d["config"]["fused_grid"] == "per_pair" and set(d["roofline"]["fused_grid_ms_per_launch"]) == {"per_pair", "persistent"}
+    assert d["config"]["fused_grid"] == "persistent" and set(d["roofline"]["fused_grid_ms_per_launch"]) == {"per_pair", "persistent"}
     x = d["exchange"]
     assert x["design"] == "fetch" and x["fetch"]["rows_bytes_in_per_rank_per_launch"] == 0 and x["compute_stream_wait_ms_per_launch"] >= 0
     assert x["rescore"] is None and x["designs"]["sharded_topk_ms"] > 0 and x["fetch"]["launches_ahead"] >= 1
     d = _run({"MRS_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29534"}, ("--exchange", "allgather", "--no-extra-legs"))
-    assert d["config"]["exchange"] == "allgather" and "all-gather" in d["config"]["parallelism"]
+    assert d["config"]["exchange"] == "allgather" and "all-gather" in d["config"]["parallelism"] and d["config"]["fused_grid"] == "per_pair"
     x = d["exchange"]
     assert x["allgather"]["bytes_in_per_rank_per_launch"] == 0 and x["compute_stream_wait_ms_per_launch"] >= 0      # world size 1: nothing inbound
     assert x["rescore"]["calls"] == 4 and x["rescore"]["rounds"] >= 4 and x["designs"]["sharded_topk_ms"] > 0

@@ -49,6 +49,42 @@ def test_voxel_down_sample(dev, dtype):
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_voxel_down_sample_batch_is_the_per_scan_filter(dev, dtype):
+    """mrs_voxel_downsample_batch (hash grid, fixed-point sums, first-occurrence order) == the numpy restatement of open3d's filter per scan:
+    the same voxels, centroids within 1e-12 m; an empty scan inside the batch; run to run the same bits in the same order."""
+    import torch
+    from mr_slam_amd import preprocess, synth
+    rng = np.random.default_rng(11)
+    scans = [synth.lidar_scan(60, 40000, metric=True), np.zeros((0, 3), np.float32), synth.lidar_scan(61, 25000, metric=True) * 1.7,
+             rng.uniform(-3, 3, (5000, 3)).astype(np.float32), np.repeat(rng.normal(size=(7, 3)), 300, axis=0).astype(np.float32)]
+    pts = np.concatenate([np.concatenate([s, np.full((s.shape[0], 1), 0.5, s.dtype)], 1) for s in scans]).astype(dtype)   # [N, 4]: x, y, z, intensity
+    offs = np.concatenate([[0], np.cumsum([s.shape[0] for s in scans])]).astype(np.int64)
+    t = torch.from_numpy(pts).to(dev)
+    out, o = preprocess.voxel_down_sample_batch(t, offs, 0.2)
+    out2, o2 = preprocess.voxel_down_sample_batch(t, offs, 0.2)
+    assert torch.equal(out, out2) and torch.equal(o, o2)
+    o = o.cpu().numpy()
+    assert o[0] == 0 and (np.diff(o) >= 0).all()
+    out = out.cpu().numpy()
+    for b, sc in enumerate(scans):
+        got = out[o[b]:o[b + 1]]
+        if sc.shape[0] == 0:
+            assert got.shape[0] == 0
+            continue
+        want = _np_voxel_down_sample(pts[offs[b]:offs[b + 1], :3], 0.2)
+        assert got.shape == want.shape, (b, got.shape, want.shape)
+        gs = got[np.lexsort((got[:, 2], got[:, 1], got[:, 0]))]
+        ws = want[np.lexsort((want[:, 2], want[:, 1], want[:, 0]))]
+        np.testing.assert_allclose(gs, ws, rtol=0, atol=1e-12)
+        # first-occurrence order: the first output voxel holds the scan's first point
+        p0 = pts[offs[b], :3].astype(np.float64)
+        assert np.abs(got[0] - p0).max() <= 0.2 + 1e-9
+    single = preprocess.voxel_down_sample(t[offs[0]:offs[1]], 0.2).cpu().numpy()            # the sort-based single-scan call: same set
+    g0 = out[o[0]:o[1]]
+    np.testing.assert_allclose(g0[np.lexsort((g0[:, 2], g0[:, 1], g0[:, 0]))], single[np.lexsort((single[:, 2], single[:, 1], single[:, 0]))], rtol=0, atol=1e-12)
+
+
 def test_load_pc_infer_batch_feeds_bev(dev, oracle):
     import torch
     from mr_slam_amd import bev, preprocess, synth
