@@ -211,11 +211,6 @@ __global__ __launch_bounds__(kRadonWG) void k_bev_radon2(const float* __restrict
 // ray is marched) and the raw sums go to the output buffer instead of 30 registers: the normalisation re-reads them after a barrier in the
 // library-wide lane <-> ray order (threadIdx.x + k * 1024), so every reduction runs in the order of normalize_store / k_normalize and the
 // bits do not change.  The registers this frees pay for deeper point prefetch in the rasteriser stage (PF quads x 2 stages per lane).
-struct SlotP {
-    const int4* slot;
-    const float* nrm;
-    const int* ray;
-};
 
 template <int MAX_RAYS_PER_LANE, int STRIDE, int PF>
 __global__ __launch_bounds__(kRadonWG) void k_bev_radon3(const float* __restrict__ xyz, const int64_t* __restrict__ offs, CartP cp, RadonP p, SlotP sp,

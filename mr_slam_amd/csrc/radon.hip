@@ -540,7 +540,9 @@ int mrs_radon_forward(mrs_radon_plan* plan, const float* d_img, int32_t batch, f
         hipLaunchKernelGGL(kern, dim3(per_lane, batch), dim3(kRadonWG), lds, s, d_img, p, raw);
         if (d_sino_norm) hipLaunchKernelGGL(k_normalize, dim3(batch), dim3(1024), 0, s, raw, d_sino_norm, rays, plan->d_degenerate);
     } else if (per_lane <= 16 && plan->two_in_lds && batch > 1) {
-        // two images per workgroup share the per-sample index arithmetic (march2)
+        // two images per workgroup share the per-sample index arithmetic (march2).  The slot tables of the fused descriptor kernel (rays dealt
+        // to lanes by length, rolled ray loop, sums parked in the output) were tried here too: same bits, +13 % time (0.298 vs 0.262 ms per 1024
+        // images) -- stand-alone, without the rasteriser's register pressure, the unrolled loop with its hoisted table loads wins
         auto kern = per_lane <= 15 ? (p.stride == 125 ? k_radon2<15, 125> : k_radon2<15, 0>) : k_radon2<16, 0>;
         if (2 * lds > 48 * 1024)
             MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

@@ -42,6 +42,13 @@ struct RadonP {
     const float* nrm;   // length of one step
 };
 
+// slot tables of the two-image kernels (mrs_radon_plan::d_slot ...): lane slot s = k * 1024 + lane marches ray ray[s] (-1: idle)
+struct SlotP {
+    const int4* slot;
+    const float* nrm;
+    const int* ray;
+};
+
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(3))) char* lds_cptr;
 
