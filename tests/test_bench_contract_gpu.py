@@ -41,7 +41,10 @@ def test_bench_line_contract():
         assert leg in d, leg
     assert d["roofline_polar"]["bound"] == "hbm" and d["sweeps"]["ring_q1"]["pairs_per_s"] > 0 and d["sweeps"]["disco_q4"]["queries_per_s"] > 0
     # default step: BEV + Radon + normalisation of a group of launches in one kernel; the rasteriser's own roofline rides along
-    assert d["config"]["fused_launches"] == 3 and "k_bev_radon2" in r["kernel"] and d["kernel_ms"]["bev_radon"] > 0
+    assert d["config"]["fused_launches"] == 3 and "k_bev_radon3" in r["kernel"] and d["kernel_ms"]["bev_radon"] > 0
+    assert set(r["fused_grid_ms_per_launch"]) == {"persistent", "per_pair"} and r["valu_roofline"] is None or r["valu_roofline"]["floor_ms_bounds"][0] > 0
+    b3 = d["builds"]
+    assert b3["disco_build"]["scans_per_s"] > 0 and b3["ringpp_build"]["scans_per_s"] > 0 and b3["ingest"]["scans_per_s"] > b3["ingest"]["per_scan_calls"]["scans_per_s"] * 0.5
     # --verify (default 8): outputs of the timed loop's last fused launch against the oracle, after the timed region
     v = d["verify"]
     assert v["ok"] and v["checked"] == 8 and v["bev_mismatches"] == 0 and v["sinogram_mismatches"] == 0 and v["angle_mismatches"] == 0, v
