@@ -412,8 +412,9 @@ def build_legs(device, chunks):
     # ingest: raw clouds as the ROS message delivers them (x, y, z, intensity), ~130 k points before down-sampling
     R = min(64, B)
     raws = []
+    base_raw = [synth.lidar_scan(900 + s, 130_000, metric=True) for s in range(4)]       # 4 ray-cast scenes, every scan a rotated copy
     for i in range(R):
-        p = synth.lidar_scan(900 + i % 4, 130_000, metric=True)
+        p = base_raw[i % 4]
         th = 0.1 * i
         c, sn = np.float32(np.cos(th)), np.float32(np.sin(th))
         q = np.empty((p.shape[0], 4), np.float32)

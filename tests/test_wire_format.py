@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 sys.path.insert(0, os.path.join(HERE, "golden"))
 import ref_import  # noqa: E402
 
@@ -50,3 +51,40 @@ def test_bench_valu_roofline_helper():
     v = bench.valu_roofline(e, 0.405)
     assert abs(v["floor_ms"] - 3.0 * n / (1024 * 2.4e9) * 1e3) < 1e-12 and abs(v["mean_cycles_per_inst"] - 3.0) < 1e-12 and 0.5 < v["frac"] < 0.7
     assert bench.valu_roofline({}, 0.4) is None and bench.valu_roofline(None, 0.4) is None and bench.valu_roofline(e, 0.0) is None
+
+
+def test_reference_python_staging_for_the_gpu_box():
+    """tools/stage_reference_py.py: the five reference Python files the GPU-box test executes through the drop-in are copied into the git-ignored
+    scratch directory tests/_refpy/ (same relative layout), and tests/golden/ref_import.py falls back to it where /root/reference is absent."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import stage_reference_py as S
+    assert "tests/_refpy/" in open(os.path.join(ROOT, ".gitignore")).read().split()
+    assert not any(l.strip().startswith("tests/_refpy") for l in open(os.path.join(ROOT, ".gpurunignore")).read().splitlines()) \
+        if os.path.exists(os.path.join(ROOT, ".gpurunignore")) else True
+    if not os.path.isdir(os.path.join(S.REF, "LoopDetection")):
+        pytest.skip("reference tree not present")
+    assert S.stage(quiet=True)
+    for f in S.FILES:
+        staged = os.path.join(ROOT, "tests", "_refpy", f)
+        assert os.path.isfile(staged) and open(staged, "rb").read() == open(os.path.join(S.REF, f), "rb").read()
+
+
+def test_committed_pmc_summary_prices_instructions_by_class():
+    """profiles/r03_pmc.json: the VALU-pipe estimate of every profiled kernel lies between the all-2-cycle and the all-4-cycle bounds and the fused
+    descriptor kernel carries the launch size it was profiled at (bench.py scales its counters to 1024 scans)."""
+    import json
+    import os
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc.json")))
+    assert pmc["k_bev_radon3"]["launch_scans"] == 16384
+    seen = 0
+    for k, e in pmc.items():
+        n = e["counters"].get("SQ_INSTS_VALU")
+        if not n or not e.get("valu_pipe_cycles_est"):
+            continue
+        seen += 1
+        assert 2.0 * n <= e["valu_pipe_cycles_est"] <= 4.0 * n + 1e-6, k
+        lo, hi = e["valu_busy_frac_bounds"]
+        assert lo <= e["valu_issue_frac"] <= hi + 1e-9
+    assert seen >= 8
