@@ -596,7 +596,7 @@ __device__ __forceinline__ void knn_two_pass(int* __restrict__ list, const float
                    ++c_g2;
 #pragma unroll
                    for (int u = 0; u < 8; ++u)
-                       if (dd[u] <= tau && cnt < CAP) {
+                       if (dd[u] <= tau && dd[u] < INFINITY && cnt < CAP) {     // tau is +inf for a cloud with fewer than k points: padding stays out
                            list[cnt * kNNThreads + (int)threadIdx.x] = j0 + u;
                            ++cnt;
                        }

@@ -247,6 +247,13 @@ def test_degenerate_clouds_terminate_with_finite_results(dev):
         assert f >= 0 and not np.isnan(f), i
         if i == 5:
             assert not conv[0] and f > 1e300
+    # fewer points than k: every point's neighbour list is exactly the cloud (itself first), padded with -1 -- nothing from beyond the cloud
+    tiny = rng.normal(size=(5, 3)).astype(np.float32)
+    b = gicp.GicpBatch(2)
+    b.set_params(k_correspondences=15)
+    b.set_sources([tiny, rng.normal(size=(700, 3)).astype(np.float32)])
+    knn = b.compute_covariances(0, want_knn=True).cpu().numpy()[:5]
+    assert (knn[:, 0] == np.arange(5)).all() and (np.sort(knn[:, :5], 1) == np.arange(5)).all() and (knn[:, 5:] == -1).all()
 
 
 def test_cloud_beyond_the_ordered_tile_window(dev, oracle):
