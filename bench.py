@@ -322,15 +322,17 @@ def gicp_leg(device_index, rank, n_pairs, iters):
             "natural": {"pairs_per_s": n_pairs / t_nat, "align_s": t_nat, "converged": int(conv.sum()),
                         "mean_iterations": float(np.mean(its_n)), "max_iterations": int(np.max(its_n)), "nn_passes": nn_n,
                         "iters_per_s": float(np.sum(its_n)) / t_nat},
-            "nn_search": "exact brute force over Morton-ordered LDS tiles with conservative bounding-box culling; one NN pass per "
-                         "outer iteration, LM trials score the cached correspondences (upstream compute_error)",
+            "nn_search": "exact brute force over the Morton-ordered cloud: a wave walks a two-level box hierarchy in global memory (1024-point tiles, "
+                         "16-point minis) on its own, candidates arrive as scalar loads, conservative culling; one NN pass per outer iteration, "
+                         "LM trials score the cached correspondences (upstream compute_error)",
+            "pairs_per_s_incl_covariances": n_pairs / (t_nat + t_cov),
             "covariance_s": t_cov, "covariance_clouds_per_s": 2 * n_pairs / t_cov, "k": 15,
             "max_correspondence_distance": 5.0,
             "bound": {"k_linearize": "HBM: 132 B per source point and pass (16 B point + 48 B covariance + 4 B index + gathered "
                                      "16 + 48 B); an LM trial re-reads the same bytes (Mahalanobis matrices are recomputed, not stored)",
-                      "k_knn_cov": "VALU: exact k-NN by culled brute force, sorted insertion into k register slots per candidate "
-                                   "that beats the current k-th distance; no HBM or MFMA bound applies (inputs are L2/LDS resident)",
-                      "k_nn_scan": "VALU: ~7 lane-ops per surviving (source, target) candidate after three levels of box culling"}}
+                      "k_knn_cov": "VALU: exact k-NN by culled brute force in two passes (the 16 smallest distances by a v_med3_f32 chain, then the "
+                                   "indices within the k-th distance); no HBM or MFMA bound applies (inputs are L2 resident)",
+                      "k_nn_scan": "VALU: ~7 lane-ops per surviving (source, target) candidate, ~1000 candidate evaluations per wave of 128 queries"}}
 
 
 # ---------------------------------------------------------------------------------------------------- sweep legs
