@@ -559,6 +559,12 @@ def main():
                     "fetch (default): the database stays sharded, a pre-planned all-to-all brings exactly the candidate rows asked for (exact fp32) and "
                     "the per-launch query goes through a sharded top-k sweep; allgather: fp16 replicas of every new descriptor to every rank "
                     "(north_star's wording) + owner re-scoring")
+    ap.add_argument("--corr-group", type=int, choices=(0, 1), default=1, help="N = 1 with --fuse: the half-spectrum + pair-correlation kernel of a "
+                    "group's launches in ONE launch right after the group's descriptor kernel (same pairs, same databases: a launch only reads "
+                    "entries that are at least one group old), like the descriptor kernel itself; 0 = one launch per 1024 pairs")
+    ap.add_argument("--sweep-stream", choices=("main", "side"), default="side", help="N = 1: the per-launch database sweeps on the compute stream, or on "
+                    "a second HIP stream so that they fill the tail of the next descriptor kernel (N > 1 with --exchange fetch always uses the "
+                    "side stream); joined before the step ends")
     ap.add_argument("--fused-grid", choices=("auto", "persistent", "per_pair"), default="auto", help="workgroups of the fused descriptor kernel: persistent (one "
                     "per compute unit) or one per pair of scans; auto = per_pair only with --exchange allgather at N > 1 (lets RCCL's kernels in "
                     "while the descriptor kernel runs), persistent otherwise")
@@ -638,6 +644,15 @@ def main():
         q_all = [torch.empty((world, 61, 120, 2), dtype=torch.float32, device=device) for _ in range(2)]
         sweep_pending = []                             # (launch, work of the query all-gather, event after the launch's kernels)
         last_fetched = [None]
+    GROUP_CORR = bool(FUSE and EXCH is None and args.corr_group)
+    SIDE_SWEEP = EXCH is None and args.sweep_stream == "side"
+    if GROUP_CORR:
+        # candidate rows of every launch as rows of ALL database slots laid end to end (slot s = rows [s * B, (s + 1) * B))
+        spec_flat = spec32.view(-1, 61, 120)
+        slot_of = torch.tensor([db_slot(c) for c in range(CH)], dtype=torch.int32, device=device)
+        flat_cand = (slot_of[:, None] * B + cand_idx).contiguous()
+    if SIDE_SWEEP:
+        side = torch.cuda.Stream(device=device)
     pending = []                                       # (work, source tensor) of the exchanges still in flight, oldest first
     launch_no = [0]
     rescorer = shard.OwnerRescorer(DIST_THRESHOLD, margin=2e-3, slots=64) if EXCH == "allgather" else None
@@ -669,6 +684,22 @@ def main():
         dk, ak, rk = shard.sharded_topk_sweep(qs, spec32[db_slot(c)], ring.corr_sweep_fft, 1, shard_rows=shard_rows, packed=True)
         sweep_val[c] = dk[rank, 0]; sweep_row[c] = rk[rank, 0]
 
+    def issue_side_sweeps(launches, record):
+        """(N = 1) one new query per launch against the database that launch reads, on the side stream: the compute stream goes on with
+        the next descriptor kernel, the sweeps run where compute units are free (the tail of that kernel, between the small kernels)"""
+        ready = torch.cuda.Event(); ready.record()
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            s0 = torch.cuda.Event(enable_timing=True) if record else None
+            if record:
+                s0.record()
+            for cc in launches:
+                d, a = ring.corr_sweep_fft(spec32[cc, :1], spec32[db_slot(cc)])
+                torch.min(d, 1, out=(sweep_val[cc:cc + 1], sweep_row[cc:cc + 1]))
+            if record:
+                s1 = torch.cuda.Event(enable_timing=True); s1.record()
+                ev["sweep"].append((s0, s1, len(launches)))
+
     def step(record):
         def mark():
             e = torch.cuda.Event(enable_timing=True)
@@ -685,6 +716,15 @@ def main():
                                                 out_norm=norm_group[:ng * B])
                     if record:
                         ev["bev_radon"].append((ef0, mark(), ng))
+                    if GROUP_CORR:                 # half spectra (kept: database entries) + correlation with the candidates, all launches of the group
+                        ec0 = mark() if record else None
+                        ring.spectrum_corr_pairs_db(norm_group[:ng * B], spec_flat, flat_cand[c:c + ng].view(-1),
+                                                    out=(out_dist[c:c + ng].view(-1), out_ang[c:c + ng].view(-1)),
+                                                    spec_out=spec32[c:c + ng].view(-1, 61, 120))
+                        if record:
+                            ev["corr"].append((ec0, mark(), ng))
+                        if SIDE_SWEEP:
+                            issue_side_sweeps(range(c, c + ng), record)
                 norm = norm_group[(c % FUSE) * B:(c % FUSE + 1) * B]
                 e0 = e1 = None
                 e2 = mark() if record else None
@@ -717,6 +757,9 @@ def main():
                 last_fetched[0] = rows
                 spec, spec16, _, _ = ring.spectrum_corr_pairs_db(norm, rows, ident_idx, out=(out_dist[c], out_ang[c]), spec_out=spec32[c])
                 db = None
+            elif GROUP_CORR:
+                db = spec32[db_slot(c)]
+                spec = spec32[c]
             else:
                 db = spec32[db_slot(c)]
                 spec, spec16, _, _ = ring.spectrum_corr_pairs_db(norm, db, cand_idx[c], out=(out_dist[c], out_ang[c]), spec_out=spec32[c])
@@ -734,6 +777,9 @@ def main():
                     sweep_pending.append((c, qw))
                     if len(sweep_pending) > 1:
                         run_sharded_sweep(*sweep_pending.pop(0))
+            elif SIDE_SWEEP:
+                if not GROUP_CORR:
+                    issue_side_sweeps((c,), record)
             else:
                 d, a = ring.corr_sweep_fft(spec[:1], db)   # one new query against the whole (replicated) database
                 torch.min(d, 1, out=(sweep_val[c:c + 1], sweep_row[c:c + 1]))
@@ -743,9 +789,14 @@ def main():
             if record:
                 if not FUSE:
                     ev["bev"].append((e0, e1)); ev["radon"].append((e1, e2))
-                ev["corr"].append((e2, e3)); ev["sweep"].append((e3, e4))
+                if not GROUP_CORR:
+                    ev["corr"].append((e2, e3, 1))
+                if not SIDE_SWEEP:
+                    ev["sweep"].append((e3, e4, 1))
                 if dist_on:
                     ev["wait"].append((ew0, ew1))
+        if SIDE_SWEEP:
+            torch.cuda.current_stream().wait_stream(side)      # every sweep of the step is done before the step ends
         if EXCH == "fetch":
             with torch.cuda.stream(side):              # the last launch's sweep; the compute stream joins the side stream at the step's end
                 while sweep_pending:
@@ -771,6 +822,8 @@ def main():
             if EXCH == "fetch":
                 torch.cuda.current_stream().wait_stream(side)
             dist.barrier()
+        if SIDE_SWEEP:
+            torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -786,9 +839,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kern_ms = {k: float(np.mean([t[0].elapsed_time(t[1]) for t in v])) for k, v in ev.items() if v and k != "bev_radon"}
-    if ev["bev_radon"]:       # per launch of B scans, like the other entries
-        kern_ms["bev_radon"] = float(sum(a.elapsed_time(b) for a, b, _ in ev["bev_radon"]) / sum(n for _, _, n in ev["bev_radon"]))
+    # per launch of B scans; entries that cover several launches (descriptor kernel, grouped correlation, a group's sweeps) carry their count.
+    # With --sweep-stream side the sweep figure is stream time on the side stream (it includes waiting for compute units the other stream holds)
+    kern_ms = {k: float(sum(t[0].elapsed_time(t[1]) for t in v) / sum((t[2] if len(t) > 2 else 1) for t in v)) for k, v in ev.items() if v}
 
     extra = {}
     gicp_res = None
@@ -899,6 +952,8 @@ def main():
                          counters={k: v / per for k, v in (r.get("counters") or {}).items()})
             sa = bev_bytes / (kern_ms["bev_standalone"] * 1e-3) / 1e9
             line["config"]["fused_launches"] = FUSE
+            line["config"]["corr_launches_grouped"] = FUSE if GROUP_CORR else 1
+            line["config"]["sweep_stream"] = "side" if (SIDE_SWEEP or EXCH == "fetch") else "main"
             line["roofline"] = {"kernel": f"k_bev_radon3 (BEV scatter + Radon + normalise, {FUSE} x {B} scans per launch)", "bound": "hbm",
                                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                 "traffic": r.get("hbm_bytes"), "algorithmic_bytes_per_launch": bev_bytes,
@@ -970,6 +1025,14 @@ def main():
             last = ((CH - 1) // FUSE) * FUSE
             line["verify"] = verify_timed_outputs(args.verify, make_shard.whole, norm_group[:(CH - last) * B], last, out_dist, out_ang, cand_idx,
                                                   lambda c: c - DEPTH if c >= DEPTH else CH - DEPTH + c)
+            # the per-launch sweeps of the timed loop (possibly issued on the side stream) against fresh ones over the same entries
+            bad = 0
+            for c in np.random.default_rng(1).choice(CH, size=min(args.verify, CH), replace=False):
+                d_f, _ = ring.corr_sweep_fft(spec32[int(c), :1], spec32[db_slot(int(c))])
+                v_f, r_f = torch.min(d_f, 1)
+                bad += int(float(v_f[0]) != float(sweep_val[int(c)]) or int(r_f[0]) != int(sweep_row[int(c)]))
+            line["verify"]["sweep_mismatches"] = bad
+            line["verify"]["ok"] = bool(line["verify"]["ok"] and bad == 0)
         if FUSE and not args.no_extra_legs:
             # the other workgroup shape of the fused kernel on the same scans (N > 1 runs per_pair so that RCCL's kernels get in): measured, not assumed
             other = "per_pair" if fused_grid == "persistent" else "persistent"

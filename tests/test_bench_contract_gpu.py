@@ -49,8 +49,21 @@ def test_bench_line_contract():
     v = d["verify"]
     assert v["ok"] and v["checked"] == 8 and v["bev_mismatches"] == 0 and v["sinogram_mismatches"] == 0 and v["angle_mismatches"] == 0, v
     assert v["timed_vs_fresh_launch_mismatches"] == 0 and v["max_err_dist"] < 1e-5 and v["max_err"] < 2e-5, v
+    # default schedule: the group's correlation in one launch, the per-launch sweeps on the side stream -- checked against fresh sweeps
+    assert d["config"]["corr_launches_grouped"] == 3 and d["config"]["sweep_stream"] == "side" and v["sweep_mismatches"] == 0
+    assert d["kernel_ms"]["corr"] > 0 and d["kernel_ms"]["sweep"] > 0
     b = d["roofline_bev_scatter"]
     assert b["bound"] == "hbm" and "k_cart_lds" in b["kernel"] and abs(b["frac"] - b["achieved"] / b["peak"]) < 1e-12
+
+
+def test_bench_line_per_launch_schedule():
+    """--corr-group 0 --sweep-stream main: one correlation launch per 1024 pairs and the sweeps on the compute stream (the round-2 schedule);
+    the same verification block must hold"""
+    d = _run(extra_args=("--corr-group", "0", "--sweep-stream", "main", "--no-extra-legs", "--no-cpu-baseline", "--gicp-pairs", "0"))
+    assert d["config"]["corr_launches_grouped"] == 1 and d["config"]["sweep_stream"] == "main"
+    v = d["verify"]
+    assert v["ok"] and v["sweep_mismatches"] == 0 and v["angle_mismatches"] == 0 and v["max_err_dist"] < 1e-5, v
+    assert d["kernel_ms"]["corr"] > 0 and d["kernel_ms"]["sweep"] > 0
 
 
 def test_bench_line_two_kernel_step():
