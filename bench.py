@@ -599,7 +599,7 @@ def main():
     plan = ring.ring_plan(local_rank)
     img = torch.empty((B, 1, 120, 120), dtype=torch.float32, device=device)
     # the rank's exact database entries: Hermitian half spectra [61][120] complex64 (58 560 B) of the normalised
-    # sinograms of every resident scan; slots CH, CH + 1 = the entries of the previous step's last two launches.
+    # sinograms of every resident scan; see RING_DB below for where the entries of the previous step live.
     # The database a launch reads is the one built DEPTH launches earlier: its exchange then has DEPTH launches of kernels to
     # hide behind.
     FUSE = max(0, min(args.fuse, CH))
@@ -607,13 +607,20 @@ def main():
     # launch reads is then one group (+ 2 launches) old, so that the burst has the next group's descriptor kernel to hide behind
     DEPTH = min(FUSE + 2, CH) if FUSE else 2
     assert CH >= DEPTH
-    spec32 = torch.empty((CH + DEPTH, B, 61, 120), dtype=torch.complex64, device=device)
+    # N = 1: the CH slots are a ring -- launch c reads slot (c - DEPTH) mod CH, which for the step's first DEPTH launches still holds what the
+    # previous step's last launches wrote (they are rewritten at least a group later in stream order).  N > 1 (and rings shorter than a group)
+    # keep DEPTH extra slots that receive a copy of those entries at the start of every step: the exchanges read them asynchronously
+    RING_DB = (not dist_on) and CH - DEPTH >= max(FUSE, 1)
+    spec32 = torch.empty((CH + (0 if RING_DB else DEPTH), B, 61, 120), dtype=torch.complex64, device=device)
     for c, (xyz, offs) in enumerate(chunks):
         _, _, nrm = ring.ring_descriptors(xyz, offs)
         spec32[c] = ring.half_spectrum(nrm)
-    spec32[CH:] = spec32[CH - DEPTH:CH]
+    if not RING_DB:
+        spec32[CH:] = spec32[CH - DEPTH:CH]
 
     def db_slot(c):
+        if RING_DB:
+            return (c - DEPTH) % CH
         return c - DEPTH if c >= DEPTH else CH + c
     g = torch.Generator(device=device).manual_seed(7 + rank)
     NDB = world * B
@@ -684,6 +691,17 @@ def main():
         dk, ak, rk = shard.sharded_topk_sweep(qs, spec32[db_slot(c)], ring.corr_sweep_fft, 1, shard_rows=shard_rows, packed=True)
         sweep_val[c] = dk[rank, 0]; sweep_row[c] = rk[rank, 0]
 
+    sweep_done = {}                                    # launch -> event on the side stream after the batch of sweeps that contains it
+
+    def wait_readers(s_lo, s_hi):
+        """ring database + side-stream sweeps: slots [s_lo, s_hi) are about to be rewritten on the compute stream; the sweeps of this step's
+        first DEPTH launches read slots CH - DEPTH + c (the previous step's entries) and must be through with them"""
+        if not (SIDE_SWEEP and RING_DB):
+            return
+        c = min(s_hi - 1 - (CH - DEPTH), DEPTH - 1)
+        if c >= 0 and s_lo - (CH - DEPTH) < DEPTH and c in sweep_done:
+            torch.cuda.current_stream().wait_event(sweep_done[c])
+
     def issue_side_sweeps(launches, record):
         """(N = 1) one new query per launch against the database that launch reads, on the side stream: the compute stream goes on with
         the next descriptor kernel, the sweeps run where compute units are free (the tail of that kernel, between the small kernels)"""
@@ -699,13 +717,17 @@ def main():
             if record:
                 s1 = torch.cuda.Event(enable_timing=True); s1.record()
                 ev["sweep"].append((s0, s1, len(launches)))
+            fin = torch.cuda.Event(); fin.record()
+            for cc in launches:
+                sweep_done[cc] = fin
 
     def step(record):
         def mark():
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             return e
-        spec32[CH:] = spec32[CH - DEPTH:CH]            # last launches of the previous step = databases of this step's first
+        if not RING_DB:
+            spec32[CH:] = spec32[CH - DEPTH:CH]        # last launches of the previous step = databases of this step's first
         for c, (xyz, offs) in enumerate(chunks):
             g = launch_no[0]; launch_no[0] += 1
             if FUSE:
@@ -718,6 +740,7 @@ def main():
                         ev["bev_radon"].append((ef0, mark(), ng))
                     if GROUP_CORR:                 # half spectra (kept: database entries) + correlation with the candidates, all launches of the group
                         ec0 = mark() if record else None
+                        wait_readers(c, c + ng)
                         ring.spectrum_corr_pairs_db(norm_group[:ng * B], spec_flat, flat_cand[c:c + ng].view(-1),
                                                     out=(out_dist[c:c + ng].view(-1), out_ang[c:c + ng].view(-1)),
                                                     spec_out=spec32[c:c + ng].view(-1, 61, 120))
@@ -762,6 +785,7 @@ def main():
                 spec = spec32[c]
             else:
                 db = spec32[db_slot(c)]
+                wait_readers(c, c + 1)
                 spec, spec16, _, _ = ring.spectrum_corr_pairs_db(norm, db, cand_idx[c], out=(out_dist[c], out_ang[c]), spec_out=spec32[c])
             e3 = mark() if record else None
             if EXCH == "fetch":
@@ -954,6 +978,7 @@ def main():
             line["config"]["fused_launches"] = FUSE
             line["config"]["corr_launches_grouped"] = FUSE if GROUP_CORR else 1
             line["config"]["sweep_stream"] = "side" if (SIDE_SWEEP or EXCH == "fetch") else "main"
+            line["config"]["database_slots"] = "ring" if RING_DB else "ring + copies of the previous step's last entries"
             line["roofline"] = {"kernel": f"k_bev_radon3 (BEV scatter + Radon + normalise, {FUSE} x {B} scans per launch)", "bound": "hbm",
                                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                 "traffic": r.get("hbm_bytes"), "algorithmic_bytes_per_launch": bev_bytes,
