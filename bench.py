@@ -607,20 +607,28 @@ def main():
     # launch reads is then one group (+ 2 launches) old, so that the burst has the next group's descriptor kernel to hide behind
     DEPTH = min(FUSE + 2, CH) if FUSE else 2
     assert CH >= DEPTH
-    # N = 1: the CH slots are a ring -- launch c reads slot (c - DEPTH) mod CH, which for the step's first DEPTH launches still holds what the
-    # previous step's last launches wrote (they are rewritten at least a group later in stream order).  N > 1 (and rings shorter than a group)
-    # keep DEPTH extra slots that receive a copy of those entries at the start of every step: the exchanges read them asynchronously
-    RING_DB = (not dist_on) and CH - DEPTH >= max(FUSE, 1)
-    spec32 = torch.empty((CH + (0 if RING_DB else DEPTH), B, 61, 120), dtype=torch.complex64, device=device)
+    # N = 1: two sets of CH slots, written alternately (step parity): launch c writes slot c of this step's set and reads the entry built DEPTH
+    # launches earlier -- slot c - DEPTH of the same set or, for the step's first DEPTH launches, slot CH - DEPTH + c of the OTHER set (what the
+    # previous step's last launches wrote).  Nothing is copied and no kernel reads a slot that is rewritten within the same step, whatever
+    # stream it runs on.  N > 1 keeps one set + DEPTH extra slots that receive a copy of the previous step's last entries at the start of every
+    # step (the exchanges read them asynchronously).
+    RING_DB = not dist_on
+    spec32 = torch.empty(((2 * CH) if RING_DB else (CH + DEPTH), B, 61, 120), dtype=torch.complex64, device=device)
     for c, (xyz, offs) in enumerate(chunks):
         _, _, nrm = ring.ring_descriptors(xyz, offs)
         spec32[c] = ring.half_spectrum(nrm)
-    if not RING_DB:
+    if RING_DB:
+        spec32[CH:] = spec32[:CH]
+    else:
         spec32[CH:] = spec32[CH - DEPTH:CH]
+    parity = [0]                                       # the set the current (or, after the loop, the last) step writes
+
+    def wslot(c):
+        return parity[0] * CH + c if RING_DB else c
 
     def db_slot(c):
         if RING_DB:
-            return (c - DEPTH) % CH
+            return parity[0] * CH + c - DEPTH if c >= DEPTH else (1 - parity[0]) * CH + CH - DEPTH + c
         return c - DEPTH if c >= DEPTH else CH + c
     g = torch.Generator(device=device).manual_seed(7 + rank)
     NDB = world * B
@@ -656,8 +664,12 @@ def main():
     if GROUP_CORR:
         # candidate rows of every launch as rows of ALL database slots laid end to end (slot s = rows [s * B, (s + 1) * B))
         spec_flat = spec32.view(-1, 61, 120)
-        slot_of = torch.tensor([db_slot(c) for c in range(CH)], dtype=torch.int32, device=device)
-        flat_cand = (slot_of[:, None] * B + cand_idx).contiguous()
+        flat_cand = []                                 # per step parity
+        for par in (0, 1):
+            parity[0] = par
+            slot_of = torch.tensor([db_slot(c) for c in range(CH)], dtype=torch.int32, device=device)
+            flat_cand.append((slot_of[:, None] * B + cand_idx).contiguous())
+        parity[0] = 0
     if SIDE_SWEEP:
         side = torch.cuda.Stream(device=device)
     pending = []                                       # (work, source tensor) of the exchanges still in flight, oldest first
@@ -691,17 +703,6 @@ def main():
         dk, ak, rk = shard.sharded_topk_sweep(qs, spec32[db_slot(c)], ring.corr_sweep_fft, 1, shard_rows=shard_rows, packed=True)
         sweep_val[c] = dk[rank, 0]; sweep_row[c] = rk[rank, 0]
 
-    sweep_done = {}                                    # launch -> event on the side stream after the batch of sweeps that contains it
-
-    def wait_readers(s_lo, s_hi):
-        """ring database + side-stream sweeps: slots [s_lo, s_hi) are about to be rewritten on the compute stream; the sweeps of this step's
-        first DEPTH launches read slots CH - DEPTH + c (the previous step's entries) and must be through with them"""
-        if not (SIDE_SWEEP and RING_DB):
-            return
-        c = min(s_hi - 1 - (CH - DEPTH), DEPTH - 1)
-        if c >= 0 and s_lo - (CH - DEPTH) < DEPTH and c in sweep_done:
-            torch.cuda.current_stream().wait_event(sweep_done[c])
-
     def issue_side_sweeps(launches, record):
         """(N = 1) one new query per launch against the database that launch reads, on the side stream: the compute stream goes on with
         the next descriptor kernel, the sweeps run where compute units are free (the tail of that kernel, between the small kernels)"""
@@ -712,21 +713,20 @@ def main():
             if record:
                 s0.record()
             for cc in launches:
-                d, a = ring.corr_sweep_fft(spec32[cc, :1], spec32[db_slot(cc)])
+                d, a = ring.corr_sweep_fft(spec32[wslot(cc), :1], spec32[db_slot(cc)])
                 torch.min(d, 1, out=(sweep_val[cc:cc + 1], sweep_row[cc:cc + 1]))
             if record:
                 s1 = torch.cuda.Event(enable_timing=True); s1.record()
                 ev["sweep"].append((s0, s1, len(launches)))
-            fin = torch.cuda.Event(); fin.record()
-            for cc in launches:
-                sweep_done[cc] = fin
 
     def step(record):
         def mark():
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             return e
-        if not RING_DB:
+        if RING_DB:
+            parity[0] ^= 1                             # this step writes the other set of slots
+        else:
             spec32[CH:] = spec32[CH - DEPTH:CH]        # last launches of the previous step = databases of this step's first
         for c, (xyz, offs) in enumerate(chunks):
             g = launch_no[0]; launch_no[0] += 1
@@ -740,10 +740,9 @@ def main():
                         ev["bev_radon"].append((ef0, mark(), ng))
                     if GROUP_CORR:                 # half spectra (kept: database entries) + correlation with the candidates, all launches of the group
                         ec0 = mark() if record else None
-                        wait_readers(c, c + ng)
-                        ring.spectrum_corr_pairs_db(norm_group[:ng * B], spec_flat, flat_cand[c:c + ng].view(-1),
+                        ring.spectrum_corr_pairs_db(norm_group[:ng * B], spec_flat, flat_cand[parity[0] if RING_DB else 0][c:c + ng].view(-1),
                                                     out=(out_dist[c:c + ng].view(-1), out_ang[c:c + ng].view(-1)),
-                                                    spec_out=spec32[c:c + ng].view(-1, 61, 120))
+                                                    spec_out=spec32[wslot(c):wslot(c) + ng].view(-1, 61, 120))
                         if record:
                             ev["corr"].append((ec0, mark(), ng))
                         if SIDE_SWEEP:
@@ -782,11 +781,10 @@ def main():
                 db = None
             elif GROUP_CORR:
                 db = spec32[db_slot(c)]
-                spec = spec32[c]
+                spec = spec32[wslot(c)]
             else:
                 db = spec32[db_slot(c)]
-                wait_readers(c, c + 1)
-                spec, spec16, _, _ = ring.spectrum_corr_pairs_db(norm, db, cand_idx[c], out=(out_dist[c], out_ang[c]), spec_out=spec32[c])
+                spec, spec16, _, _ = ring.spectrum_corr_pairs_db(norm, db, cand_idx[c], out=(out_dist[c], out_ang[c]), spec_out=spec32[wslot(c)])
             e3 = mark() if record else None
             if EXCH == "fetch":
                 # the rows of launch c + FETCH_AHEAD: slot c + FETCH_AHEAD - DEPTH <= c is written on every owner by now
@@ -978,7 +976,7 @@ def main():
             line["config"]["fused_launches"] = FUSE
             line["config"]["corr_launches_grouped"] = FUSE if GROUP_CORR else 1
             line["config"]["sweep_stream"] = "side" if (SIDE_SWEEP or EXCH == "fetch") else "main"
-            line["config"]["database_slots"] = "ring" if RING_DB else "ring + copies of the previous step's last entries"
+            line["config"]["database_slots"] = "two sets, alternating per step" if RING_DB else "one set + copies of the previous step's last entries"
             line["roofline"] = {"kernel": f"k_bev_radon3 (BEV scatter + Radon + normalise, {FUSE} x {B} scans per launch)", "bound": "hbm",
                                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                 "traffic": r.get("hbm_bytes"), "algorithmic_bytes_per_launch": bev_bytes,
@@ -1053,7 +1051,7 @@ def main():
             # the per-launch sweeps of the timed loop (possibly issued on the side stream) against fresh ones over the same entries
             bad = 0
             for c in np.random.default_rng(1).choice(CH, size=min(args.verify, CH), replace=False):
-                d_f, _ = ring.corr_sweep_fft(spec32[int(c), :1], spec32[db_slot(int(c))])
+                d_f, _ = ring.corr_sweep_fft(spec32[wslot(int(c)), :1], spec32[db_slot(int(c))])
                 v_f, r_f = torch.min(d_f, 1)
                 bad += int(float(v_f[0]) != float(sweep_val[int(c)]) or int(r_f[0]) != int(sweep_row[int(c)]))
             line["verify"]["sweep_mismatches"] = bad
