@@ -565,6 +565,9 @@ def main():
     ap.add_argument("--sweep-stream", choices=("main", "side"), default="side", help="N = 1: the per-launch database sweeps on the compute stream, or on "
                     "a second HIP stream so that they fill the tail of the next descriptor kernel (N > 1 with --exchange fetch always uses the "
                     "side stream); joined before the step ends")
+    ap.add_argument("--sweep-join", choices=("step", "lag"), default="lag", help="--sweep-stream side: the compute stream joins the side stream at the "
+                    "end of every step, or (lag) only waits for all but the step's LAST batch of sweeps, which then runs under the next step's "
+                    "first descriptor kernel (it reads only the slot set the next step does not write); everything is joined before the clock stops")
     ap.add_argument("--fused-grid", choices=("auto", "persistent", "per_pair"), default="auto", help="workgroups of the fused descriptor kernel: persistent (one "
                     "per compute unit) or one per pair of scans; auto = per_pair only with --exchange allgather at N > 1 (lets RCCL's kernels in "
                     "while the descriptor kernel runs), persistent otherwise")
@@ -703,6 +706,8 @@ def main():
         dk, ak, rk = shard.sharded_topk_sweep(qs, spec32[db_slot(c)], ring.corr_sweep_fft, 1, shard_rows=shard_rows, packed=True)
         sweep_val[c] = dk[rank, 0]; sweep_row[c] = rk[rank, 0]
 
+    sweep_batches = []                                 # this step's batches of side-stream sweeps: (first launch, event after the batch)
+
     def issue_side_sweeps(launches, record):
         """(N = 1) one new query per launch against the database that launch reads, on the side stream: the compute stream goes on with
         the next descriptor kernel, the sweeps run where compute units are free (the tail of that kernel, between the small kernels)"""
@@ -718,6 +723,8 @@ def main():
             if record:
                 s1 = torch.cuda.Event(enable_timing=True); s1.record()
                 ev["sweep"].append((s0, s1, len(launches)))
+            fin = torch.cuda.Event(); fin.record()
+            sweep_batches.append((launches[0], fin))
 
     def step(record):
         def mark():
@@ -818,7 +825,13 @@ def main():
                 if dist_on:
                     ev["wait"].append((ew0, ew1))
         if SIDE_SWEEP:
-            torch.cuda.current_stream().wait_stream(side)      # every sweep of the step is done before the step ends
+            # lag: the step's last batch of sweeps may still run while the next step starts.  Its launches (>= DEPTH) read only this step's
+            # set of slots, which the next step does not write; the step after that waits (here) for later events of the same stream
+            if args.sweep_join == "lag" and len(sweep_batches) >= 2 and sweep_batches[-1][0] >= DEPTH:
+                torch.cuda.current_stream().wait_event(sweep_batches[-2][1])
+            else:
+                torch.cuda.current_stream().wait_stream(side)  # every sweep of the step is done before the step ends
+            sweep_batches.clear()
         if EXCH == "fetch":
             with torch.cuda.stream(side):              # the last launch's sweep; the compute stream joins the side stream at the step's end
                 while sweep_pending:
@@ -976,6 +989,8 @@ def main():
             line["config"]["fused_launches"] = FUSE
             line["config"]["corr_launches_grouped"] = FUSE if GROUP_CORR else 1
             line["config"]["sweep_stream"] = "side" if (SIDE_SWEEP or EXCH == "fetch") else "main"
+            if SIDE_SWEEP:
+                line["config"]["sweep_join"] = args.sweep_join
             line["config"]["database_slots"] = "two sets, alternating per step" if RING_DB else "one set + copies of the previous step's last entries"
             line["roofline"] = {"kernel": f"k_bev_radon3 (BEV scatter + Radon + normalise, {FUSE} x {B} scans per launch)", "bound": "hbm",
                                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -71,6 +71,7 @@ def test_bench_database_slots_across_steps():
     across the step boundary (two sets of slots written alternately, nothing copied)"""
     d = _run(extra_args=("--chunks", "6", "--fuse", "2", "--no-extra-legs", "--no-cpu-baseline", "--gicp-pairs", "0"))
     assert d["config"]["database_slots"].startswith("two sets") and d["config"]["corr_launches_grouped"] == 2 and d["config"]["launches_per_step"] == 6
+    assert d["config"]["sweep_join"] == "lag"          # three batches of sweeps per step, the last one runs into the next step
     v = d["verify"]
     assert v["ok"] and v["sweep_mismatches"] == 0 and v["angle_mismatches"] == 0 and v["max_err_dist"] < 1e-5, v
 
