@@ -565,6 +565,8 @@ def main():
     ap.add_argument("--sweep-stream", choices=("main", "side"), default="side", help="N = 1: the per-launch database sweeps on the compute stream, or on "
                     "a second HIP stream so that they fill the tail of the next descriptor kernel (N > 1 with --exchange fetch always uses the "
                     "side stream); joined before the step ends")
+    ap.add_argument("--fused-wgs", type=int, default=0, help="persistent workgroups of the descriptor kernel (0 = one per compute unit); fewer leave "
+                    "compute units to the side-stream sweeps while the descriptor kernel runs")
     ap.add_argument("--sweep-join", choices=("step", "lag"), default="lag", help="--sweep-stream side: the compute stream joins the side stream at the "
                     "end of every step, or (lag) only waits for all but the step's LAST batch of sweeps, which then runs under the next step's "
                     "first descriptor kernel (it reads only the slot set the next step does not write); everything is joined before the clock stops")
@@ -690,7 +692,7 @@ def main():
         # per_pair: one workgroup per pair of scans instead of persistent ones.  A persistent workgroup holds its compute unit's whole
         # register file (4 waves x 128 VGPRs per SIMD) until the launch ends, so RCCL's kernels could not start before that;
         # workgroups that retire every ~0.2 ms let the collective's workgroups in between them
-        plan.set_option(plan.OPT_FUSED_GRID, 65535 if mode == "per_pair" else 0)
+        plan.set_option(plan.OPT_FUSED_GRID, 65535 if mode == "per_pair" else max(0, args.fused_wgs))
         plan.set_option(plan.OPT_FUSED_STAGGER_US, 0 if mode == "per_pair" else 70)
     if FUSE:
         set_fused_grid(fused_grid)
@@ -991,6 +993,8 @@ def main():
             line["config"]["sweep_stream"] = "side" if (SIDE_SWEEP or EXCH == "fetch") else "main"
             if SIDE_SWEEP:
                 line["config"]["sweep_join"] = args.sweep_join
+            if args.fused_wgs > 0:
+                line["config"]["fused_persistent_workgroups"] = args.fused_wgs
             line["config"]["database_slots"] = "two sets, alternating per step" if RING_DB else "one set + copies of the previous step's last entries"
             line["roofline"] = {"kernel": f"k_bev_radon3 (BEV scatter + Radon + normalise, {FUSE} x {B} scans per launch)", "bound": "hbm",
                                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
