@@ -253,7 +253,7 @@ int voxel_downsample_impl(mrs_ctx* ctx, const T* d_pts, int stride, int n, doubl
 // voxel's slot (atomicCAS on the key, linear probing), records the smallest point index seen there (atomicMin: the voxel's "head"), counts
 // itself and adds its offset from the voxel's lower corner as 64-bit FIXED-POINT numbers (atomicAdd: integer sums do not depend on the order,
 // so the result is deterministic whichever slot order the probing produced; the offsets are < one voxel, so scale 2^46 / voxel keeps 2^17
-// points per voxel inside 63 bits at a resolution of voxel x 1.4e-14).  Heads are then numbered in point order (prefix sum): the output
+// points per voxel inside 63 bits at a resolution of voxel x 1.4e-14; scans with more points get a coarser scale, see the launch code).  Heads are then numbered in point order (prefix sum): the output
 // lists the voxels of a scan in order of first occurrence, mean = corner + sum / (scale x count) -- within 1e-13 m of the double sums of
 // the sorted form.
 struct VoxSlot {
@@ -373,7 +373,12 @@ int voxel_downsample_batch_impl(mrs_ctx* ctx, const T* d_pts, int stride, const 
         MRS_HIP_TRY(hipMemset2DAsync(reinterpret_cast<char*>(tab.p) + offsetof(VoxSlot, first), sizeof(VoxSlot), 0x7f, 4, (size_t)total * 2, s));
     }
     const dim3 g((unsigned)std::min<int64_t>((longest + 255) / 256, 512), batch);
-    const double scale = ldexp(1.0, 46 - (int)ceil(log2(voxel)));     // offsets < voxel <= 2^ceil(log2 voxel): |offset x scale| < 2^46
+    // offsets < voxel <= 2^ceil(log2 voxel): |offset x scale| < 2^bits, and a voxel holds at most `longest` points: bits = 46 up to 2^17 points per
+    // scan, fewer beyond (a million-point scan: 42 bits = voxel x 2e-13), so that no sum can leave 63 bits whatever the distribution of the points
+    int pbits = 1;
+    while (pbits < 31 && (1ll << pbits) < (long long)longest) ++pbits;
+    const int bits = pbits <= 17 ? 46 : 62 - pbits;
+    const double scale = ldexp(1.0, bits - (int)ceil(log2(voxel)));
     hipLaunchKernelGGL(k_min_bound_batch<T>, g, dim3(256), 0, s, d_pts, stride, d_offs, mn.as<unsigned long long>());
     hipLaunchKernelGGL(k_vox_insert<T>, g, dim3(256), 0, s, d_pts, stride, d_offs, voxel, scale, mn.as<unsigned long long>(), tab.as<VoxSlot>(),
                        slot_of.as<int>(), ovf.as<int>());

@@ -85,6 +85,20 @@ def test_voxel_down_sample_batch_is_the_per_scan_filter(dev, dtype):
     np.testing.assert_allclose(g0[np.lexsort((g0[:, 2], g0[:, 1], g0[:, 0]))], single[np.lexsort((single[:, 2], single[:, 1], single[:, 0]))], rtol=0, atol=1e-12)
 
 
+def test_voxel_down_sample_batch_crowded_voxel(dev):
+    """200 000 copies of one point (0.9 of a voxel from the voxel's lower corner in every axis) + a corner marker: the fixed-point sums of the
+    hash grid must not leave 63 bits (at the 2^46 scale of scans up to 2^17 points they would)"""
+    import torch
+    from mr_slam_amd import preprocess
+    p = np.array([0.18, 0.18, 0.18])
+    pts = np.concatenate([np.full((1, 3), -0.1), np.tile(p, (200000, 1)), np.array([[3.0, 3.0, 3.0]])]).astype(np.float64)
+    out, o = preprocess.voxel_down_sample_batch(torch.from_numpy(pts).to(dev), np.array([0, pts.shape[0]], np.int64), 0.2)
+    out = out.cpu().numpy()
+    want = _np_voxel_down_sample(pts, 0.2)
+    assert out.shape == want.shape == (3, 3)
+    np.testing.assert_allclose(out[np.lexsort((out[:, 2], out[:, 1], out[:, 0]))], want[np.lexsort((want[:, 2], want[:, 1], want[:, 0]))], rtol=0, atol=1e-11)
+
+
 def test_load_pc_infer_batch_feeds_bev(dev, oracle):
     import torch
     from mr_slam_amd import bev, preprocess, synth
