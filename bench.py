@@ -198,6 +198,20 @@ def cpu_baseline(scans):
     return out
 
 
+def write_slot(c, parity, n_launch, two_sets):
+    """database slot launch c of a step writes: slot c of the step's set (two sets written alternately, N = 1) or slot c of the only set"""
+    return parity * n_launch + c if two_sets else c
+
+
+def read_slot(c, parity, n_launch, depth, two_sets):
+    """database slot launch c reads = the entries built `depth` launches earlier.  Two sets: slot c - depth of this step's set or, for the step's
+    first `depth` launches, the tail of the OTHER set (written at the end of the previous step).  One set: slot c - depth, or one of `depth`
+    extra slots behind the set that receive a copy of the previous step's tail when a step starts."""
+    if two_sets:
+        return parity * n_launch + c - depth if c >= depth else (1 - parity) * n_launch + n_launch - depth + c
+    return c - depth if c >= depth else n_launch + c
+
+
 def verify_timed_outputs(n, whole, norm_group, group_first, out_dist, out_ang, cand_idx, db_launch_of, seed=0):
     """Checker leg, run AFTER the timed region (the oracle is the checker, never the thing measured): proves that the timed kernels did the
     work.  For n random (launch, scan) picks out of the LAST fused descriptor launch of the timed loop:
@@ -629,12 +643,10 @@ def main():
     parity = [0]                                       # the set the current (or, after the loop, the last) step writes
 
     def wslot(c):
-        return parity[0] * CH + c if RING_DB else c
+        return write_slot(c, parity[0], CH, RING_DB)
 
     def db_slot(c):
-        if RING_DB:
-            return parity[0] * CH + c - DEPTH if c >= DEPTH else (1 - parity[0]) * CH + CH - DEPTH + c
-        return c - DEPTH if c >= DEPTH else CH + c
+        return read_slot(c, parity[0], CH, DEPTH, RING_DB)
     g = torch.Generator(device=device).manual_seed(7 + rank)
     NDB = world * B
     cand_idx = torch.randint(0, NDB, (CH, B), generator=g, device=device, dtype=torch.int32)   # pre-selected candidate rows

@@ -88,3 +88,43 @@ def test_committed_pmc_summary_prices_instructions_by_class():
         lo, hi = e["valu_busy_frac_bounds"]
         assert lo <= e["valu_issue_frac"] <= hi + 1e-9
     assert seen >= 8
+
+
+def test_bench_database_slot_plan():
+    """bench.py's database slots (N = 1: two sets written alternately; N > 1: one set + copies): a launch reads the entry built DEPTH launches
+    earlier, across the step boundary; a group's kernel never reads a slot it writes; with two sets no slot read during a step is written in
+    that step after the read's launch, and the step's LAST group of launches reads only the set the next step does not write (the lagged join)."""
+    import bench
+    for CH, FUSE in ((48, 16), (6, 2), (3, 3), (5, 0), (48, 1)):
+        DEPTH = min(FUSE + 2, CH) if FUSE else 2
+        built = {}                                     # slot -> (step, launch) that wrote it
+        for two in (True, False):
+            built.clear()
+            for c in range(CH):                        # step 0 (setup): both sets / the copies hold step "-1"
+                built[bench.write_slot(c, 0, CH, two)] = (-1, c)
+                if two:
+                    built[bench.write_slot(c, 1, CH, two)] = (-1, c)
+            for step in range(1, 5):
+                par = step % 2 if two else 0
+                if not two:                            # the copies made when the step starts
+                    for c in range(DEPTH):
+                        built[CH + c] = built[CH - DEPTH + c]
+                G = FUSE if FUSE else 1
+                for g0 in range(0, CH, G):
+                    grp = range(g0, min(g0 + G, CH))
+                    writes = {bench.write_slot(c, par, CH, two) for c in grp}
+                    for c in grp:
+                        r = bench.read_slot(c, par, CH, DEPTH, two)
+                        assert r not in writes, (CH, FUSE, two, c)
+                        st, lc = built[r]
+                        want = (step, c - DEPTH) if c >= DEPTH else (step - 1 if step > 1 else -1, CH - DEPTH + c)
+                        assert (st, lc) == want, (CH, FUSE, two, step, c, (st, lc), want)
+                        if two and c >= DEPTH:
+                            assert r // CH == par          # only this step's set
+                        if two and c < DEPTH:
+                            assert r // CH == 1 - par      # the other set: not written during this step at all
+                    for c in grp:
+                        built[bench.write_slot(c, par, CH, two)] = (step, c)
+                if two and G < CH and (CH - 1) // G * G >= DEPTH:
+                    last = range((CH - 1) // G * G, CH)    # the batch of sweeps the lagged join lets run into the next step
+                    assert all(bench.read_slot(c, par, CH, DEPTH, two) // CH == par for c in last)
