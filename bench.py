@@ -943,6 +943,17 @@ def main():
         topk_cmp = {"replicate_db_ms": ms_a, "sharded_topk_ms": ms_b, "queries_per_rank": 4, "db_rows_per_rank": B,
                     "replicate_bytes_in_per_rank": (world - 1) * B * 29280, "sharded_bytes_in_per_rank": (world - 1) * 4 * (58560 + 4 * 16)}
 
+    side_stream = None
+    if SIDE_SWEEP and "sweep" in kern_ms:
+        # on the side stream the interval between a batch's events is STREAM time: it contains the wait for compute units the descriptor
+        # kernel holds, so it is not a kernel duration and must not be added to the others.  The sweep's own duration is measured stand-alone
+        # right here (same entries), the stream time is reported apart
+        fence()
+        side_stream = {"sweeps_stream_time_ms_per_launch": kern_ms.pop("sweep"),
+                       "note": "time between the events around a batch of sweeps on the side stream / launches in the batch: includes waiting for "
+                               "compute units held by the descriptor kernel on the compute stream; kernel_ms.sweep_standalone is the sweep's own duration"}
+        kern_ms["sweep_standalone"] = ev_ms(lambda: torch.min(ring.corr_sweep_fft(spec32[wslot(0), :1], spec32[db_slot(0)])[0], 1))
+
     if rank == 0:
         pmc = load_pmc()
         cells = 120 * 120
@@ -985,6 +996,7 @@ def main():
             "timed_region_s": elapsed,
             "setup_s": setup_s,
             "kernel_ms": kern_ms,
+            "side_stream": side_stream,
             "roofline": {"kernel": "k_cart_lds (BEV scatter)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc.get("k_cart_lds", {}).get("hbm_bytes"), "algorithmic_bytes_per_launch": bev_bytes,

@@ -51,7 +51,10 @@ def test_bench_line_contract():
     assert v["timed_vs_fresh_launch_mismatches"] == 0 and v["max_err_dist"] < 1e-5 and v["max_err"] < 2e-5, v
     # default schedule: the group's correlation in one launch, the per-launch sweeps on the side stream -- checked against fresh sweeps
     assert d["config"]["corr_launches_grouped"] == 3 and d["config"]["sweep_stream"] == "side" and v["sweep_mismatches"] == 0
-    assert d["kernel_ms"]["corr"] > 0 and d["kernel_ms"]["sweep"] > 0
+    assert d["kernel_ms"]["corr"] > 0 and d["kernel_ms"]["sweep_standalone"] > 0 and "sweep" not in d["kernel_ms"]
+    assert d["side_stream"]["sweeps_stream_time_ms_per_launch"] > 0
+    # the kernel times of a step's launches (the sweeps overlap them) fit inside the step
+    assert 3 * (d["kernel_ms"]["bev_radon"] + d["kernel_ms"]["corr"]) <= d["ms_per_step"] * 1.02
     b = d["roofline_bev_scatter"]
     assert b["bound"] == "hbm" and "k_cart_lds" in b["kernel"] and abs(b["frac"] - b["achieved"] / b["peak"]) < 1e-12
 
