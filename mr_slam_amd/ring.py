@@ -4,6 +4,8 @@ LoopDetection/src/RING_ros/util.py so the parity tests read like the reference's
 """
 import ctypes as C
 
+import threading
+
 import numpy as np
 import torch
 
@@ -69,16 +71,19 @@ class RadonPlan:
 
 
 _plans = {}
+_plans_lock = threading.Lock()
 
 
 def ring_plan(device=0, num_ring=NUM_RING, num_sector=NUM_SECTOR):
     """The geometry generate_RING builds (util.py:191-192): det_count = num_sector,
-    angles = linspace(0, 2*pi, num_ring) (endpoint included), image num_ring x num_sector."""
+    angles = linspace(0, 2*pi, num_ring) (endpoint included), image num_ring x num_sector.
+    One plan per (device, geometry), shared by the threads of the process (the reference's detectors run in rospy callback threads)."""
     key = (device, num_ring, num_sector)
-    if key not in _plans:
-        angles = np.linspace(0, 2 * np.pi, num_ring).astype(np.float32)
-        _plans[key] = RadonPlan(num_sector, angles, 1.0, num_ring, num_sector, device)
-    return _plans[key]
+    with _plans_lock:
+        if key not in _plans:
+            angles = np.linspace(0, 2 * np.pi, num_ring).astype(np.float32)
+            _plans[key] = RadonPlan(num_sector, angles, 1.0, num_ring, num_sector, device)
+        return _plans[key]
 
 
 def normalize(x, group_len=None):
