@@ -3,7 +3,6 @@ correlation and translation solving.  Function names and argument meaning mirror
 LoopDetection/src/RING_ros/util.py so the parity tests read like the reference's call sites.
 """
 import ctypes as C
-
 import threading
 
 import numpy as np
