@@ -134,11 +134,12 @@ def load_pmc():
 # --------------------------------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(scans):
     """The same workload on the host cores with the oracle port (BEV restatement in C, Radon restatement in C + OpenMP,
-    fast_corr restatement on torch CPU) on a bounded sample."""
+    fast_corr restatement on torch CPU) on a bounded sample.  Protocol of SURVEY.md 8(d): `nproc` threads (`value`, `cores`); the 16-thread
+    run of the earlier rounds rides along (`at_16_threads`: the tiny FFTs of fast_corr do not scale past a few threads)."""
     from oracle import pyoracle as O
     from oracle import corr_oracle as K
+    from concurrent.futures import ThreadPoolExecutor
     nproc = os.cpu_count() or 1
-    cores = min(nproc, 16)       # tiny FFTs do not scale past a few threads
     cpu_model = "unknown"
     try:
         for ln in open("/proc/cpuinfo"):
@@ -147,30 +148,37 @@ def cpu_baseline(scans):
                 break
     except OSError:
         pass
-    torch.set_num_threads(cores)
-    os.environ["OMP_NUM_THREADS"] = str(cores)
     ang = np.linspace(0, 2 * np.pi, 120).astype(np.float32)
     soas = [synth.to_soa(s) for s in scans]
-    w = O.bev_cart(soas[0], 1, 1, 120, 120, 1).reshape(-1, 3)[:, 2].reshape(1, 120, 120)
-    ws = O.radon_parallel(w, ang, 120, 1.0)
-    wt = K.tiring_from_sinogram(ws)
-    K.fast_corr(wt, wt)
-    from concurrent.futures import ThreadPoolExecutor
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:      # the reference rasteriser is single-threaded per scan; ctypes drops the GIL
-        imgs = np.stack(list(ex.map(lambda s: O.bev_cart(s, 1, 1, 120, 120, 1).reshape(-1, 3)[:, 2].reshape(120, 120), soas)))
-    t1 = time.perf_counter()
-    sino = O.radon_parallel(imgs, ang, 120, 1.0)
-    t2 = time.perf_counter()
-    tir = [K.tiring_from_sinogram(s[None]) for s in sino]
-    for i in range(len(tir)):
-        K.fast_corr(tir[i], tir[(i + 1) % len(tir)])
-    t3 = time.perf_counter()
-    out = {"value": len(scans) / (t3 - t0), "unit": "pairs/s", "cores": cores, "nproc": nproc, "cpu_model": cpu_model, "kind": "port",
-           "sample": f"{len(scans)} scans x 120k pts: C BEV restatement (1 thread per scan, scans over {cores} threads), "
-                     f"C Radon restatement (OpenMP over images), torch-CPU fast_corr ({cores} threads)",
-           "ms_per_pair": {"bev": 1e3 * (t1 - t0) / len(scans), "radon": 1e3 * (t2 - t1) / len(scans),
-                           "fft_corr": 1e3 * (t3 - t2) / len(scans)}}
+
+    def run(cores):
+        torch.set_num_threads(cores)
+        os.environ["OMP_NUM_THREADS"] = str(cores)
+        O.set_omp_threads(cores)
+        w = O.bev_cart(soas[0], 1, 1, 120, 120, 1).reshape(-1, 3)[:, 2].reshape(1, 120, 120)
+        wt = K.tiring_from_sinogram(O.radon_parallel(w, ang, 120, 1.0))
+        K.fast_corr(wt, wt)
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:      # the reference rasteriser is single-threaded per scan; ctypes drops the GIL
+            imgs = np.stack(list(ex.map(lambda s: O.bev_cart(s, 1, 1, 120, 120, 1).reshape(-1, 3)[:, 2].reshape(120, 120), soas)))
+        t1 = time.perf_counter()
+        sino = O.radon_parallel(imgs, ang, 120, 1.0)
+        t2 = time.perf_counter()
+        tir = [K.tiring_from_sinogram(s[None]) for s in sino]
+        for i in range(len(tir)):
+            K.fast_corr(tir[i], tir[(i + 1) % len(tir)])
+        t3 = time.perf_counter()
+        return {"value": len(scans) / (t3 - t0), "cores": cores,
+                "ms_per_pair": {"bev": 1e3 * (t1 - t0) / len(scans), "radon": 1e3 * (t2 - t1) / len(scans), "fft_corr": 1e3 * (t3 - t2) / len(scans)}}
+    full = run(nproc)
+    out = {"value": full["value"], "unit": "pairs/s", "cores": nproc, "nproc": nproc, "cpu_model": cpu_model, "kind": "port",
+           "sample": f"{len(scans)} scans x 120k pts: C BEV restatement (1 thread per scan, scans over {nproc} threads), "
+                     f"C Radon restatement (OpenMP over images), torch-CPU fast_corr ({nproc} threads)",
+           "ms_per_pair": full["ms_per_pair"]}
+    if nproc > 16:
+        out["at_16_threads"] = run(16)
+        out["value_at_16_threads"] = out["at_16_threads"]["value"]
+    cores = nproc
     out["gicp"] = cpu_gicp_baseline(cores)
     # the reference's own CPU rasterisers, compiled from its sources (kind "reference"): one thread, and one scan per thread on every core
     def ref_rate(fn, label):
@@ -275,21 +283,28 @@ def _gicp_pairs(n_pairs, rank, seed0=500):
     return srcs, tgts
 
 
-def cpu_gicp_baseline(cores, iters=20):
-    """fast_gicp restatement (kd-tree + OpenMP, oracle/gicp_oracle.cpp) on ONE 120k x 120k pair of the GICP leg's shape."""
+def cpu_gicp_baseline(nproc, iters=20):
+    """fast_gicp restatement (kd-tree + OpenMP, oracle/gicp_oracle.cpp) on ONE 120k x 120k pair of the GICP leg's shape, at the reference's own
+    thread settings (4: main_RING.py:93, 8: global_manager.cpp:2438) and at `nproc`."""
     from oracle import pyoracle as O
     srcs, tgts = _gicp_pairs(1, 0)
-    g = O.Gicp(k=15, max_corr=5.0, threads=cores)
-    t0 = time.perf_counter()
-    g.set_source(srcs[0]); g.set_target(tgts[0])        # builds both kd-trees
-    t1 = time.perf_counter()
-    g.covariances(0); g.covariances(1)
-    t2 = time.perf_counter()
-    _, _, its, trials = g.align(np.eye(4), force_iters=iters)
-    t3 = time.perf_counter()
-    return {"iters_per_s": its / (t3 - t2), "iterations": its, "lm_trials": trials, "nn_passes": g.nn_passes, "align_s": t3 - t2,
-            "covariance_clouds_per_s": 2 / (t2 - t1), "kdtree_build_s": t1 - t0, "cores": cores,
-            "sample": f"1 pair x 120k pts, {its} forced iterations, k=15, max_corr 5.0 (restated fast_gicp, kd-tree + OpenMP)"}
+    out = {"sample": f"1 pair x 120k pts, {iters} forced iterations, k=15, max_corr 5.0 (restated fast_gicp, kd-tree + OpenMP)", "by_threads": {}}
+    for th in sorted({4, 8, nproc}):
+        g = O.Gicp(k=15, max_corr=5.0, threads=th)
+        t0 = time.perf_counter()
+        g.set_source(srcs[0]); g.set_target(tgts[0])        # builds both kd-trees
+        t1 = time.perf_counter()
+        g.covariances(0); g.covariances(1)
+        t2 = time.perf_counter()
+        _, _, its, trials = g.align(np.eye(4), force_iters=iters)
+        t3 = time.perf_counter()
+        out["by_threads"][str(th)] = {"iters_per_s": its / (t3 - t2), "iterations": its, "lm_trials": trials, "nn_passes": g.nn_passes, "align_s": t3 - t2,
+                                      "covariance_clouds_per_s": 2 / (t2 - t1), "kdtree_build_s": t1 - t0, "cores": th,
+                                      "pairs_per_s_incl_covariances_and_trees": 1.0 / (t3 - t0)}
+    best = max(out["by_threads"].values(), key=lambda r: r["iters_per_s"])
+    out.update({k: best[k] for k in ("iters_per_s", "iterations", "lm_trials", "nn_passes", "align_s", "covariance_clouds_per_s", "kdtree_build_s", "cores")})
+    out["note"] = "top-level figures = the fastest of the thread counts tried (by_threads holds all of them)"
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------- GICP leg
@@ -552,6 +567,27 @@ def dropin_latency_leg(scan):
 
 
 # ------------------------------------------------------------------------------------------------------------ main
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: re-exec through torch.distributed.run with N ranks on this
+    node (rendezvous on 127.0.0.1, a port that is free right now), pass the command line through, return its exit code.  Fails loudly when the
+    node has fewer than N GPUs (sharing one GPU between ranks is the gloo test mode only: MRS_BENCH_SHARE_GPU=1)."""
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("MRS_BENCH_SHARE_GPU") != "1":
+        print(f"bench.py: --gpus {n} needs {n} visible GPUs, found {have} (one rank per GPU)", file=sys.stderr)
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -587,12 +623,22 @@ def main():
     ap.add_argument("--fused-grid", choices=("auto", "persistent", "per_pair"), default="auto", help="workgroups of the fused descriptor kernel: persistent (one "
                     "per compute unit) or one per pair of scans; auto = per_pair only with --exchange allgather at N > 1 (lets RCCL's kernels in "
                     "while the descriptor kernel runs), persistent otherwise")
+    ap.add_argument("--replica", choices=("f16", "f32"), default="f16", help="--exchange allgather: fp16 replicas (29 280 B, half the bytes) + exact "
+                    "owner re-scoring of every candidate within 2e-3 of the acceptance threshold, or the exact fp32 entries themselves (58 560 B, no re-scoring)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))               # bare `python bench.py --gpus N`: start the N ranks ourselves (one JSON line from rank 0)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1 or os.environ.get("MRS_BENCH_FORCE_DIST") == "1"   # the env var exercises the RCCL path on 1 GPU
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or run bare `python bench.py "
+                 f"--gpus {args.gpus}`, which starts the ranks itself)")
+    if world > 1 and torch.cuda.device_count() < world and os.environ.get("MRS_BENCH_SHARE_GPU") != "1":
+        sys.exit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible (one rank per GPU; MRS_BENCH_SHARE_GPU=1 "
+                 f"MRS_BENCH_BACKEND=gloo is the correctness-only test mode that shares one)")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
     # test hook: MRS_BENCH_BACKEND=gloo MRS_BENCH_SHARE_GPU=1 runs the N > 1 control flow with several ranks on ONE GPU
     # (RCCL refuses two ranks per device; gloo stages the collectives through the host) -- correctness only, not a measurement
@@ -604,7 +650,7 @@ def main():
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))      # only reached without a launcher (MRS_BENCH_FORCE_DIST at world 1)
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
@@ -657,12 +703,14 @@ def main():
     # N > 1: the replicated database of the previous launch's descriptors (fp16 replicas, 29 280 B each; the owner keeps
     # the exact fp32 entry) -- at > 1 M descriptors/s/GPU fp32 spectra would exceed what the xGMI links carry
     gathered = None
+    REP32 = False
     EXCH = args.exchange if dist_on else None
     fetch_plans = fetch_q = None
     if EXCH == "allgather":
-        gathered = [torch.empty((NDB, 61, 120, 2), dtype=torch.float16, device=device) for _ in range(DEPTH + 1)]
+        REP32 = args.replica == "f32"                  # exact fp32 entries to every rank (twice the bytes, nothing to re-score)
+        gathered = [torch.empty((NDB, 61, 120, 2), dtype=torch.float32 if REP32 else torch.float16, device=device) for _ in range(DEPTH + 1)]
         for gbuf in gathered:
-            gbuf.copy_(torch.view_as_real(spec32[CH - 1]).to(torch.float16).repeat(world, 1, 1, 1))
+            gbuf.copy_(torch.view_as_real(spec32[CH - 1]).to(gbuf.dtype).repeat(world, 1, 1, 1))
     elif EXCH == "fetch":
         # request phase once, ahead of time (the candidates of every launch are known before the step starts): per launch ONE all-to-all
         # of exactly the rows asked for, exact fp32, issued FETCH_AHEAD launches early; the swept query of launch c travels after launch c
@@ -691,7 +739,7 @@ def main():
         side = torch.cuda.Stream(device=device)
     pending = []                                       # (work, source tensor) of the exchanges still in flight, oldest first
     launch_no = [0]
-    rescorer = shard.OwnerRescorer(DIST_THRESHOLD, margin=2e-3, slots=64) if EXCH == "allgather" else None
+    rescorer = shard.OwnerRescorer(DIST_THRESHOLD, margin=2e-3, slots=64) if (EXCH == "allgather" and not REP32) else None
     setup_s = time.perf_counter() - t_setup
 
     ev = {k: [] for k in ("bev", "radon", "bev_radon", "corr", "sweep", "wait")}
@@ -785,8 +833,12 @@ def main():
                 db = gathered[(g - DEPTH) % (DEPTH + 1)]
                 # half spectrum of the new descriptors (kept: database entries; fp16 replica for the other ranks) +
                 # correlation with their candidates out of the replicated database, one launch
-                spec, spec16, _, _ = ring.spectrum_corr_pairs_db(norm, db, cand_idx[c], want_f16=True, out=(out_dist[c], out_ang[c]),
+                if REP32:
+                    db = torch.view_as_complex(db)
+                spec, spec16, _, _ = ring.spectrum_corr_pairs_db(norm, db, cand_idx[c], want_f16=not REP32, out=(out_dist[c], out_ang[c]),
                                                                  spec_out=spec32[c])
+                if REP32:
+                    spec16 = torch.view_as_real(spec32[c])         # the exact entry itself travels
             elif EXCH == "fetch":
                 if c == 0:                             # the first fetches of the step read the slots copied at its start
                     for L in range(min(FETCH_AHEAD, CH)):
@@ -851,7 +903,7 @@ def main():
                 while sweep_pending:
                     run_sharded_sweep(*sweep_pending.pop(0))
             torch.cuda.current_stream().wait_stream(side)
-        if EXCH == "allgather":
+        if EXCH == "allgather" and rescorer is not None:
             # exact re-scoring of the candidates whose replica score is within 2e-3 of the acceptance threshold: global row r
             # of launch c's database = descriptor r % B of rank r // B, built in launch c - DEPTH
             slot = torch.tensor([db_slot(c) for c in range(CH)], device=device)
@@ -1036,22 +1088,36 @@ def main():
                                             "algorithmic_bytes_per_launch": bev_bytes}
         if dist_on:
             # bytes a rank receives per launch under either design, and the inbound rate each would need at the measured step time
-            ag_launch = (world - 1) * B * 29280
+            ag_launch = (world - 1) * B * (58560 if REP32 else 29280)
             if EXCH == "fetch":
                 fetch_launch = float(np.mean([pl.bytes_in(58560) for pl in fetch_plans]))
             else:
                 fetch_launch = (world - 1) / world * B * 58560                    # expected for uniformly drawn candidates
             sweep_launch = (world - 1) * (58560 + world * 16)                     # the other ranks' queries + their packed top-1 answers
             step_s = 1e-3 * line["ms_per_step"]
+            undecided = None
+            if rescorer is not None:
+                # proof that no loop decision rests on a replica score: after re-scoring, every (query, candidate) whose REPLICA distance was
+                # within the margin of the acceptance threshold carries the owner's exact value (rescore.requested of them, in rescore.rounds
+                # fixed-size rounds that only end when every rank reports none left); the rest differ from exact by < 2e-3 < margin
+                undecided = {"replica_margin": rescorer.margin, "threshold": rescorer.threshold, "requested": rescorer.stats["requested"],
+                             "rounds": rescorer.stats["rounds"], "left_undecided": 0,
+                             "note": "the rescoring loop ends only when an all-reduce(MAX) of the per-rank remaining counts is 0"}
             line["exchange"] = {"design": EXCH,
-                                "allgather": {"format": "fp16 half spectra, 29 280 B per descriptor, every descriptor to every rank",
+                                "process_group": {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "gpus_flag": args.gpus,
+                                                  "devices_visible": torch.cuda.device_count()},
+                                "replica": (args.replica if EXCH == "allgather" else None),
+                                "decisions_on_replica_scores": (None if EXCH != "allgather" else 0),
+                                "rescore_proof": undecided,
+                                "allgather": {"format": ("exact fp32 half spectra, 58 560 B per descriptor" if REP32 else
+                                                         "fp16 half spectra, 29 280 B per descriptor") + ", every descriptor to every rank",
                                               "bytes_in_per_rank_per_launch": ag_launch,
-                                              "inbound_gbs_needed_at_this_rate": ag_launch * CH / step_s / 1e9},
+                                              "inbound_gbs_needed_at_this_rate": (ag_launch * CH / step_s / 1e9) if world > 1 else None},
                                 "fetch": {"format": "exact fp32 half spectra, 58 560 B per candidate row actually asked for (pre-planned all-to-all) + one "
                                                     "query per rank and launch all-gathered for the sharded top-1 sweep",
                                           "bytes_in_per_rank_per_launch": fetch_launch + sweep_launch,
                                           "rows_bytes_in_per_rank_per_launch": fetch_launch, "sweep_bytes_in_per_rank_per_launch": sweep_launch,
-                                          "inbound_gbs_needed_at_this_rate": (fetch_launch + sweep_launch) * CH / step_s / 1e9,
+                                          "inbound_gbs_needed_at_this_rate": ((fetch_launch + sweep_launch) * CH / step_s / 1e9) if world > 1 else None,
                                           "launches_ahead": FETCH_AHEAD if EXCH == "fetch" else None},
                                 "compute_stream_wait_ms_per_launch": kern_ms.get("wait"),
                                 "compute_stream_wait_ms_per_step": kern_ms.get("wait", 0.0) * CH,

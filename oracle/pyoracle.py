@@ -213,6 +213,15 @@ def occupied_fingerprint(out3):
 
 
 # ---------------------------------------------------------------------------------- Radon
+def set_omp_threads(n):
+    """threads of the OpenMP loops of the C restatements (Radon over images) from now on; OMP_NUM_THREADS is only read when libgomp starts"""
+    lib()
+    try:
+        C.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+    except OSError:
+        pass
+
+
 def radon_parallel(img, angles, det, spacing=1.0):
     """img [B,H,W] or [H,W] float32 -> sinogram [B,n_angles,det] (orc_radon_parallel)."""
     img = _f32(img)

@@ -137,3 +137,27 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     v = x["verify"]
     assert v["checked"] == 32 and v["remote_candidates"] > 0 and v["max_abs_dist_error"] < 2e-3
     assert v["angle_mismatches"] <= 3          # fp16 replicas may move the peak of a flat correlation (unrelated scans)
+
+
+def test_bench_bare_gpus_flag_starts_the_ranks():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: bench.py starts the two ranks itself (torch.distributed.run, a free port),
+    rank 0 prints the one JSON line with n_gpus == 2.  Test mode: both ranks on the one GPU over gloo.  Without that mode the same command on a
+    one-GPU box must fail loudly instead of measuring one rank."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "32", "--chunks", "3",
+            "--gicp-pairs", "0", "--no-extra-legs", "--exchange", "allgather", "--replica", "f32", "--verify-exchange"]
+    p = subprocess.run(args, capture_output=True, text=True, env=dict(env, MRS_BENCH_BACKEND="gloo", MRS_BENCH_SHARE_GPU="1"), timeout=900)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.strip().startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["exchange"] == "allgather" and d["config"]["pairs_per_rank_per_step"] == 96
+    x = d["exchange"]
+    assert x["process_group"] == {"backend": "gloo", "world_size": 2, "gpus_flag": 2, "devices_visible": x["process_group"]["devices_visible"]}
+    # exact fp32 replicas: scores against the gathered database are the exact ones, nothing to re-score
+    assert x["replica"] == "f32" and x["rescore"] is None and x["allgather"]["bytes_in_per_rank_per_launch"] == 32 * 58560
+    v = x["verify"]
+    assert v["checked"] == 32 and v["remote_candidates"] > 0 and v["max_abs_dist_error"] < 1e-6 and v["angle_mismatches"] == 0
+    import torch
+    if torch.cuda.device_count() < 2:
+        p = subprocess.run(args, capture_output=True, text=True, env=env, timeout=300)
+        assert p.returncode != 0 and "needs 2 visible GPUs" in p.stderr and not [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+
