@@ -314,6 +314,14 @@ int mrs_gicp_batch_fitness(mrs_gicp_batch* h, const double* h_poses, double max_
 /* number of brute-force NN passes the last align() issued (for iterations/s accounting) */
 double mrs_gicp_batch_last_nn_passes(const mrs_gicp_batch* h);
 
+/* Which exact nearest-neighbour search the batch uses for G2 / G3 (no reference counterpart: upstream fast_gicp searches a
+ * kd-tree; both cores return the exact neighbours, ties aside):
+ *   1 (default) octree-cell leaves of <= 16 points + groups of 8 queries that share a candidate list (csrc/nn_core.hpp);
+ *   0           the round-3 traversal (1024-point tiles / 16-point minis, candidates shared by a whole wave), kept for A/B
+ *               measurements and as a cross-check in the tests.
+ * Invalidates cached covariances. */
+int mrs_gicp_batch_set_search(mrs_gicp_batch* h, int32_t core);
+
 /* ------------------------------------------------------------------------------------
  * rocFFT-backed 2-D correlations: DiSCO (rows D1, D2) and RING++ BEV translation (row C4)
  * ---------------------------------------------------------------------------------- */

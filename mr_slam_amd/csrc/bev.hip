@@ -913,7 +913,7 @@ int mrs_bev_feat_batch(mrs_ctx* ctx, const float* d_pts, const int64_t* d_offset
     }
     const size_t cells = (size_t)p.NX * p.NY;
     const size_t tot = (size_t)batch * cells * (layout == MRS_BEV_OUT_COMPACT ? p.F - 3 : p.F);
-    if (layout == MRS_BEV_OUT_COMPACT && p.F > 3 && cells * sizeof(int) <= 96 * 1024 && batch <= mrs::kMaxGridY) {
+    if (layout == MRS_BEV_OUT_COMPACT && p.F > 3 && cells * sizeof(int) <= std::min<size_t>(ctx->lds_bytes, 96 * 1024) && batch <= mrs::kMaxGridY) {
         const size_t lds = cells * sizeof(int);
         if (lds > 48 * 1024)
             MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_feat_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -2,6 +2,7 @@
 #include "common.hpp"
 
 #include <cstdlib>
+#include <string>
 
 namespace mrs {
 
@@ -13,6 +14,23 @@ void set_error(const char* fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+const char* dev_env(const char* name)
+{
+    const char* v = getenv(name);
+    if (!v) return nullptr;
+    const char* d = getenv("MRS_DEV");
+    static std::mutex mu;
+    static std::map<std::string, bool> told;
+    std::lock_guard<std::mutex> lk(mu);
+    const bool on = d && atoi(d) == 1;
+    if (!told[name]) {
+        told[name] = true;
+        if (on) fprintf(stderr, "[mrslam] development switch %s=%s is ACTIVE (MRS_DEV=1): outputs and timings of this process are not production results\n", name, v);
+        else fprintf(stderr, "[mrslam] %s is set but ignored: development switches need MRS_DEV=1\n", name);
+    }
+    return on ? v : nullptr;
 }
 
 // ---- scratch allocator (see common.hpp) -------------------------------------------------------------------------

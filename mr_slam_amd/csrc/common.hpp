@@ -18,6 +18,11 @@ constexpr int kMaxGridY = 65535;  // HIP grid limit in y: entry points that put 
 
 void set_error(const char* fmt, ...);
 
+// Development switches (phase timers, ablations, debug counters) are read from the environment ONLY when MRS_DEV=1 is set as well, and
+// each active one is announced on stderr once: a stray variable in a production environment can neither change results nor add
+// synchronisation silently.  Returns the variable's value, or nullptr.
+const char* dev_env(const char* name);
+
 #define MRS_HIP_TRY(expr)                                                                   \
     do {                                                                                    \
         hipError_t e__ = (expr);                                                            \

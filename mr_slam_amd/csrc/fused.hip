@@ -428,8 +428,9 @@ int mrs_ring_descriptors_batch(mrs_radon_plan* plan, const float* d_xyz, const i
             if ((st = parkbuf.alloc((size_t)grid * 2 * rays * sizeof(float), s)) != MRS_OK) return st;
             d_park = parkbuf.as<float>();
         }
-        static const bool want_prof = getenv("MRS_FUSED_PROF") != nullptr;     // development aid: phase times on stderr (synchronises)
-        static const int dev_skip_env = getenv("MRS_FUSED_SKIP") ? atoi(getenv("MRS_FUSED_SKIP")) : 0;
+        static const bool want_prof = mrs::dev_env("MRS_FUSED_PROF") != nullptr;     // development aid: phase times on stderr (synchronises)
+        static const char* const dev_skip_s = mrs::dev_env("MRS_FUSED_SKIP");
+        static const int dev_skip_env = dev_skip_s ? atoi(dev_skip_s) : 0;
         int dev_skip = dev_skip_env;
         unsigned long long* d_prof = nullptr;
         if (want_prof) {

@@ -38,6 +38,7 @@
 #include <cmath>
 
 #include "common.hpp"
+#include "nn_core.hpp"
 
 namespace {
 
@@ -1025,6 +1026,264 @@ __global__ __launch_bounds__(kNNThreads) void k_linearize(
 }
 
 
+// ================================================================================================================================
+// Round 4 search core (nn_core.hpp): octree-cell leaves + query groups.  The kernels below replace k_nn_scan / k_knn_cov /
+// k_knn_features; the round-3 kernels stay selectable (mrs_gicp_batch_set_search(h, 0)) for A/B runs and as a cross-check in the tests.
+struct HierArrays {
+    const float4* llo; const float4* lhi; const float4* tlo; const float4* thi; const float4* slo; const float4* shi;
+    const int* leaf_first; const int* tile_first; const int* super_first;   // [clouds + 1]
+};
+
+__device__ __forceinline__ nnc::LeafHier cloud_hier(const HierArrays& A, int c)
+{
+    nnc::LeafHier H;
+    const int l0 = A.leaf_first[c], t0 = A.tile_first[c], s0 = A.super_first[c];
+    H.llo = A.llo + l0; H.lhi = A.lhi + l0; H.nleaf = A.leaf_first[c + 1] - l0;
+    H.tlo = A.tlo + t0; H.thi = A.thi + t0; H.ntile = A.tile_first[c + 1] - t0;
+    H.slo = A.slo + s0; H.shi = A.shi + s0; H.nsuper = A.super_first[c + 1] - s0;
+    return H;
+}
+
+constexpr int kGS = 8;   // queries per group (nn_core.hpp)
+
+// G3a, round 4: exact 1-NN of every (float-)transformed source point.  One query per lane; semantics of k_nn_scan (corr = target index in
+// sorted space or -1 when d^2 >= max_corr^2; nn_seed = the neighbour found, warm start of the next pass), ties to the smaller index.
+template <int GS>
+__global__ __launch_bounds__(kNNThreads) void k_nn_scan_g(
+    const float4* __restrict__ src_all, const int64_t* __restrict__ src_offs,
+    const float4* __restrict__ tgt_all, const int64_t* __restrict__ tgt_offs, HierArrays HA,
+    const LmState* __restrict__ st, GicpParams prm, int* __restrict__ corr, int* __restrict__ nn_seed,
+    const int* __restrict__ tgt_bbox)
+{
+    __shared__ nnc::GrpLds<GS> lds[kNNThreads / 64];
+    const int pair = blockIdx.y;
+    const LmState& S = st[pair];
+    if (!S.active || S.phase != 0) return;
+    const int64_t so = src_offs[pair], to = tgt_offs[pair];
+    const int n = (int)(src_offs[pair + 1] - so), m = (int)(tgt_offs[pair + 1] - to);
+    const float4* src = src_all + so;
+    const float4* tgt = tgt_all + to;
+    const nnc::LeafHier H = cloud_hier(HA, pair);
+    const float maxc2 = prm.max_corr2 < 3.0e38 ? (float)prm.max_corr2 * 1.0001f : INFINITY;
+    float Tf[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Tf[i] = (float)S.x[i];
+    float glo[3];
+    const float gsc = morton_grid(tgt_bbox, pair, glo);
+    nnc::GrpLds<GS>& L = lds[threadIdx.x >> 6];
+    for (int base = blockIdx.x * kNNThreads; base < n; base += gridDim.x * kNNThreads) {
+        const int i = base + (int)threadIdx.x;
+        const bool live = i < n;
+        const float4 a = src[live ? i : 0];
+        const float qx = Tf[0] * a.x + Tf[1] * a.y + Tf[2] * a.z + Tf[3];
+        const float qy = Tf[4] * a.x + Tf[5] * a.y + Tf[6] * a.z + Tf[7];
+        const float qz = Tf[8] * a.x + Tf[9] * a.y + Tf[10] * a.z + Tf[11];
+        int seed = live ? nn_seed[so + i] : -1;
+        if (live && seed < 0 && m > 0) seed = morton_seed(tgt, m, qx, qy, qz, glo, gsc);   // cold start
+        float limv = maxc2;    // any target point is an upper bound: last pass's neighbour is nearly always the winner again
+        if (live && seed >= 0 && seed < m) limv = fminf(limv, dist2(qx, qy, qz, tgt[seed]));
+        float best = INFINITY;
+        int bidx = -1;
+        nnc::grp_search<GS>(tgt, H, L, qx, qy, qz, live,
+                            [&]() { return fminf(limv, best); },
+                            [&](int j, float d, bool) { if (d < best) { best = d; bidx = j; } });
+        if (live) {
+            corr[so + i] = (bidx >= 0 && (double)best < prm.max_corr2) ? bidx : -1;
+            nn_seed[so + i] = bidx;
+        }
+    }
+}
+
+template <int KMAX>
+__device__ __forceinline__ float kth_of(const float (&dk)[KMAX], int k)
+{
+    float v = dk[KMAX - 1];
+#pragma unroll
+    for (int s = 0; s < KMAX - 1; ++s) v = (s == k - 1) ? dk[s] : v;
+    return v;
+}
+
+// G2 / N1, round 4: exact k nearest neighbours (the point itself included) of every point of every cloud, as cloud-local sorted-space
+// indices in (distance, index) order: knn[(offs[c] + i) * k + s]; -1 in the slots a cloud with fewer than k points cannot fill.
+// Seed: the group's 32 (64 for k > 16) neighbours along the Morton curve give a bound close to the final one; pass 1: the KMAX smallest
+// DISTANCES (v_med3 chain, no indices) over the leaves within the shrinking bound -> tau = the exact k-th distance; pass 2: every candidate
+// within tau, strictly closer ones from the bottom of a k-slot LDS list, exact ties from its top (they arrive in ascending index order, and a
+// tie is only kept while the list still has room for it: at most k - #closer can be needed), so a cluster of duplicates can neither
+// overflow the list nor push a closer point out; selection: (distance, index) insertion of the <= k collected.
+template <int KMAX, int GS>
+__global__ __launch_bounds__(kNNThreads) void k_knn_select(const float4* __restrict__ pts_all, const int64_t* __restrict__ offs, HierArrays HA,
+                                                           int k, int* __restrict__ knn)
+{
+    __shared__ nnc::GrpLds<GS> lds[kNNThreads / 64];
+    __shared__ int lst[KMAX * kNNThreads];          // slot-major: slot s of lane t at lst[s * kNNThreads + t]
+    const int c = blockIdx.y;
+    const int64_t o = offs[c];
+    const int n = (int)(offs[c + 1] - o);
+    const float4* pts = pts_all + o;
+    const nnc::LeafHier H = cloud_hier(HA, c);
+    nnc::GrpLds<GS>& L = lds[threadIdx.x >> 6];
+    constexpr int HS = KMAX <= 16 ? 32 : 64;
+    const int tid = (int)threadIdx.x;
+    for (int base = blockIdx.x * kNNThreads; base < n; base += gridDim.x * kNNThreads) {
+        const int i = base + tid;
+        const bool live = i < n;
+        const float4 q = pts[live ? i : 0];
+        float dk[KMAX];
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) dk[s] = INFINITY;
+        // seed phase: HS consecutive points around the group's queries
+        const int hc = min(HS, n);
+        const int h0 = max(0, min(base + (tid & ~(GS - 1)) + GS / 2 - HS / 2, n - hc));
+        nnc::grp_eval_range<GS>(pts, q.x, q.y, q.z, h0, hc, [&](int, float d, bool ok) { dist_insert<KMAX>(dk, (ok && live && d == d) ? d : INFINITY); });
+        // pass 1: the k-th distance
+        nnc::grp_search<GS>(pts, H, L, q.x, q.y, q.z, live, [&]() { return kth_of<KMAX>(dk, k); },
+                            [&](int j, float d, bool ok) {
+                                const bool use = ok && live && (unsigned)(j - h0) >= (unsigned)hc && d == d;
+                                dist_insert<KMAX>(dk, use ? d : INFINITY);
+                            });
+        const float tau = live ? kth_of<KMAX>(dk, k) : -1.0f;
+        // pass 2: indices within tau
+        int nlt = 0, ntie = 0;
+        nnc::grp_search<GS>(pts, H, L, q.x, q.y, q.z, live, [&]() { return tau; },
+                            [&](int j, float d, bool ok) {
+                                if (!(ok && live)) return;
+                                if (d < tau) {
+                                    if (nlt + ntie == k && ntie > 0) --ntie;           // the tie with the largest index is no longer needed
+                                    if (nlt + ntie < k) { lst[nlt * kNNThreads + tid] = j; ++nlt; }
+                                } else if (d == tau && d < INFINITY && nlt + ntie < k) {
+                                    lst[(k - 1 - ntie) * kNNThreads + tid] = j;
+                                    ++ntie;
+                                }
+                            });
+        // selection in (distance, index) order
+        int ik[KMAX];
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) { dk[s] = INFINITY; ik[s] = -1; }
+        int most = max(nlt, ntie);
+        for (int w = 32; w > 0; w >>= 1) most = max(most, __shfl_xor(most, w, 64));
+        for (int e = 0; e < most; ++e) {
+            const bool ha = e < nlt, hb = e < ntie;
+            const int ja = ha ? lst[e * kNNThreads + tid] : 0;
+            const int jb = hb ? lst[(k - 1 - e) * kNNThreads + tid] : 0;
+            const float da = dist2(q.x, q.y, q.z, pts[ja]), db = dist2(q.x, q.y, q.z, pts[jb]);
+            if (ha) knn_insert_tie<KMAX>(dk, ik, da, ja);
+            if (hb) knn_insert_tie<KMAX>(dk, ik, db, jb);
+        }
+        if (live) {
+            int* out = knn + (size_t)(o + i) * k;
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s)
+                if (s < k) out[s] = ik[s];
+        }
+    }
+}
+
+// G2 tail: covariance of the k neighbours (double, neighbours summed in (distance, index) order like k_knn_cov) + PLANE regularisation.
+// One point per lane; knn = k_knn_select's output.  knn_out optional, ORIGINAL indexing.
+__global__ __launch_bounds__(256) void k_cov_from_knn(const float4* __restrict__ pts_all, const int64_t* __restrict__ offs, int k,
+                                                     const int* __restrict__ knn, double* __restrict__ cov_all, int* __restrict__ knn_out)
+{
+    const int c = blockIdx.y;
+    const int64_t o = offs[c];
+    const int n = (int)(offs[c + 1] - o);
+    const float4* pts = pts_all + o;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int* nb = knn + (size_t)(o + i) * k;
+        double mean[3] = {0, 0, 0};
+        int cnt = 0;
+        for (int s = 0; s < k; ++s) {
+            const int j = nb[s];
+            if (j < 0) continue;
+            const float4 p = pts[j];
+            mean[0] += (double)p.x; mean[1] += (double)p.y; mean[2] += (double)p.z;
+            ++cnt;
+        }
+        mean[0] /= cnt; mean[1] /= cnt; mean[2] /= cnt;
+        double cv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int s = 0; s < k; ++s) {
+            const int j = nb[s];
+            if (j < 0) continue;
+            const float4 p = pts[j];
+            const double dx = (double)p.x - mean[0], dy = (double)p.y - mean[1], dz = (double)p.z - mean[2];
+            cv[0] += dx * dx; cv[1] += dx * dy; cv[2] += dx * dz;
+            cv[4] += dy * dy; cv[5] += dy * dz; cv[8] += dz * dz;
+        }
+        cv[3] = cv[1]; cv[6] = cv[2]; cv[7] = cv[5];
+        for (int a = 0; a < 9; ++a) cv[a] /= cnt;
+        double nrm[3];
+        smallest_eigvec(cv, nrm);
+        double* out = cov_all + 6 * (size_t)(o + i);
+        out[0] = 1.0 - 0.999 * nrm[0] * nrm[0];
+        out[1] = -0.999 * nrm[0] * nrm[1];
+        out[2] = -0.999 * nrm[0] * nrm[2];
+        out[3] = 1.0 - 0.999 * nrm[1] * nrm[1];
+        out[4] = -0.999 * nrm[1] * nrm[2];
+        out[5] = 1.0 - 0.999 * nrm[2] * nrm[2];
+        if (knn_out) {
+            const int oi = __float_as_int(pts[i].w);
+            for (int s = 0; s < k; ++s) knn_out[(size_t)(o + oi) * k + s] = nb[s] >= 0 ? __float_as_int(pts[nb[s]].w) : -1;
+        }
+    }
+}
+
+// N1 tail: covariance / eigenvalues / the 13 features of every point from its k neighbours (k_knn_features' arithmetic, same order)
+__global__ __launch_bounds__(256) void k_feat_from_knn(const float4* __restrict__ pts_all, const int64_t* __restrict__ offs, int k,
+                                                      const int* __restrict__ knn, int* __restrict__ knn_out, float* __restrict__ eig_out,
+                                                      float* __restrict__ feat_out, float* __restrict__ feat_planes)
+{
+    const int c = blockIdx.y;
+    const int64_t o = offs[c];
+    const int n = (int)(offs[c + 1] - o);
+    const float4* pts = pts_all + o;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int* nb = knn + (size_t)(o + i) * k;
+        const float4 q = pts[i];
+        const int oi = __float_as_int(q.w);
+        double mean[3] = {0, 0, 0};
+        float nz[32];
+        int cnt = 0;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            nz[s] = 0.0f;
+            if (s < k && nb[s] >= 0) {
+                const float4 p = pts[nb[s]];
+                mean[0] += (double)p.x; mean[1] += (double)p.y; mean[2] += (double)p.z;
+                nz[s] = p.z;
+                ++cnt;
+            }
+        }
+        mean[0] /= cnt; mean[1] /= cnt; mean[2] /= cnt;
+        double cv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int s = 0; s < k; ++s) {
+            if (nb[s] < 0) continue;
+            const float4 p = pts[nb[s]];
+            const double dx = (double)p.x - mean[0], dy = (double)p.y - mean[1], dz = (double)p.z - mean[2];
+            cv[0] += dx * dx; cv[1] += dx * dy; cv[2] += dx * dz;
+            cv[4] += dy * dy; cv[5] += dy * dz; cv[8] += dz * dz;
+        }
+        cv[3] = cv[1]; cv[6] = cv[2]; cv[7] = cv[5];
+        for (int a = 0; a < 9; ++a) cv[a] /= (double)(cnt - 1);
+        double w[3];
+        sym3_eigvals(cv, w);
+        const double hm = 0.5 * (cv[0] + cv[4]), hd = 0.5 * (cv[0] - cv[4]);
+        const double rad = sqrt(hd * hd + cv[1] * cv[1]);
+        float e[5] = {(float)w[0], (float)w[1], (float)w[2], (float)(hm + rad), (float)(hm - rad)};
+        float f[13];
+        point_features(e, nz, k, f);
+        const size_t gi = (size_t)(o + oi);
+        if (knn_out)
+            for (int s = 0; s < k; ++s) knn_out[gi * k + s] = nb[s] >= 0 ? __float_as_int(pts[nb[s]].w) : -1;
+        if (eig_out) for (int j = 0; j < 5; ++j) eig_out[gi * 5 + j] = e[j];
+        if (feat_out) for (int j = 0; j < 13; ++j) feat_out[gi * 13 + j] = f[j];
+        if (feat_planes) {
+            float* pl = feat_planes + (size_t)9 * o;  // scan-local channel-major planes
+            pl[0 * (size_t)n + oi] = q.x; pl[1 * (size_t)n + oi] = q.y; pl[2 * (size_t)n + oi] = q.z;
+            pl[3 * (size_t)n + oi] = f[0]; pl[4 * (size_t)n + oi] = f[1]; pl[5 * (size_t)n + oi] = f[3];
+            pl[6 * (size_t)n + oi] = f[10]; pl[7 * (size_t)n + oi] = f[11]; pl[8 * (size_t)n + oi] = f[12];
+        }
+    }
+}
+
 // ---- G7: voxelised GICP (fast_gicp FastVGICP / FastVGICPCuda; Koide et al., ICRA 2021) ---------------------
 // The target is summarised per voxel of edge `res`: mean of its points and mean of their (regularised)
 // covariances (ADDITIVE accumulation).  A transformed source point corresponds to the voxel that contains it
@@ -1484,6 +1743,23 @@ struct mrs_gicp_batch {
     int max_blocks = 0;
     int longest_src = 0;            // points in the largest source cloud (grid of the NN scan)
     double last_nn_passes = 0;
+    // round-4 search structure (nn_core.hpp): octree-cell leaves of <= 16 points, tiles of 64 leaves, supers of 64 tiles, per cloud
+    float4* d_llo[2] = {nullptr, nullptr};
+    float4* d_lhi[2] = {nullptr, nullptr};
+    float4* d_t2lo[2] = {nullptr, nullptr};
+    float4* d_t2hi[2] = {nullptr, nullptr};
+    float4* d_slo[2] = {nullptr, nullptr};
+    float4* d_shi[2] = {nullptr, nullptr};
+    int* d_leaf_first[2] = {nullptr, nullptr};    // [n_pairs + 1] each
+    int* d_tile_first[2] = {nullptr, nullptr};
+    int* d_super_first[2] = {nullptr, nullptr};
+    int cap_leaves[2] = {0, 0}, cap_tiles2[2] = {0, 0}, cap_supers[2] = {0, 0};
+    int n_leaves[2] = {0, 0};
+    int search_core = 1;            // 1: octree leaves + query groups (round 4), 0: round-3 wave-shared traversal (A/B, cross-check)
+    HierArrays hier(int w) const
+    {
+        return HierArrays{d_llo[w], d_lhi[w], d_t2lo[w], d_t2hi[w], d_slo[w], d_shi[w], d_leaf_first[w], d_tile_first[w], d_super_first[w]};
+    }
 };
 
 namespace {
@@ -1499,6 +1775,12 @@ void free_cloud(mrs_gicp_batch* h, int w)
     if (h->d_thi[w]) (void)hipFree(h->d_thi[w]);
     if (h->d_mlo[w]) (void)hipFree(h->d_mlo[w]);
     if (h->d_mhi[w]) (void)hipFree(h->d_mhi[w]);
+    for (void* p : {(void*)h->d_llo[w], (void*)h->d_lhi[w], (void*)h->d_t2lo[w], (void*)h->d_t2hi[w], (void*)h->d_slo[w], (void*)h->d_shi[w],
+                    (void*)h->d_leaf_first[w], (void*)h->d_tile_first[w], (void*)h->d_super_first[w]})
+        if (p) (void)hipFree(p);
+    h->d_llo[w] = h->d_lhi[w] = h->d_t2lo[w] = h->d_t2hi[w] = h->d_slo[w] = h->d_shi[w] = nullptr;
+    h->d_leaf_first[w] = h->d_tile_first[w] = h->d_super_first[w] = nullptr;
+    h->cap_leaves[w] = h->cap_tiles2[w] = h->cap_supers[w] = 0; h->n_leaves[w] = 0;
     h->d_mlo[w] = nullptr; h->d_mhi[w] = nullptr;
     h->d_offs[w] = nullptr; h->d_pts[w] = nullptr; h->d_cov[w] = nullptr;
     h->d_tile_base[w] = nullptr; h->d_tlo[w] = nullptr; h->d_thi[w] = nullptr; h->d_bbox[w] = nullptr;
@@ -1517,16 +1799,104 @@ void launch_nn_scan(int longest_src, int n_pairs, int num_cu, hipStream_t s, Arg
 {
     const int cus = num_cu > 0 ? num_cu : 256;
     auto wgs = [&](int P) { return (long)n_pairs * ((longest_src + kNNThreads * P - 1) / (kNNThreads * P)); };
-    static const int force_p = getenv("MRS_NN_P") ? atoi(getenv("MRS_NN_P")) : 0;     // development aid: 1 or 2 source points per lane
+    static const char* const force_p_s = mrs::dev_env("MRS_NN_P");
+    static const int force_p = force_p_s ? atoi(force_p_s) : 0;     // development aid: 1 or 2 source points per lane
     if (force_p == 2 || (force_p != 1 && wgs(2) >= 3L * cus))
         hipLaunchKernelGGL(k_nn_scan<2>, dim3((unsigned)(wgs(2) / n_pairs), n_pairs), dim3(kNNThreads), 0, s, args...);
     else
         hipLaunchKernelGGL(k_nn_scan<1>, dim3((unsigned)(wgs(1) / n_pairs), n_pairs), dim3(kNNThreads), 0, s, args...);
 }
 
+// Octree-cell leaves + tiles + supers of every cloud of side `w` from the sorted keys (set_clouds).  Synchronises (the leaf counts size the arrays).
+int build_leaf_hier(mrs_gicp_batch* h, int w, const unsigned long long* d_keys, int64_t total, hipStream_t s)
+{
+    const int P = h->n_pairs;
+    mrs::Scratch cellhead, cellstart, head, leafid, tmp;
+    int st;
+    for (mrs::Scratch* b : {&cellhead, &cellstart, &head, &leafid})
+        if ((st = b->alloc((size_t)total * sizeof(int), s)) != MRS_OK) return st;
+    const int fb = (int)std::min<int64_t>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(nnc::k_leaf_level, dim3(fb), dim3(256), 0, s, d_keys, (size_t)total, cellhead.as<int>());
+    size_t b1 = 0, b2 = 0;
+    MRS_HIP_TRY(hipcub::DeviceScan::InclusiveScan(nullptr, b1, cellhead.as<int>(), cellstart.as<int>(), hipcub::Max(), (int)total, s));
+    MRS_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, b2, head.as<int>(), leafid.as<int>(), (int)total, s));
+    if ((st = tmp.alloc(std::max(b1, b2), s)) != MRS_OK) return st;
+    MRS_HIP_TRY(hipcub::DeviceScan::InclusiveScan(tmp.p, b1, cellhead.as<int>(), cellstart.as<int>(), hipcub::Max(), (int)total, s));
+    hipLaunchKernelGGL(nnc::k_leaf_heads, dim3(fb), dim3(256), 0, s, cellstart.as<int>(), (size_t)total, head.as<int>());
+    MRS_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, b2, head.as<int>(), leafid.as<int>(), (int)total, s));
+    if (!h->d_leaf_first[w]) {
+        MRS_HIP_TRY(hipMalloc(&h->d_leaf_first[w], (size_t)(P + 1) * sizeof(int)));
+        MRS_HIP_TRY(hipMalloc(&h->d_tile_first[w], (size_t)(P + 1) * sizeof(int)));
+        MRS_HIP_TRY(hipMalloc(&h->d_super_first[w], (size_t)(P + 1) * sizeof(int)));
+    }
+    hipLaunchKernelGGL(nnc::k_leaf_first, dim3((P + 1 + 255) / 256), dim3(256), 0, s, head.as<int>(), leafid.as<int>(), h->d_offs[w], P,
+                       h->d_leaf_first[w]);
+    MRS_HIP_TRY(hipGetLastError());
+    std::vector<int> lf(P + 1), tf(P + 1), sf(P + 1);
+    MRS_HIP_TRY(hipMemcpyAsync(lf.data(), h->d_leaf_first[w], lf.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+    MRS_HIP_TRY(hipStreamSynchronize(s));
+    int most_tiles = 0, most_supers = 0;
+    tf[0] = sf[0] = 0;
+    for (int c = 0; c < P; ++c) {
+        const int nl = lf[c + 1] - lf[c], nt = (nl + 63) / 64, ns = (nt + 63) / 64;
+        tf[c + 1] = tf[c] + nt; sf[c + 1] = sf[c] + ns;
+        most_tiles = std::max(most_tiles, nt); most_supers = std::max(most_supers, ns);
+    }
+    h->n_leaves[w] = lf[P];
+    auto grow = [](float4*& a, float4*& b, int& cap, int need) -> hipError_t {
+        if (need <= cap && a) return hipSuccess;
+        if (a) (void)hipFree(a);
+        if (b) (void)hipFree(b);
+        a = b = nullptr;
+        cap = need + need / 8 + 1;
+        hipError_t e = hipMalloc(&a, (size_t)cap * sizeof(float4));
+        return e != hipSuccess ? e : hipMalloc(&b, (size_t)cap * sizeof(float4));
+    };
+    MRS_HIP_TRY(grow(h->d_llo[w], h->d_lhi[w], h->cap_leaves[w], lf[P]));
+    MRS_HIP_TRY(grow(h->d_t2lo[w], h->d_t2hi[w], h->cap_tiles2[w], tf[P]));
+    MRS_HIP_TRY(grow(h->d_slo[w], h->d_shi[w], h->cap_supers[w], sf[P]));
+    MRS_HIP_TRY(hipMemcpyAsync(h->d_tile_first[w], tf.data(), tf.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    MRS_HIP_TRY(hipMemcpyAsync(h->d_super_first[w], sf.data(), sf.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(nnc::k_leaf_boxes, dim3(fb), dim3(256), 0, s, (const float4*)h->d_pts[w], d_keys, head.as<int>(), leafid.as<int>(),
+                       h->d_offs[w], (size_t)total, h->d_llo[w], h->d_lhi[w]);
+    hipLaunchKernelGGL(nnc::k_group_boxes, dim3(most_tiles, P), dim3(64), 0, s, (const float4*)h->d_llo[w], (const float4*)h->d_lhi[w],
+                       (const int*)h->d_leaf_first[w], (const int*)h->d_tile_first[w], h->d_t2lo[w], h->d_t2hi[w]);
+    hipLaunchKernelGGL(nnc::k_group_boxes, dim3(most_supers, P), dim3(64), 0, s, (const float4*)h->d_t2lo[w], (const float4*)h->d_t2hi[w],
+                       (const int*)h->d_tile_first[w], (const int*)h->d_super_first[w], h->d_slo[w], h->d_shi[w]);
+    MRS_HIP_TRY(hipGetLastError());
+    MRS_HIP_TRY(hipStreamSynchronize(s));     // tf / sf are temporaries
+    return MRS_OK;
+}
+
+// k nearest neighbours of every point of side `w` (k_knn_select) into knn [total][k]
+int launch_knn_select(mrs_gicp_batch* h, int w, int k, int* d_knn, hipStream_t s)
+{
+    int64_t longest = 0;
+    for (int i = 0; i < h->n_pairs; ++i) longest = std::max(longest, h->offs[w][i + 1] - h->offs[w][i]);
+    const dim3 grid((unsigned)((longest + kNNThreads - 1) / kNNThreads), h->n_pairs);
+    const HierArrays HA = h->hier(w);
+    if (k <= 16)
+        hipLaunchKernelGGL((k_knn_select<16, kGS>), grid, dim3(kNNThreads), 0, s, (const float4*)h->d_pts[w], (const int64_t*)h->d_offs[w], HA, k, d_knn);
+    else if (k <= 20)
+        hipLaunchKernelGGL((k_knn_select<20, kGS>), grid, dim3(kNNThreads), 0, s, (const float4*)h->d_pts[w], (const int64_t*)h->d_offs[w], HA, k, d_knn);
+    else
+        hipLaunchKernelGGL((k_knn_select<32, kGS>), grid, dim3(kNNThreads), 0, s, (const float4*)h->d_pts[w], (const int64_t*)h->d_offs[w], HA, k, d_knn);
+    MRS_HIP_TRY(hipGetLastError());
+    return MRS_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int mrs_gicp_batch_set_search(mrs_gicp_batch* h, int32_t core)
+{
+    MRS_REQUIRE(h, "null handle");
+    MRS_REQUIRE(core == 0 || core == 1, "core must be 0 (round-3 wave-shared traversal) or 1 (octree leaves + query groups)");
+    if (core != h->search_core) h->cov_valid[0] = h->cov_valid[1] = false;
+    h->search_core = core;
+    return MRS_OK;
+}
 
 void mrs_gicp_default_params(mrs_gicp_params* p)
 {
@@ -1698,6 +2068,7 @@ int mrs_gicp_batch_set_clouds(mrs_gicp_batch* h, int32_t which, const float* d_p
     hipLaunchKernelGGL(k_boxes, dim3(longest_tiles, h->n_pairs), dim3(256), 0, s, h->d_pts[which], h->d_offs[which],
                        h->d_tile_base[which], h->d_tlo[which], h->d_thi[which], h->d_mlo[which], h->d_mhi[which]);
     MRS_HIP_TRY(hipGetLastError());
+    if ((st = build_leaf_hier(h, which, keys_out.as<unsigned long long>(), total, s)) != MRS_OK) return st;
     MRS_HIP_TRY(hipStreamSynchronize(s));
     return MRS_OK;
 }
@@ -1731,7 +2102,19 @@ int mrs_gicp_batch_compute_covariances(mrs_gicp_batch* h, int32_t which, int32_t
     for (int i = 0; i < h->n_pairs; ++i) longest = std::max(longest, h->offs[which][i + 1] - h->offs[which][i]);
     const dim3 grid((unsigned)((longest + kNNThreads - 1) / kNNThreads), h->n_pairs);
     const int k = h->prm.k;
-    if (getenv("MRS_KNN_DBG")) {
+    if (h->search_core == 1) {
+        mrs::Scratch knn;
+        int st = knn.alloc((size_t)h->offs[which][h->n_pairs] * k * sizeof(int), s);
+        if (st != MRS_OK) return st;
+        if ((st = launch_knn_select(h, which, k, knn.as<int>(), s)) != MRS_OK) return st;
+        hipLaunchKernelGGL(k_cov_from_knn, dim3((unsigned)((longest + 255) / 256), h->n_pairs), dim3(256), 0, s, (const float4*)h->d_pts[which],
+                           (const int64_t*)h->d_offs[which], k, (const int*)knn.as<int>(), h->d_cov[which], d_knn_out);
+        MRS_HIP_TRY(hipGetLastError());
+        h->cov_valid[which] = true;
+        if (which == 1) h->vox_res_built = 0.0;
+        return MRS_OK;
+    }
+    if (mrs::dev_env("MRS_KNN_DBG")) {
         const int on = 1;
         MRS_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_knn_dbg_on), &on, sizeof(on)));
     }
@@ -1745,7 +2128,7 @@ int mrs_gicp_batch_compute_covariances(mrs_gicp_batch* h, int32_t which, int32_t
         hipLaunchKernelGGL(k_knn_cov<32>, grid, dim3(kNNThreads), 0, s, h->d_pts[which], h->d_offs[which], h->d_tile_base[which],
                            h->d_tlo[which], h->d_thi[which], h->d_mlo[which], h->d_mhi[which], k, h->d_cov[which], d_knn_out);
     MRS_HIP_TRY(hipGetLastError());
-    static const bool knn_dbg = getenv("MRS_KNN_DBG") != nullptr;
+    static const bool knn_dbg = mrs::dev_env("MRS_KNN_DBG") != nullptr;
     if (knn_dbg) {
         unsigned long long c[8];
         MRS_HIP_TRY(hipStreamSynchronize(s));
@@ -1892,7 +2275,11 @@ int mrs_gicp_batch_align(mrs_gicp_batch* h, const double* h_guess, double* h_fin
             hipLaunchKernelGGL(k_linearize_voxel, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_cov[0], h->d_vkeys,
                                h->d_vmean, h->d_vcov, h->n_voxels, h->d_state, h->prm, h->d_partial, h->max_blocks);
         } else {
-            if (next[0] > 0)   // only linearisations search; LM trials score the cached correspondences
+            if (next[0] > 0 && h->search_core == 1) {   // only linearisations search; LM trials score the cached correspondences
+                hipLaunchKernelGGL((k_nn_scan_g<kGS>), dim3((unsigned)((h->longest_src + kNNThreads - 1) / kNNThreads), h->n_pairs), dim3(kNNThreads), 0, s,
+                                   (const float4*)h->d_pts[0], (const int64_t*)h->d_offs[0], (const float4*)h->d_pts[1], (const int64_t*)h->d_offs[1],
+                                   h->hier(1), (const LmState*)h->d_state, h->prm, h->d_corr, h->d_seed, (const int*)h->d_bbox[1]);
+            } else if (next[0] > 0)
                 launch_nn_scan(h->longest_src, h->n_pairs, h->ctx->num_cu, s, h->d_pts[0], h->d_offs[0], h->d_pts[1], h->d_offs[1],
                                h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_mlo[1], h->d_mhi[1], h->d_state, h->prm, h->d_corr, h->d_seed, (const int*)h->d_bbox[1]);
             hipLaunchKernelGGL(k_linearize, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_cov[0],
@@ -1945,8 +2332,14 @@ int mrs_gicp_batch_linearize(mrs_gicp_batch* h, const double* h_poses, double* h
                            h->d_cov[0], h->d_vkeys, h->d_vmean, h->d_vcov, h->n_voxels, h->d_state, h->prm, h->d_partial,
                            h->max_blocks);
     } else {
-        launch_nn_scan(h->longest_src, h->n_pairs, h->ctx->num_cu, s, h->d_pts[0], h->d_offs[0],
-                       h->d_pts[1], h->d_offs[1], h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_mlo[1], h->d_mhi[1], h->d_state, h->prm, h->d_corr, h->d_seed, (const int*)h->d_bbox[1]);
+        if (h->search_core == 1) {
+            hipLaunchKernelGGL((k_nn_scan_g<kGS>), dim3((unsigned)((h->longest_src + kNNThreads - 1) / kNNThreads), h->n_pairs), dim3(kNNThreads), 0, s,
+                               (const float4*)h->d_pts[0], (const int64_t*)h->d_offs[0], (const float4*)h->d_pts[1], (const int64_t*)h->d_offs[1],
+                               h->hier(1), (const LmState*)h->d_state, h->prm, h->d_corr, h->d_seed, (const int*)h->d_bbox[1]);
+        } else {
+            launch_nn_scan(h->longest_src, h->n_pairs, h->ctx->num_cu, s, h->d_pts[0], h->d_offs[0],
+                           h->d_pts[1], h->d_offs[1], h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_mlo[1], h->d_mhi[1], h->d_state, h->prm, h->d_corr, h->d_seed, (const int*)h->d_bbox[1]);
+        }
         hipLaunchKernelGGL(k_linearize, dim3(h->max_blocks, h->n_pairs), dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0],
                            h->d_cov[0], h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->d_corr, h->d_partial,
                            h->max_blocks);
@@ -2070,8 +2463,23 @@ int mrs_pointfeat_batch(mrs_ctx* ctx, const float* d_points, int32_t stride_floa
         int64_t longest = 0;
         for (int i = 0; i < batch; ++i) longest = std::max(longest, h_offsets[i + 1] - h_offsets[i]);
         const dim3 grid((unsigned)((longest + kNNThreads - 1) / kNNThreads), batch);
-        hipLaunchKernelGGL(k_knn_features<32>, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_tile_base[0],
-                           h->d_tlo[0], h->d_thi[0], h->d_mlo[0], h->d_mhi[0], k, d_knn, d_eigens, d_features, d_feat_planes);
+        static const char* const core_s = mrs::dev_env("MRS_NN_CORE");      // development aid: 0 = the round-3 kernel
+        if (!(core_s && atoi(core_s) == 0)) {
+            mrs::Scratch knn;
+            st = knn.alloc((size_t)h_offsets[batch] * k * sizeof(int), s);
+            if (st == MRS_OK) st = launch_knn_select(h, 0, k, knn.as<int>(), s);
+            if (st == MRS_OK) {
+                hipLaunchKernelGGL(k_feat_from_knn, dim3((unsigned)((longest + 255) / 256), batch), dim3(256), 0, s, (const float4*)h->d_pts[0],
+                                   (const int64_t*)h->d_offs[0], k, (const int*)knn.as<int>(), d_knn, d_eigens, d_features, d_feat_planes);
+                if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+                    mrs::set_error("k_feat_from_knn launch failed");
+                    st = MRS_ERR_HIP;
+                }
+            }
+        } else {
+            hipLaunchKernelGGL(k_knn_features<32>, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_tile_base[0],
+                               h->d_tlo[0], h->d_thi[0], h->d_mlo[0], h->d_mhi[0], k, d_knn, d_eigens, d_features, d_feat_planes);
+        }
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
             mrs::set_error("k_knn_features launch failed");
             st = MRS_ERR_HIP;

@@ -49,6 +49,10 @@ class GicpBatch:
             setattr(self.params, k, v)
         _lib.check(_lib.load().mrs_gicp_batch_set_params(self._h, C.byref(self.params)))
 
+    def set_search(self, core):
+        """1 (default): octree-cell leaves + query groups; 0: the round-3 wave-shared traversal (A/B, cross-check)."""
+        _lib.check(_lib.load().mrs_gicp_batch_set_search(self._h, int(core)))
+
     def _set(self, which, clouds):
         """clouds: list of [n_i, >=3] arrays (host) or a (device tensor [N, s], offsets) tuple."""
         if isinstance(clouds, tuple):

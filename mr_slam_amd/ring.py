@@ -254,7 +254,13 @@ def solve_translation(query, positive, rot_angle, device="cuda:0", want_shifts=F
     ~ sqrt(H/2)): it is formed on the host with the same torch.svd call the reference makes on CPU tensors, on the GPU-computed
     shifts, and equals the reference-run numbers of tests/golden/ref_corr.npz.  main_RING.py:177-178 consumes exactly these x, y.
     least_squares=True returns the pseudo-inverse solution instead (the reference's own `method='pinv'` branch), evaluated in
-    the kernel."""
+    the kernel.
+
+    Scope of the parity claim: the default equals the reference run on CPU tensors (torch.svd -> LAPACK gesdd).  The reference runs
+    torch.svd on its `device`; on a CUDA device another SVD backend may pick other signs / another order for the two nearly equal
+    singular vectors, and `v.t() @ ...` (instead of `v @ ...`) then yields a differently turned (x, y).  The default is therefore not
+    a property of the data; callers that need the well-defined answer use least_squares=True, callers that compare with the
+    reference's logged numbers keep the default."""
     q = torch.as_tensor(query, dtype=torch.float32).to(device).contiguous()
     p = torch.as_tensor(positive, dtype=torch.float32).to(device).contiguous()
     Cc, H, W = q.shape

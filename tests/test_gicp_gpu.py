@@ -302,3 +302,96 @@ def test_timed_protocol_batch_matches_restatement(dev, oracle):
         assert wits == iters and dt < TOL_T and dr < TOL_R, (i, dt, dr)
         worst = (max(worst[0], dt), max(worst[1], dr))
     print("timed-protocol GICP parity, worst of 8 pairs: %.2e m, %.2e rad" % worst)
+
+
+def _clouds_for_search_tests():
+    from mr_slam_amd import synth
+    rng = np.random.default_rng(11)
+    lidar = synth.lidar_scan(7, 30000, metric=True)
+    uni = rng.uniform(-20, 20, size=(6000, 3)).astype(np.float32)
+    lattice = np.stack(np.meshgrid(np.arange(24), np.arange(24), np.arange(12), indexing="ij"), -1).reshape(-1, 3).astype(np.float32) * 0.25
+    lattice = lattice[rng.permutation(lattice.shape[0])]
+    # 60 copies of one point right next to a handful of distinct points: more exact ties at the k-th distance than any list has room for
+    cluster = np.concatenate([np.repeat(np.array([[1.0, 2.0, 0.5]], np.float32), 60, 0), rng.normal(0, 0.3, (300, 3)).astype(np.float32) + [1.0, 2.0, 0.5],
+                              np.repeat(np.array([[1.05, 2.0, 0.5]], np.float32), 45, 0)])
+    cluster = cluster[rng.permutation(cluster.shape[0])]
+    same = np.repeat(np.array([[3.0, -1.0, 2.0]], np.float32), 200, 0)           # one cell of the finest level holds everything
+    return {"lidar": lidar, "uniform": uni, "lattice": lattice, "cluster": cluster, "same": same, "seventeen": uni[:17], "one": uni[:1]}
+
+
+def _knn_d2(oracle, cloud, knn):
+    I = np.eye(4)
+    return np.stack([oracle.pair_d2(cloud, I, cloud, knn[:, j]) for j in range(knn.shape[1])], 1)
+
+
+@pytest.mark.parametrize("k", [15, 20, 30])
+def test_knn_exact_on_adversarial_clouds(dev, oracle, k):
+    """Round-4 search (octree-cell leaves + query groups): the k nearest of every point against brute force -- same multiset of float
+    distances, ascending, every index valid and distinct, ties broken towards the smaller index -- on a lidar scan, uniform points, a
+    lattice (every distance tied many times over), clusters of duplicates larger than k (ties must not push closer
+    neighbours out) and clouds smaller than a leaf / than k; and against the round-3 core on the same clouds."""
+    from mr_slam_amd import gicp
+    for name, cloud in _clouds_for_search_tests().items():
+        n = cloud.shape[0]
+        res = {}
+        for core in (1, 0):
+            b = gicp.GicpBatch(1)
+            b.set_search(core)
+            b.set_params(k_correspondences=k)
+            b.set_sources([cloud])
+            res[core] = b.compute_covariances(0, want_knn=True).cpu().numpy()
+            cov = b.covariances(0)
+            assert np.isfinite(cov).all(), (name, core)
+        knn = res[1]
+        kk = min(k, n)
+        assert (knn[:, kk:] == -1).all() and (knn[:, :kk] >= 0).all() and (knn[:, :kk] < n).all(), name
+        assert all(len(set(r[:kk])) == kk for r in knn[:: max(1, n // 500)]), name        # no point twice
+        d = _knn_d2(oracle, cloud, knn[:, :kk])
+        want = _knn_d2(oracle, cloud, oracle.knn(cloud, kk))                               # the restatement's exact kd-tree search
+        assert np.array_equal(d, np.sort(want, 1)), name                                   # same multiset of float distances, ascending
+        # (distance, index) order: among equal distances the indices the caller sees need not ascend (the search orders ties by its
+        # internal Morton index), but the round-3 core must agree on every distance
+        if name not in ("cluster", "same"):      # the round-3 core drops neighbours when > 8 candidates tie at the k-th distance
+            d0 = _knn_d2(oracle, cloud, res[0][:, :kk])
+            assert np.array_equal(d0, d), name
+
+
+def test_correspondences_agree_between_search_cores(dev, oracle):
+    """k_nn_scan_g (round 4) and k_nn_scan (round 3) on the same pairs and poses: the same squared distance for every source point
+    (indices may differ only at exact ties), cold and warm-started, with and without a correspondence threshold."""
+    from mr_slam_amd import gicp
+    src, tgt, Ttrue = _pair(21, 40000)
+    poses = [np.eye(4), Ttrue]
+    for max_corr in (5.0, 0.3, 1e300):
+        got = {}
+        for core in (1, 0):
+            b = gicp.GicpBatch(2)
+            b.set_search(core)
+            b.set_params(max_correspondence_distance=max_corr)
+            b.set_sources([src, src[:777]]); b.set_targets([tgt, tgt[:5000]])
+            out = []
+            for T in poses:                      # the second call is warm-started from the first one's neighbours
+                e, H, bb, corr = b.linearize(np.stack([T, T]), want_corr=True)
+                out.append((e, corr))
+            got[core] = out
+        for (e1, c1), (e0, c0), T in zip(got[1], got[0], poses):
+            for sl, s, t in ((slice(0, src.shape[0]), src, tgt), (slice(src.shape[0], None), src[:777], tgt[:5000])):
+                a = oracle.pair_d2(s, T, t, c1[sl]); bq = oracle.pair_d2(s, T, t, c0[sl])
+                assert np.array_equal(a, bq)
+                assert np.array_equal(c1[sl] >= 0, c0[sl] >= 0)
+            assert (c1 == c0).mean() > 0.999
+            np.testing.assert_allclose(e1, e0, rtol=1e-6)
+
+
+def test_align_identical_between_search_cores(dev):
+    """whole alignments (cold start, LM trials, warm passes): both search cores give the same transforms"""
+    from mr_slam_amd import gicp
+    pairs = [_pair(31 + i, 15000 + 1000 * i) for i in range(3)]
+    out = {}
+    for core in (1, 0):
+        b = gicp.GicpBatch(3)
+        b.set_search(core)
+        b.set_params(k_correspondences=15, max_correspondence_distance=5.0)
+        b.set_sources([p[0] for p in pairs]); b.set_targets([p[1] for p in pairs])
+        out[core] = b.align()
+    assert np.abs(out[1][0] - out[0][0]).max() < 1e-6 and (out[1][2] == out[0][2]).all() and (out[1][1] == out[0][1]).all()
