@@ -315,12 +315,20 @@ int mrs_gicp_batch_fitness(mrs_gicp_batch* h, const double* h_poses, double max_
 double mrs_gicp_batch_last_nn_passes(const mrs_gicp_batch* h);
 
 /* Which exact nearest-neighbour search the batch uses for G2 / G3 (no reference counterpart: upstream fast_gicp searches a
- * kd-tree; both cores return the exact neighbours, ties aside):
- *   1 (default) octree-cell leaves of <= 16 points + groups of 8 queries that share a candidate list (csrc/nn_core.hpp);
- *   0           the round-3 traversal (1024-point tiles / 16-point minis, candidates shared by a whole wave), kept for A/B
+ * kd-tree; every setting returns the exact neighbours, ties aside):
+ *   1 (default) k-NN and correspondence search on octree-cell leaves with per-query culling (csrc/nn_core.hpp); in align() the first
+ *               pass runs the round-3 kernel (a cold search is broad: brute force over fat boxes is at its best there), every later
+ *               pass first CERTIFIES the neighbours of the previous pass (triangle inequality: a query that moved by delta keeps its
+ *               neighbour if that neighbour's new distance is below the old lower bound of every other point's distance - delta)
+ *               and searches only the queries that could not be certified;
+ *   2           like 1 without certificates (every pass searches every point);
+ *   3           like 1 with the round-4 kernel for the first pass as well;
+ *   0           the round-3 traversal everywhere (1024-point tiles / 16-point minis, candidates shared by a whole wave), kept for A/B
  *               measurements and as a cross-check in the tests.
- * Invalidates cached covariances. */
+ * Invalidates cached covariances when the k-NN kernel changes. */
 int mrs_gicp_batch_set_search(mrs_gicp_batch* h, int32_t core);
+/* share of (source point, nearest-neighbour pass) of the last align() that needed a search (1.0 without certificates) */
+double mrs_gicp_batch_last_searched_fraction(const mrs_gicp_batch* h);
 
 /* ------------------------------------------------------------------------------------
  * rocFFT-backed 2-D correlations: DiSCO (rows D1, D2) and RING++ BEV translation (row C4)

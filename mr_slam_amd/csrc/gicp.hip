@@ -79,8 +79,19 @@ struct GicpParams {
     int k;
     double voxel_res;     // > 0: VGICP (voxelised target, G7); 0: GICP
     int voxel_neighbors;  // 1, 7 or 27 (DIRECT1 / DIRECT7 / DIRECT27)
-    int pad;
+    float cert_margin;    // metres the round-4 search looks beyond the neighbour it found (what later passes certify against)
+    float motion_switch;  // round-4 schedule: a pair whose last step moved it farther than this (metres) is searched by the round-3 kernel
+    int pad2;
 };
+
+// How far the last accepted LM increment moved the source cloud: |translation| + rotation angle x 60 m (metres, an upper estimate for
+// points within 60 m of the origin).  Decides which search a pair gets in the round-4 schedule (nn_pass).
+__device__ __forceinline__ float pair_motion(const LmState& S)
+{
+    const double tx = S.delta[3], ty = S.delta[7], tz = S.delta[11];
+    const double c = fmin(fmax(0.5 * (S.delta[0] + S.delta[5] + S.delta[10] - 1.0), -1.0), 1.0);
+    return (float)(sqrt(tx * tx + ty * ty + tz * tz) + 60.0 * sqrt(fmax(2.0 - 2.0 * c, 0.0)));
+}
 
 __device__ __forceinline__ double wave_sum_d(double v)
 {
@@ -881,11 +892,12 @@ __global__ __launch_bounds__(kNNThreads) void k_nn_scan(
     const int* __restrict__ tgt_tile_base, const float4* __restrict__ tlo, const float4* __restrict__ thi,
         const float4* __restrict__ mlo, const float4* __restrict__ mhi,
     const LmState* __restrict__ st, GicpParams prm, int* __restrict__ corr, int* __restrict__ nn_seed,
-    const int* __restrict__ tgt_bbox)
+    const int* __restrict__ tgt_bbox, float* __restrict__ lb_out, int gate)
 {
     const int pair = blockIdx.y;
     const LmState& S = st[pair];
     if (!S.active || S.phase != 0) return;   // LM trials reuse the cached correspondences (upstream compute_error)
+    if (gate && !(pair_motion(S) > prm.motion_switch)) return;   // round-4 schedule: this pair is certified / searched by k_nn_scan_g
     const int64_t so = src_offs[pair], to = tgt_offs[pair];
     const int n = (int)(src_offs[pair + 1] - so), m = (int)(tgt_offs[pair + 1] - to);
     const float4* src = src_all + so;
@@ -925,6 +937,7 @@ __global__ __launch_bounds__(kNNThreads) void k_nn_scan(
             if (live[p]) {
                 corr[so + si[p]] = (bidx[p] >= 0 && (double)best[p] < prm.max_corr2) ? bidx[p] : -1;
                 nn_seed[so + si[p]] = bidx[p];
+                if (lb_out) lb_out[so + si[p]] = 0.0f;     // this search leaves no certificate
             }
     }
 }
@@ -1044,52 +1057,209 @@ __device__ __forceinline__ nnc::LeafHier cloud_hier(const HierArrays& A, int c)
     return H;
 }
 
-constexpr int kGS = 8;   // queries per group (nn_core.hpp)
-
 // G3a, round 4: exact 1-NN of every (float-)transformed source point.  One query per lane; semantics of k_nn_scan (corr = target index in
 // sorted space or -1 when d^2 >= max_corr^2; nn_seed = the neighbour found, warm start of the next pass), ties to the smaller index.
-template <int GS>
-__global__ __launch_bounds__(kNNThreads) void k_nn_scan_g(
-    const float4* __restrict__ src_all, const int64_t* __restrict__ src_offs,
-    const float4* __restrict__ tgt_all, const int64_t* __restrict__ tgt_offs, HierArrays HA,
-    const LmState* __restrict__ st, GicpParams prm, int* __restrict__ corr, int* __restrict__ nn_seed,
-    const int* __restrict__ tgt_bbox)
+// Certificates (round 4).  After a search the lane knows lb = a lower bound of the distance from its query to every target point OTHER
+// than the neighbour found: the second smallest distance it evaluated, or the radius it searched (neighbour distance + a margin), whichever
+// is smaller.  When the pose changes, a query moves by delta = |T_new a - T_prev a|, so every other point is still at least lb - delta
+// away; if the old neighbour's new distance is below that, it is still THE nearest neighbour -- exactly, by the triangle inequality --
+// and no search is needed (k_nn_certify).  Queries that cannot be certified go to a per-pair work list and are searched as before.
+// Late iterations of an alignment move the cloud by less than the gap between a point's nearest and second nearest neighbour, so most of
+// their passes reduce to one streaming kernel.  Float evaluation error is covered by a relative 1e-5 + absolute 1e-6 m slack on both
+// sides; an exact tie (two points at one distance) leaves no gap and is always searched, so ties still resolve to the smaller index.
+struct CertArrays {
+    float* lb;             // [source points] lower bound described above (0: none)
+    float* t_prev;         // [pairs][12] pose of the pair's last nearest-neighbour pass (float, like the searches use it)
+    int* work;             // [source points] per pair (at the pair's source offset): source indices that need a search
+    int* bcount;           // [pairs][nb] entries in the work list of each block of 1024 consecutive source points (its list starts at the block)
+    int nb;                // blocks of the longest source cloud
+    unsigned long long* searched;   // [2] statistics of an align(): queries searched, queries due (points of the pairs that searched, per pass)
+};
+
+__device__ __forceinline__ void pose_f(const LmState& S, float (&Tf)[12])
 {
-    __shared__ nnc::GrpLds<GS> lds[kNNThreads / 64];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Tf[i] = (float)S.x[i];
+}
+
+constexpr int kCertBlock = 1024;   // consecutive source points whose uncertified members form one work list (searched by one workgroup)
+
+// One workgroup per 1024 consecutive source points of every pair that is about to search: certify the old neighbour or put the point on
+// the block's work list, in index order (lists of consecutive points keep the search's waves spatially compact; appended with atomics in
+// completion order, the waves of a sparse list spanned the whole cloud and tested ~1000 tiles each).
+__global__ __launch_bounds__(256) void k_nn_certify(const float4* __restrict__ src_all, const int64_t* __restrict__ src_offs,
+                                                   const float4* __restrict__ tgt_all, const int64_t* __restrict__ tgt_offs,
+                                                   const LmState* __restrict__ st, GicpParams prm, int* __restrict__ corr,
+                                                   const int* __restrict__ nn_seed, CertArrays C)
+{
+    __shared__ int wcnt[16];
     const int pair = blockIdx.y;
     const LmState& S = st[pair];
     if (!S.active || S.phase != 0) return;
+    if (pair_motion(S) > prm.motion_switch) return;      // a pair that moved this far goes to the round-3 kernel (nn_pass)
     const int64_t so = src_offs[pair], to = tgt_offs[pair];
     const int n = (int)(src_offs[pair + 1] - so), m = (int)(tgt_offs[pair + 1] - to);
+    const int b0 = (int)blockIdx.x * kCertBlock;
+    if (b0 >= n) return;
+    const float4* src = src_all + so;
+    const float4* tgt = tgt_all + to;
+    float Tf[12], Tp[12];
+    pose_f(S, Tf);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Tp[i] = C.t_prev[12 * pair + i];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int rank[4];
+    bool need[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = b0 + j * 256 + (int)threadIdx.x;
+        const bool live = i < n;
+        bool certified = false;
+        if (live) {
+            const float4 a = src[i];
+            const float qx = Tf[0] * a.x + Tf[1] * a.y + Tf[2] * a.z + Tf[3];
+            const float qy = Tf[4] * a.x + Tf[5] * a.y + Tf[6] * a.z + Tf[7];
+            const float qz = Tf[8] * a.x + Tf[9] * a.y + Tf[10] * a.z + Tf[11];
+            const float px = Tp[0] * a.x + Tp[1] * a.y + Tp[2] * a.z + Tp[3];
+            const float py = Tp[4] * a.x + Tp[5] * a.y + Tp[6] * a.z + Tp[7];
+            const float pz = Tp[8] * a.x + Tp[9] * a.y + Tp[10] * a.z + Tp[11];
+            const int seed = nn_seed[so + i];
+            const float lb = C.lb[so + i];
+            if (seed >= 0 && seed < m && lb > 0.0f) {
+                const float dx = qx - px, dy = qy - py, dz = qz - pz;
+                const float delta = sqrtf(dx * dx + dy * dy + dz * dz);
+                const float lbn = lb - delta * 1.00001f - 1e-6f;
+                const float d1sq = dist2(qx, qy, qz, tgt[seed]);
+                if (sqrtf(d1sq) * 1.00001f + 1e-6f < lbn) {       // (false for NaN)
+                    certified = true;
+                    corr[so + i] = (double)d1sq < prm.max_corr2 ? seed : -1;
+                    C.lb[so + i] = lbn;
+                }
+            }
+        }
+        need[j] = live && !certified;
+        const unsigned long long mk = __ballot(need[j]);
+        rank[j] = (int)__popcll(mk & ((1ull << lane) - 1ull));
+        if (lane == 0) wcnt[j * 4 + wave] = (int)__popcll(mk);
+    }
+    __syncthreads();
+    int total = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int off = 0;
+        for (int u = 0; u < j * 4 + wave; ++u) off += wcnt[u];
+        if (need[j]) C.work[so + b0 + off + rank[j]] = b0 + j * 256 + (int)threadIdx.x;
+    }
+    if (threadIdx.x == 0) {
+        for (int u = 0; u < 16; ++u) total += wcnt[u];
+        C.bcount[(size_t)pair * C.nb + blockIdx.x] = total;
+        const int members = min(kCertBlock, n - b0);
+        atomicAdd(&C.searched[0], (unsigned long long)(2 * total > members ? members : total));
+        atomicAdd(&C.searched[1], (unsigned long long)members);
+    }
+}
+
+// the pose of this pass becomes t_prev of every pair that searched; the work-list sizes go to the statistics
+__global__ void k_nn_store_pose(const LmState* __restrict__ st, int n_pairs, CertArrays C, int worklists, const int64_t* __restrict__ src_offs,
+                                float motion_switch)
+{
+    const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= n_pairs) return;
+    const LmState& S = st[pair];
+    if (!S.active || S.phase != 0) return;
+    float Tf[12];
+    pose_f(S, Tf);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) C.t_prev[12 * pair + i] = Tf[i];
+    const int n_src = (int)(src_offs[pair + 1] - src_offs[pair]);
+    if (worklists && !(pair_motion(S) > motion_switch)) return;        // counted block by block in k_nn_certify
+    atomicAdd(&C.searched[0], (unsigned long long)n_src);
+    atomicAdd(&C.searched[1], (unsigned long long)n_src);
+}
+
+// G3a, round 4: exact 1-NN of every (float-)transformed source point.  One query per lane; semantics of k_nn_scan (corr = target index in
+// sorted space or -1 when d^2 >= max_corr^2; nn_seed = the neighbour found, warm start of the next pass), ties to the smaller index.
+// WORK: the queries are the entries of the pair's work list (k_nn_certify) instead of all source points.  Always leaves the certificate
+// bound of every query it searched in C.lb.
+template <bool PROF, bool WORK>
+__global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_nn_scan_g(
+    const float4* __restrict__ src_all, const int64_t* __restrict__ src_offs,
+    const float4* __restrict__ tgt_all, const int64_t* __restrict__ tgt_offs, HierArrays HA,
+    const LmState* __restrict__ st, GicpParams prm, int* __restrict__ corr, int* __restrict__ nn_seed,
+    const int* __restrict__ tgt_bbox, CertArrays C)
+{
+    __shared__ nnc::GrpLds lds[kNNThreads / 64];
+    const int pair = blockIdx.y;
+    const LmState& S = st[pair];
+    if (!S.active || S.phase != 0) return;
+    if (WORK && pair_motion(S) > prm.motion_switch) return;
+    const int64_t so = src_offs[pair], to = tgt_offs[pair];
+    const int n_src = (int)(src_offs[pair + 1] - so), m = (int)(tgt_offs[pair + 1] - to);
+    // one workgroup per block of 1024 consecutive source points: its work list, or (no lists, or more than half of the block listed) all of it
+    const int b0 = (int)blockIdx.x * kCertBlock;
+    if (b0 >= n_src) return;
+    const int members = min(kCertBlock, n_src - b0);
+    const int listed_n = WORK ? C.bcount[(size_t)pair * C.nb + blockIdx.x] : members;
+    const bool listed = WORK && 2 * listed_n <= members;
+    const int n = listed ? listed_n : members;
     const float4* src = src_all + so;
     const float4* tgt = tgt_all + to;
     const nnc::LeafHier H = cloud_hier(HA, pair);
     const float maxc2 = prm.max_corr2 < 3.0e38 ? (float)prm.max_corr2 * 1.0001f : INFINITY;
     float Tf[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) Tf[i] = (float)S.x[i];
+    pose_f(S, Tf);
     float glo[3];
     const float gsc = morton_grid(tgt_bbox, pair, glo);
-    nnc::GrpLds<GS>& L = lds[threadIdx.x >> 6];
-    for (int base = blockIdx.x * kNNThreads; base < n; base += gridDim.x * kNNThreads) {
-        const int i = base + (int)threadIdx.x;
-        const bool live = i < n;
-        const float4 a = src[live ? i : 0];
+    nnc::GrpLds& L = lds[threadIdx.x >> 6];
+    for (int base = 0; base < n; base += kNNThreads) {
+        const unsigned long long t_wave = PROF ? __builtin_readcyclecounter() : 0ull;
+        const int w = base + (int)threadIdx.x;
+        const bool live = w < n;
+        const int i = listed ? C.work[so + b0 + (live ? w : 0)] : b0 + (live ? w : 0);
+        const float4 a = src[i];
         const float qx = Tf[0] * a.x + Tf[1] * a.y + Tf[2] * a.z + Tf[3];
         const float qy = Tf[4] * a.x + Tf[5] * a.y + Tf[6] * a.z + Tf[7];
         const float qz = Tf[8] * a.x + Tf[9] * a.y + Tf[10] * a.z + Tf[11];
+        // margin of the search radius beyond the neighbour's distance: what a later pass may certify against.  The volume searched grows
+        // with the cube of the radius, so it stays small: it pays in the late passes of an alignment, where a point moves by well under a
+        // millimetre per pass (a 6 cm margin made the searches of the early passes 70 times as long and certified nothing there)
+        const float margin = prm.cert_margin;
         int seed = live ? nn_seed[so + i] : -1;
         if (live && seed < 0 && m > 0) seed = morton_seed(tgt, m, qx, qy, qz, glo, gsc);   // cold start
-        float limv = maxc2;    // any target point is an upper bound: last pass's neighbour is nearly always the winner again
-        if (live && seed >= 0 && seed < m) limv = fminf(limv, dist2(qx, qy, qz, tgt[seed]));
-        float best = INFINITY;
+        // any target point is an upper bound: last pass's neighbour is nearly always the winner again.  Its distance is formed inside the
+        // search's first radius evaluation, after the search has requested the top of the hierarchy: the two loads overlap
+        const bool has_seed = live && seed >= 0 && seed < m;
+        const float4 sp = tgt[has_seed ? seed : 0];
+        float best = INFINITY, second = INFINITY;
         int bidx = -1;
-        nnc::grp_search<GS>(tgt, H, L, qx, qy, qz, live,
-                            [&]() { return fminf(limv, best); },
-                            [&](int j, float d, bool) { if (d < best) { best = d; bidx = j; } });
+        nnc::Prof prof;
+        const unsigned long long t_in = PROF ? __builtin_readcyclecounter() : 0ull;
+        auto radius2 = [&]() {       // squared search radius: (distance of the best candidate so far + margin)^2, capped by the threshold
+            const float r = sqrtf(fminf(has_seed ? dist2(qx, qy, qz, sp) : INFINITY, best)) + margin;
+            return fminf(maxc2, r * r);
+        };
+        nnc::grp_search<PROF>(tgt, H, L, qx, qy, qz, live, radius2,
+                              [&](int j, float d, bool ok) {
+                                  if (!ok) return;
+                                  second = __builtin_amdgcn_fmed3f(best, d, second);      // second smallest of everything evaluated
+                                  if (d < best) { best = d; bidx = j; }
+                              }, &prof);
+        if (PROF) {
+            const unsigned long long t_out = __builtin_readcyclecounter();
+            if ((threadIdx.x & 63) == 0) {
+                atomicAdd(&nnc::g_prof[0], 1ull); atomicAdd(&nnc::g_prof[1], t_in - t_wave); atomicAdd(&nnc::g_prof[2], prof.cyc_top);
+                atomicAdd(&nnc::g_prof[3], prof.cyc_leaf); atomicAdd(&nnc::g_prof[4], prof.cyc_drain); atomicAdd(&nnc::g_prof[5], prof.tiles_near);
+                atomicAdd(&nnc::g_prof[6], prof.tiles_needed); atomicAdd(&nnc::g_prof[7], prof.grp_tiles); atomicAdd(&nnc::g_prof[8], prof.query_tests);
+                atomicAdd(&nnc::g_prof[9], prof.queued); atomicAdd(&nnc::g_prof[10], prof.batches); atomicAdd(&nnc::g_prof[12], prof.drains);
+                atomicAdd(&nnc::g_prof[13], t_out - t_wave); atomicMax(&nnc::g_prof[14], t_out - t_wave);
+            }
+            if ((threadIdx.x & 63) == 63) atomicAdd(&nnc::g_prof[11], prof.staged);
+        }
         if (live) {
             corr[so + i] = (bidx >= 0 && (double)best < prm.max_corr2) ? bidx : -1;
             nn_seed[so + i] = bidx;
+            // every point that was not evaluated lies beyond the final radius (radii only shrink while the search runs)
+            C.lb[so + i] = bidx >= 0 ? fminf(sqrtf(second), sqrtf(radius2()) * 0.9999f) : 0.0f;
         }
     }
 }
@@ -1110,19 +1280,20 @@ __device__ __forceinline__ float kth_of(const float (&dk)[KMAX], int k)
 // within tau, strictly closer ones from the bottom of a k-slot LDS list, exact ties from its top (they arrive in ascending index order, and a
 // tie is only kept while the list still has room for it: at most k - #closer can be needed), so a cluster of duplicates can neither
 // overflow the list nor push a closer point out; selection: (distance, index) insertion of the <= k collected.
-template <int KMAX, int GS>
+template <int KMAX>
 __global__ __launch_bounds__(kNNThreads) void k_knn_select(const float4* __restrict__ pts_all, const int64_t* __restrict__ offs, HierArrays HA,
                                                            int k, int* __restrict__ knn)
 {
-    __shared__ nnc::GrpLds<GS> lds[kNNThreads / 64];
+    __shared__ nnc::GrpLds lds[kNNThreads / 64];
     __shared__ int lst[KMAX * kNNThreads];          // slot-major: slot s of lane t at lst[s * kNNThreads + t]
     const int c = blockIdx.y;
     const int64_t o = offs[c];
     const int n = (int)(offs[c + 1] - o);
     const float4* pts = pts_all + o;
     const nnc::LeafHier H = cloud_hier(HA, c);
-    nnc::GrpLds<GS>& L = lds[threadIdx.x >> 6];
+    nnc::GrpLds& L = lds[threadIdx.x >> 6];
     constexpr int HS = KMAX <= 16 ? 32 : 64;
+    constexpr int GS = 8;
     const int tid = (int)threadIdx.x;
     for (int base = blockIdx.x * kNNThreads; base < n; base += gridDim.x * kNNThreads) {
         const int i = base + tid;
@@ -1134,9 +1305,9 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_select(const float4* __restr
         // seed phase: HS consecutive points around the group's queries
         const int hc = min(HS, n);
         const int h0 = max(0, min(base + (tid & ~(GS - 1)) + GS / 2 - HS / 2, n - hc));
-        nnc::grp_eval_range<GS>(pts, q.x, q.y, q.z, h0, hc, [&](int, float d, bool ok) { dist_insert<KMAX>(dk, (ok && live && d == d) ? d : INFINITY); });
+        nnc::grp_eval_range(pts, L, q.x, q.y, q.z, h0, hc, [&](int, float d, bool ok) { dist_insert<KMAX>(dk, (ok && live && d == d) ? d : INFINITY); });
         // pass 1: the k-th distance
-        nnc::grp_search<GS>(pts, H, L, q.x, q.y, q.z, live, [&]() { return kth_of<KMAX>(dk, k); },
+        nnc::grp_search(pts, H, L, q.x, q.y, q.z, live, [&]() { return kth_of<KMAX>(dk, k); },
                             [&](int j, float d, bool ok) {
                                 const bool use = ok && live && (unsigned)(j - h0) >= (unsigned)hc && d == d;
                                 dist_insert<KMAX>(dk, use ? d : INFINITY);
@@ -1144,7 +1315,7 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_select(const float4* __restr
         const float tau = live ? kth_of<KMAX>(dk, k) : -1.0f;
         // pass 2: indices within tau
         int nlt = 0, ntie = 0;
-        nnc::grp_search<GS>(pts, H, L, q.x, q.y, q.z, live, [&]() { return tau; },
+        nnc::grp_search(pts, H, L, q.x, q.y, q.z, live, [&]() { return tau; },
                             [&](int j, float d, bool ok) {
                                 if (!(ok && live)) return;
                                 if (d < tau) {
@@ -1553,7 +1724,8 @@ __device__ void propose(LmState& S)
 //   phase 0 result = linearize(x0): H, b, y0 -> first LM candidate, phase 1
 //   phase 1 result = compute_error(delta * x0) on the cached correspondences -> rho -> accept (x0 <- xi, next
 //   outer iteration linearises again: phase 0) or reject (lambda *= nu, next candidate, stay in phase 1)
-// n_next[0] counts the pairs that need a linearisation next tick, n_next[1] the pairs in an LM trial.
+// n_next[0] counts the pairs that need a linearisation next tick, n_next[1] the pairs in an LM trial, n_next[2] those of [0] that moved
+// farther than prm.motion_switch in the step just accepted.
 __global__ void k_lm_update(LmState* __restrict__ st, const double* __restrict__ partial, const int* __restrict__ nblocks,
                             int max_blocks, GicpParams prm, int* __restrict__ n_next)
 {
@@ -1628,6 +1800,7 @@ __global__ void k_lm_update(LmState* __restrict__ st, const double* __restrict__
         }
     }
     if (S.active) atomicAdd(&n_next[S.phase == 0 ? 0 : 1], 1);
+    if (S.active && S.phase == 0 && pair_motion(S) > prm.motion_switch) atomicAdd(&n_next[2], 1);   // pairs whose next search is a broad one
 }
 
 // G6: fitness partials: [pair][block][2] = (sum of d^2 <= max_range, count)
@@ -1756,6 +1929,11 @@ struct mrs_gicp_batch {
     int cap_leaves[2] = {0, 0}, cap_tiles2[2] = {0, 0}, cap_supers[2] = {0, 0};
     int n_leaves[2] = {0, 0};
     int search_core = 1;            // 1: octree leaves + query groups (round 4), 0: round-3 wave-shared traversal (A/B, cross-check)
+    int cold_core = 0;              // search_core 1: kernel of the FIRST pass of an align() (0: round-3 kernel, 1: round-4 kernel)
+    bool use_certificates = true;   // search_core 1: certify unchanged neighbours before searching (k_nn_certify)
+    CertArrays cert = {nullptr, nullptr, nullptr, nullptr, 0, nullptr};
+    double last_searched = 0;       // share of (source point, pass) that needed a search in the last align()
+    int big_movers = 1;             // pairs whose last step exceeded motion_switch (counted by k_lm_update): do they need the round-3 kernel?
     HierArrays hier(int w) const
     {
         return HierArrays{d_llo[w], d_lhi[w], d_t2lo[w], d_t2hi[w], d_slo[w], d_shi[w], d_leaf_first[w], d_tile_first[w], d_super_first[w]};
@@ -1832,15 +2010,28 @@ int build_leaf_hier(mrs_gicp_batch* h, int w, const unsigned long long* d_keys, 
     hipLaunchKernelGGL(nnc::k_leaf_first, dim3((P + 1 + 255) / 256), dim3(256), 0, s, head.as<int>(), leafid.as<int>(), h->d_offs[w], P,
                        h->d_leaf_first[w]);
     MRS_HIP_TRY(hipGetLastError());
+    // tiles: octree cells of <= 256 points (every leaf cell lies inside one of them)
+    mrs::Scratch tpre, thead, tid;
+    if ((st = tpre.alloc((size_t)total, s)) != MRS_OK) return st;
+    if ((st = thead.alloc((size_t)total * sizeof(int), s)) != MRS_OK) return st;
+    if ((st = tid.alloc((size_t)total * sizeof(int), s)) != MRS_OK) return st;
+    hipLaunchKernelGGL(nnc::k_tile_prefix, dim3(fb), dim3(256), 0, s, d_keys, (size_t)total, tpre.as<signed char>());
+    hipLaunchKernelGGL(nnc::k_tile_heads, dim3((unsigned)std::min<int64_t>((total + 1023) / 1024, 16384)), dim3(1024), 0, s, d_keys,
+                       (const signed char*)tpre.as<signed char>(), (size_t)total, thead.as<int>());
+    MRS_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, b2, thead.as<int>(), tid.as<int>(), (int)total, s));
+    hipLaunchKernelGGL(nnc::k_leaf_first, dim3((P + 1 + 255) / 256), dim3(256), 0, s, thead.as<int>(), tid.as<int>(), h->d_offs[w], P,
+                       h->d_tile_first[w]);
+    MRS_HIP_TRY(hipGetLastError());
     std::vector<int> lf(P + 1), tf(P + 1), sf(P + 1);
     MRS_HIP_TRY(hipMemcpyAsync(lf.data(), h->d_leaf_first[w], lf.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+    MRS_HIP_TRY(hipMemcpyAsync(tf.data(), h->d_tile_first[w], tf.size() * sizeof(int), hipMemcpyDeviceToHost, s));
     MRS_HIP_TRY(hipStreamSynchronize(s));
-    int most_tiles = 0, most_supers = 0;
-    tf[0] = sf[0] = 0;
+    int most_supers = 0;
+    sf[0] = 0;
     for (int c = 0; c < P; ++c) {
-        const int nl = lf[c + 1] - lf[c], nt = (nl + 63) / 64, ns = (nt + 63) / 64;
-        tf[c + 1] = tf[c] + nt; sf[c + 1] = sf[c] + ns;
-        most_tiles = std::max(most_tiles, nt); most_supers = std::max(most_supers, ns);
+        const int nt = tf[c + 1] - tf[c], ns = (nt + 63) / 64;
+        sf[c + 1] = sf[c] + ns;
+        most_supers = std::max(most_supers, ns);
     }
     h->n_leaves[w] = lf[P];
     auto grow = [](float4*& a, float4*& b, int& cap, int need) -> hipError_t {
@@ -1855,16 +2046,74 @@ int build_leaf_hier(mrs_gicp_batch* h, int w, const unsigned long long* d_keys, 
     MRS_HIP_TRY(grow(h->d_llo[w], h->d_lhi[w], h->cap_leaves[w], lf[P]));
     MRS_HIP_TRY(grow(h->d_t2lo[w], h->d_t2hi[w], h->cap_tiles2[w], tf[P]));
     MRS_HIP_TRY(grow(h->d_slo[w], h->d_shi[w], h->cap_supers[w], sf[P]));
-    MRS_HIP_TRY(hipMemcpyAsync(h->d_tile_first[w], tf.data(), tf.size() * sizeof(int), hipMemcpyHostToDevice, s));
     MRS_HIP_TRY(hipMemcpyAsync(h->d_super_first[w], sf.data(), sf.size() * sizeof(int), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(nnc::k_leaf_boxes, dim3(fb), dim3(256), 0, s, (const float4*)h->d_pts[w], d_keys, head.as<int>(), leafid.as<int>(),
                        h->d_offs[w], (size_t)total, h->d_llo[w], h->d_lhi[w]);
-    hipLaunchKernelGGL(nnc::k_group_boxes, dim3(most_tiles, P), dim3(64), 0, s, (const float4*)h->d_llo[w], (const float4*)h->d_lhi[w],
-                       (const int*)h->d_leaf_first[w], (const int*)h->d_tile_first[w], h->d_t2lo[w], h->d_t2hi[w]);
+    hipLaunchKernelGGL(nnc::k_tile_boxes, dim3(fb), dim3(256), 0, s, d_keys, (const int*)thead.as<int>(), (const int*)tid.as<int>(),
+                       (const int*)head.as<int>(), (const int*)leafid.as<int>(), (const int*)h->d_leaf_first[w], (const int64_t*)h->d_offs[w],
+                       (size_t)total, (const float4*)h->d_llo[w], (const float4*)h->d_lhi[w], h->d_t2lo[w], h->d_t2hi[w]);
     hipLaunchKernelGGL(nnc::k_group_boxes, dim3(most_supers, P), dim3(64), 0, s, (const float4*)h->d_t2lo[w], (const float4*)h->d_t2hi[w],
                        (const int*)h->d_tile_first[w], (const int*)h->d_super_first[w], h->d_slo[w], h->d_shi[w]);
     MRS_HIP_TRY(hipGetLastError());
     MRS_HIP_TRY(hipStreamSynchronize(s));     // tf / sf are temporaries
+    return MRS_OK;
+}
+
+// k_nn_scan_g, or its instrumented twin under MRS_DEV=1 MRS_NN_PROF=1 (per-launch phase cycles and event counts on stderr; synchronises)
+template <bool WORK, class... Args>
+void launch_nn_scan_g(dim3 grid, hipStream_t s, Args... args)
+{
+    static const bool prof = mrs::dev_env("MRS_NN_PROF") != nullptr;
+    if (!prof) {
+        hipLaunchKernelGGL((k_nn_scan_g<false, WORK>), grid, dim3(kNNThreads), 0, s, args...);
+        return;
+    }
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(nnc::g_prof), z, sizeof(z));
+    hipLaunchKernelGGL((k_nn_scan_g<true, WORK>), grid, dim3(kNNThreads), 0, s, args...);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(nnc::g_prof), sizeof(z));
+    const double w = (double)(z[0] ? z[0] : 1);
+    fprintf(stderr, "[nn prof] %llu waves%s: cycles/wave total %.0f (max %llu) = setup %.0f + top %.0f + leaf %.0f + drain %.0f; per wave: tiles near %.1f needed %.1f, "
+                    "(group,tile) %.1f, query-vs-leaves tests %.1f, leaves queued %.1f, drains %.2f, batches %.2f, staged points (max group) %.1f\n",
+            z[0], WORK ? " (work list)" : "", z[13] / w, z[14], z[1] / w, z[2] / w, z[3] / w, z[4] / w, z[5] / w, z[6] / w, z[7] / w, z[8] / w, z[9] / w, z[12] / w, z[10] / w, z[11] / w);
+}
+
+// One nearest-neighbour pass for every pair in phase 0 (h->d_state): fills h->d_corr / h->d_seed.
+// mode 0: first pass of an align(), 1: later pass, 2: one plain search with the selected core (linearize hook).
+// search_core 0: the round-3 kernel, every point, every pass.  search_core 1 (round-4 schedule):
+//   * first pass, and every pair whose last step moved it by more than prm.motion_switch: the round-3 kernel -- a search whose radius
+//     is decimetres is a broad search, and brute force over fat minis is at its best there (measured: 17 against 26 ms for 5 cold
+//     passes of 64 pairs); it leaves no certificates;
+//   * the other pairs: certify the previous pass's neighbours, search what could not be certified (k_nn_scan_g leaves certificates).
+int nn_pass(mrs_gicp_batch* h, int mode, hipStream_t s)
+{
+    const dim3 wg((unsigned)((h->longest_src + kCertBlock - 1) / kCertBlock), h->n_pairs);      // one workgroup per 1024 source points
+    const dim3 pg((h->n_pairs + 255) / 256);
+    auto round3 = [&](int gate) {
+        launch_nn_scan(h->longest_src, h->n_pairs, h->ctx->num_cu, s, h->d_pts[0], h->d_offs[0], h->d_pts[1], h->d_offs[1],
+                       h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_mlo[1], h->d_mhi[1], h->d_state, h->prm, h->d_corr, h->d_seed,
+                       (const int*)h->d_bbox[1], h->search_core == 1 ? h->cert.lb : (float*)nullptr, gate);
+    };
+    if (h->search_core == 0) {
+        round3(0);
+    } else if (mode == 0 && h->cold_core == 0) {
+        round3(0);
+        hipLaunchKernelGGL(k_nn_store_pose, pg, dim3(256), 0, s, (const LmState*)h->d_state, h->n_pairs, h->cert, 0, (const int64_t*)h->d_offs[0], h->prm.motion_switch);
+    } else if (mode != 1 || !h->use_certificates) {
+        launch_nn_scan_g<false>(wg, s, (const float4*)h->d_pts[0], (const int64_t*)h->d_offs[0], (const float4*)h->d_pts[1], (const int64_t*)h->d_offs[1],
+                                h->hier(1), (const LmState*)h->d_state, h->prm, h->d_corr, h->d_seed, (const int*)h->d_bbox[1], h->cert);
+        hipLaunchKernelGGL(k_nn_store_pose, pg, dim3(256), 0, s, (const LmState*)h->d_state, h->n_pairs, h->cert, 0, (const int64_t*)h->d_offs[0], h->prm.motion_switch);
+    } else {
+        if (h->big_movers > 0) round3(1);
+        hipLaunchKernelGGL(k_nn_certify, wg, dim3(256), 0, s, (const float4*)h->d_pts[0],
+                           (const int64_t*)h->d_offs[0], (const float4*)h->d_pts[1], (const int64_t*)h->d_offs[1], (const LmState*)h->d_state, h->prm,
+                           h->d_corr, (const int*)h->d_seed, h->cert);
+        launch_nn_scan_g<true>(wg, s, (const float4*)h->d_pts[0], (const int64_t*)h->d_offs[0], (const float4*)h->d_pts[1], (const int64_t*)h->d_offs[1],
+                               h->hier(1), (const LmState*)h->d_state, h->prm, h->d_corr, h->d_seed, (const int*)h->d_bbox[1], h->cert);
+        hipLaunchKernelGGL(k_nn_store_pose, pg, dim3(256), 0, s, (const LmState*)h->d_state, h->n_pairs, h->cert, 1, (const int64_t*)h->d_offs[0], h->prm.motion_switch);
+    }
+    MRS_HIP_TRY(hipGetLastError());
     return MRS_OK;
 }
 
@@ -1876,11 +2125,11 @@ int launch_knn_select(mrs_gicp_batch* h, int w, int k, int* d_knn, hipStream_t s
     const dim3 grid((unsigned)((longest + kNNThreads - 1) / kNNThreads), h->n_pairs);
     const HierArrays HA = h->hier(w);
     if (k <= 16)
-        hipLaunchKernelGGL((k_knn_select<16, kGS>), grid, dim3(kNNThreads), 0, s, (const float4*)h->d_pts[w], (const int64_t*)h->d_offs[w], HA, k, d_knn);
+        hipLaunchKernelGGL((k_knn_select<16>), grid, dim3(kNNThreads), 0, s, (const float4*)h->d_pts[w], (const int64_t*)h->d_offs[w], HA, k, d_knn);
     else if (k <= 20)
-        hipLaunchKernelGGL((k_knn_select<20, kGS>), grid, dim3(kNNThreads), 0, s, (const float4*)h->d_pts[w], (const int64_t*)h->d_offs[w], HA, k, d_knn);
+        hipLaunchKernelGGL((k_knn_select<20>), grid, dim3(kNNThreads), 0, s, (const float4*)h->d_pts[w], (const int64_t*)h->d_offs[w], HA, k, d_knn);
     else
-        hipLaunchKernelGGL((k_knn_select<32, kGS>), grid, dim3(kNNThreads), 0, s, (const float4*)h->d_pts[w], (const int64_t*)h->d_offs[w], HA, k, d_knn);
+        hipLaunchKernelGGL((k_knn_select<32>), grid, dim3(kNNThreads), 0, s, (const float4*)h->d_pts[w], (const int64_t*)h->d_offs[w], HA, k, d_knn);
     MRS_HIP_TRY(hipGetLastError());
     return MRS_OK;
 }
@@ -1892,11 +2141,17 @@ extern "C" {
 int mrs_gicp_batch_set_search(mrs_gicp_batch* h, int32_t core)
 {
     MRS_REQUIRE(h, "null handle");
-    MRS_REQUIRE(core == 0 || core == 1, "core must be 0 (round-3 wave-shared traversal) or 1 (octree leaves + query groups)");
-    if (core != h->search_core) h->cov_valid[0] = h->cov_valid[1] = false;
-    h->search_core = core;
+    MRS_REQUIRE(core >= 0 && core <= 3, "core must be 0 .. 3");
+    const int base = core == 0 ? 0 : 1;
+    if (base != h->search_core) h->cov_valid[0] = h->cov_valid[1] = false;
+    h->search_core = base;
+    h->use_certificates = core == 1;
+    h->cold_core = core == 3 ? 1 : 0;
+    if (core == 3) h->use_certificates = true;
     return MRS_OK;
 }
+
+double mrs_gicp_batch_last_searched_fraction(const mrs_gicp_batch* h) { return h ? h->last_searched : 1.0; }
 
 void mrs_gicp_default_params(mrs_gicp_params* p)
 {
@@ -1942,6 +2197,8 @@ int mrs_gicp_batch_destroy(mrs_gicp_batch* h)
     if (h->d_nactive) (void)hipFree(h->d_nactive);
     if (h->d_corr) (void)hipFree(h->d_corr);
     if (h->d_seed) (void)hipFree(h->d_seed);
+    for (void* p : {(void*)h->cert.lb, (void*)h->cert.work, (void*)h->cert.t_prev, (void*)h->cert.bcount, (void*)h->cert.searched})
+        if (p) (void)hipFree(p);
     if (h->d_vkeys) (void)hipFree(h->d_vkeys);
     if (h->d_vmean) (void)hipFree(h->d_vmean);
     if (h->d_vcov) (void)hipFree(h->d_vcov);
@@ -1969,6 +2226,10 @@ int mrs_gicp_batch_set_params(mrs_gicp_batch* h, const mrs_gicp_params* p)
     h->prm.force_iters = p->force_iterations;
     MRS_REQUIRE(p->voxel_resolution >= 0.0, "voxel_resolution must be >= 0");
     MRS_REQUIRE(p->voxel_neighbors == 1 || p->voxel_neighbors == 7 || p->voxel_neighbors == 27, "voxel_neighbors must be 1, 7 or 27");
+    h->prm.cert_margin = 0.004f;
+    h->prm.motion_switch = 0.02f;
+    { const char* e = mrs::dev_env("MRS_MOTION_SWITCH"); if (e) h->prm.motion_switch = (float)atof(e); }
+    { const char* e = mrs::dev_env("MRS_CERT_MARGIN"); if (e) h->prm.cert_margin = (float)atof(e); }
     h->prm.voxel_res = p->voxel_resolution;
     h->prm.voxel_neighbors = p->voxel_neighbors;
     return MRS_OK;
@@ -1983,7 +2244,7 @@ int mrs_gicp_batch_set_clouds(mrs_gicp_batch* h, int32_t which, const float* d_p
     MRS_REQUIRE(h_offsets[0] == 0, "offsets[0] must be 0");
     for (int i = 0; i < h->n_pairs; ++i) {
         MRS_REQUIRE(h_offsets[i + 1] > h_offsets[i], "every cloud needs at least one point");
-        MRS_REQUIRE(h_offsets[i + 1] - h_offsets[i] < (1ll << 30), "cloud too large");
+        MRS_REQUIRE(h_offsets[i + 1] - h_offsets[i] < (1ll << 28), "cloud too large (2^28 points at most)");
     }
     MRS_HIP_TRY(hipSetDevice(h->ctx->device));
     hipStream_t s = (hipStream_t)stream;
@@ -2026,6 +2287,16 @@ int mrs_gicp_batch_set_clouds(mrs_gicp_batch* h, int32_t which, const float* d_p
             h->d_corr = nullptr; h->d_seed = nullptr;
             MRS_HIP_TRY(hipMalloc(&h->d_corr, (size_t)cap * sizeof(int)));
             MRS_HIP_TRY(hipMalloc(&h->d_seed, (size_t)cap * sizeof(int)));
+            if (h->cert.lb) (void)hipFree(h->cert.lb);
+            if (h->cert.work) (void)hipFree(h->cert.work);
+            h->cert.lb = nullptr; h->cert.work = nullptr;
+            MRS_HIP_TRY(hipMalloc(&h->cert.lb, (size_t)cap * sizeof(float)));
+            MRS_HIP_TRY(hipMalloc(&h->cert.work, ((size_t)cap + kCertBlock) * sizeof(int)));
+            if (!h->cert.t_prev) {
+                MRS_HIP_TRY(hipMalloc(&h->cert.t_prev, (size_t)h->n_pairs * 12 * sizeof(float)));
+
+                MRS_HIP_TRY(hipMalloc(&h->cert.searched, 2 * sizeof(unsigned long long)));
+            }
         }
     }
     if (which == 0) h->n_seed = (size_t)total;
@@ -2176,12 +2447,19 @@ static int ensure_state(mrs_gicp_batch* h)
     if (!h->d_state) {
         MRS_HIP_TRY(hipMalloc(&h->d_state, h->n_pairs * sizeof(LmState)));
         MRS_HIP_TRY(hipMalloc(&h->d_nblocks, h->n_pairs * sizeof(int)));
-        MRS_HIP_TRY(hipMalloc(&h->d_nactive, 2 * sizeof(int)));
+        MRS_HIP_TRY(hipMalloc(&h->d_nactive, 4 * sizeof(int)));
     }
     if (mb > h->max_blocks) {
         if (h->d_partial) (void)hipFree(h->d_partial);
         MRS_HIP_TRY(hipMalloc(&h->d_partial, (size_t)h->n_pairs * mb * kTerms * sizeof(double)));
         h->max_blocks = mb;
+    }
+    const int cb = (int)((longest + kCertBlock - 1) / kCertBlock);
+    if (cb > h->cert.nb || !h->cert.bcount) {
+        if (h->cert.bcount) (void)hipFree(h->cert.bcount);
+        h->cert.bcount = nullptr;
+        MRS_HIP_TRY(hipMalloc(&h->cert.bcount, (size_t)h->n_pairs * cb * sizeof(int)));
+        h->cert.nb = cb;
     }
     std::vector<int> nb(h->n_pairs);
     for (int i = 0; i < h->n_pairs; ++i) nb[i] = blocks_for_points((int)(h->offs[0][i + 1] - h->offs[0][i]));
@@ -2264,24 +2542,22 @@ int mrs_gicp_batch_align(mrs_gicp_batch* h, const double* h_guess, double* h_fin
         S.lambda = -1.0; S.nu = 2.0; S.active = 1;
     }
     MRS_HIP_TRY(hipMemcpyAsync(h->d_state, init.data(), init.size() * sizeof(LmState), hipMemcpyHostToDevice, s));
+    if (h->cert.searched) MRS_HIP_TRY(hipMemsetAsync(h->cert.searched, 0, 2 * sizeof(unsigned long long), s));
     const dim3 grid(h->max_blocks, h->n_pairs);
     const int limit = h->prm.force_iters > 0 ? h->prm.force_iters : h->prm.max_iter;
     const long max_ticks = (long)limit * (h->prm.lm_max_iter + 1) + 1;
     long ticks = 0, nn_ticks = 0;
-    int next[2] = {h->n_pairs, 0};   // pairs to linearise (phase 0), pairs in an LM trial (phase 1)
+    int next[3] = {h->n_pairs, 0, h->n_pairs};   // pairs to linearise (phase 0), pairs in an LM trial (phase 1), pairs of [0] that moved far
     while (next[0] + next[1] > 0 && ticks < max_ticks) {
-        MRS_HIP_TRY(hipMemsetAsync(h->d_nactive, 0, 2 * sizeof(int), s));
+        MRS_HIP_TRY(hipMemsetAsync(h->d_nactive, 0, 4 * sizeof(int), s));
         if (h->prm.voxel_res > 0.0) {
             hipLaunchKernelGGL(k_linearize_voxel, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_cov[0], h->d_vkeys,
                                h->d_vmean, h->d_vcov, h->n_voxels, h->d_state, h->prm, h->d_partial, h->max_blocks);
         } else {
-            if (next[0] > 0 && h->search_core == 1) {   // only linearisations search; LM trials score the cached correspondences
-                hipLaunchKernelGGL((k_nn_scan_g<kGS>), dim3((unsigned)((h->longest_src + kNNThreads - 1) / kNNThreads), h->n_pairs), dim3(kNNThreads), 0, s,
-                                   (const float4*)h->d_pts[0], (const int64_t*)h->d_offs[0], (const float4*)h->d_pts[1], (const int64_t*)h->d_offs[1],
-                                   h->hier(1), (const LmState*)h->d_state, h->prm, h->d_corr, h->d_seed, (const int*)h->d_bbox[1]);
-            } else if (next[0] > 0)
-                launch_nn_scan(h->longest_src, h->n_pairs, h->ctx->num_cu, s, h->d_pts[0], h->d_offs[0], h->d_pts[1], h->d_offs[1],
-                               h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_mlo[1], h->d_mhi[1], h->d_state, h->prm, h->d_corr, h->d_seed, (const int*)h->d_bbox[1]);
+            if (next[0] > 0) {   // only linearisations search; LM trials score the cached correspondences
+                h->big_movers = next[2];
+                if ((st = nn_pass(h, nn_ticks == 0 ? 0 : 1, s)) != MRS_OK) return st;
+            }
             hipLaunchKernelGGL(k_linearize, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_cov[0],
                                h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->d_corr, h->d_partial, h->max_blocks);
         }
@@ -2289,11 +2565,17 @@ int mrs_gicp_batch_align(mrs_gicp_batch* h, const double* h_guess, double* h_fin
         hipLaunchKernelGGL(k_lm_update, dim3(h->n_pairs), dim3(64), 0, s, h->d_state, h->d_partial, h->d_nblocks,
                            h->max_blocks, h->prm, h->d_nactive);
         MRS_HIP_TRY(hipGetLastError());
-        MRS_HIP_TRY(hipMemcpyAsync(next, h->d_nactive, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+        MRS_HIP_TRY(hipMemcpyAsync(next, h->d_nactive, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
         MRS_HIP_TRY(hipStreamSynchronize(s));
         ++ticks;
     }
     h->last_nn_passes = (double)nn_ticks;
+    h->last_searched = 1.0;
+    if (h->search_core == 1 && h->cert.searched && h->prm.voxel_res <= 0.0 && nn_ticks > 0) {
+        unsigned long long q[2] = {0, 0};
+        MRS_HIP_TRY(hipMemcpy(q, h->cert.searched, sizeof(q), hipMemcpyDeviceToHost));
+        if (q[1]) h->last_searched = (double)q[0] / (double)q[1];
+    }
     MRS_HIP_TRY(hipMemcpy(init.data(), h->d_state, init.size() * sizeof(LmState), hipMemcpyDeviceToHost));
     for (int p = 0; p < h->n_pairs; ++p) {
         const LmState& S = init[p];
@@ -2332,14 +2614,7 @@ int mrs_gicp_batch_linearize(mrs_gicp_batch* h, const double* h_poses, double* h
                            h->d_cov[0], h->d_vkeys, h->d_vmean, h->d_vcov, h->n_voxels, h->d_state, h->prm, h->d_partial,
                            h->max_blocks);
     } else {
-        if (h->search_core == 1) {
-            hipLaunchKernelGGL((k_nn_scan_g<kGS>), dim3((unsigned)((h->longest_src + kNNThreads - 1) / kNNThreads), h->n_pairs), dim3(kNNThreads), 0, s,
-                               (const float4*)h->d_pts[0], (const int64_t*)h->d_offs[0], (const float4*)h->d_pts[1], (const int64_t*)h->d_offs[1],
-                               h->hier(1), (const LmState*)h->d_state, h->prm, h->d_corr, h->d_seed, (const int*)h->d_bbox[1]);
-        } else {
-            launch_nn_scan(h->longest_src, h->n_pairs, h->ctx->num_cu, s, h->d_pts[0], h->d_offs[0],
-                           h->d_pts[1], h->d_offs[1], h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_mlo[1], h->d_mhi[1], h->d_state, h->prm, h->d_corr, h->d_seed, (const int*)h->d_bbox[1]);
-        }
+        if ((st = nn_pass(h, 2, s)) != MRS_OK) return st;
         hipLaunchKernelGGL(k_linearize, dim3(h->max_blocks, h->n_pairs), dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0],
                            h->d_cov[0], h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->d_corr, h->d_partial,
                            h->max_blocks);

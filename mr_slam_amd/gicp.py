@@ -31,6 +31,7 @@ class GicpBatch:
         self._h = C.c_void_p()
         lib = _lib.load()
         lib.mrs_gicp_batch_last_nn_passes.restype = C.c_double
+        lib.mrs_gicp_batch_last_searched_fraction.restype = C.c_double
         _lib.check(lib.mrs_gicp_batch_create(_lib.ctx(device), self.n_pairs, C.byref(self._h)))
         self.params = default_params()
         self._n = [None, None]
@@ -50,7 +51,8 @@ class GicpBatch:
         _lib.check(_lib.load().mrs_gicp_batch_set_params(self._h, C.byref(self.params)))
 
     def set_search(self, core):
-        """1 (default): octree-cell leaves + query groups; 0: the round-3 wave-shared traversal (A/B, cross-check)."""
+        """1 (default): octree-cell leaves, per-query culling, certified neighbours; 2: without certificates; 3: round-4 kernel for the cold
+        pass too; 0: the round-3 wave-shared traversal (A/B, cross-check)."""
         _lib.check(_lib.load().mrs_gicp_batch_set_search(self._h, int(core)))
 
     def _set(self, which, clouds):
@@ -110,6 +112,7 @@ class GicpBatch:
                                                     _lib.ptr(conv), _lib.ptr(its), _lib.ptr(self.hessian),
                                                     _lib.current_stream(self.device)))
         self.nn_passes = float(_lib.load().mrs_gicp_batch_last_nn_passes(self._h))
+        self.searched_fraction = float(_lib.load().mrs_gicp_batch_last_searched_fraction(self._h))
         return T.reshape(P, 4, 4), conv.astype(bool), its
 
     def linearize(self, poses, want_corr=False):

@@ -384,14 +384,52 @@ def test_correspondences_agree_between_search_cores(dev, oracle):
 
 
 def test_align_identical_between_search_cores(dev):
-    """whole alignments (cold start, LM trials, warm passes): both search cores give the same transforms"""
+    """whole alignments (cold start, LM trials, warm passes): every search setting gives the same transforms -- the round-3 core (0),
+    the round-4 core with certified neighbours (1, the default), without certificates (2), with the round-4 kernel for the cold pass (3)"""
     from mr_slam_amd import gicp
     pairs = [_pair(31 + i, 15000 + 1000 * i) for i in range(3)]
-    out = {}
-    for core in (1, 0):
+    out, frac = {}, {}
+    for core in (1, 0, 2, 3):
         b = gicp.GicpBatch(3)
         b.set_search(core)
         b.set_params(k_correspondences=15, max_correspondence_distance=5.0)
         b.set_sources([p[0] for p in pairs]); b.set_targets([p[1] for p in pairs])
         out[core] = b.align()
-    assert np.abs(out[1][0] - out[0][0]).max() < 1e-6 and (out[1][2] == out[0][2]).all() and (out[1][1] == out[0][1]).all()
+        frac[core] = b.searched_fraction
+    for core in (1, 2, 3):
+        assert np.array_equal(out[core][0], out[0][0]) and (out[core][2] == out[0][2]).all() and (out[core][1] == out[0][1]).all(), core
+    assert frac[0] == 1.0 and frac[2] == 1.0 and frac[1] < 0.9 and frac[3] < 0.9, frac
+
+
+def test_certified_passes_are_exact(dev, oracle):
+    """Certificates (k_nn_certify): with forced iterations long past convergence nearly every pass is certified, and the correspondences
+    the certified passes leave behind are the exact nearest neighbours at the final pose: a fresh full search at that pose returns the same
+    squared distances for every source point, with and without a correspondence threshold, for a pose that keeps moving (second align from
+    a perturbed guess) and for clouds with duplicated points (exact ties can never be certified)."""
+    from mr_slam_amd import gicp
+    src, tgt, Ttrue = _pair(41, 30000)
+    dup = np.concatenate([tgt, tgt[:3000]])                      # 3000 exact duplicates in the target
+    for target, max_corr in ((tgt, 5.0), (tgt, 0.25), (dup, 5.0)):
+        res = {}
+        for core in (1, 2):
+            b = gicp.GicpBatch(1)
+            b.set_search(core)
+            b.set_params(k_correspondences=15, max_correspondence_distance=max_corr, force_iterations=14)
+            b.set_sources([src]); b.set_targets([target])
+            T, _, its = b.align()
+            f1 = b.searched_fraction
+            g = np.eye(4); g[:3, 3] = [0.05, -0.04, 0.02]
+            T2, _, _ = b.align((g @ T[0])[None])                  # seeds warm, certificates start over
+            res[core] = (T, T2, f1, b.searched_fraction)
+            # the correspondences a certified run leaves behind == a fresh exact search at the same pose
+            if core == 1:
+                b2 = gicp.GicpBatch(1)
+                b2.set_search(0)
+                b2.set_params(k_correspondences=15, max_correspondence_distance=max_corr)
+                b2.set_sources([src]); b2.set_targets([target])
+                for pose in (T[0], T2[0]):
+                    _, _, _, c_new = b.linearize(pose[None], want_corr=True)
+                    _, _, _, c_old = b2.linearize(pose[None], want_corr=True)
+                    assert np.array_equal(oracle.pair_d2(src, pose, target, c_new), oracle.pair_d2(src, pose, target, c_old))
+        assert np.array_equal(res[1][0], res[2][0]) and np.array_equal(res[1][1], res[2][1])
+        assert res[2][2] == 1.0 and res[1][2] < 0.5, res[1][2:]   # most (point, pass) pairs of 14 forced iterations were certified
