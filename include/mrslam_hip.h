@@ -314,17 +314,17 @@ int mrs_gicp_batch_fitness(mrs_gicp_batch* h, const double* h_poses, double max_
 /* number of brute-force NN passes the last align() issued (for iterations/s accounting) */
 double mrs_gicp_batch_last_nn_passes(const mrs_gicp_batch* h);
 
-/* Which exact nearest-neighbour search the batch uses for G2 / G3 (no reference counterpart: upstream fast_gicp searches a
- * kd-tree; every setting returns the exact neighbours, ties aside):
- *   1 (default) k-NN and correspondence search on octree-cell leaves with per-query culling (csrc/nn_core.hpp); in align() the first
- *               pass runs the round-3 kernel (a cold search is broad: brute force over fat boxes is at its best there), every later
- *               pass first CERTIFIES the neighbours of the previous pass (triangle inequality: a query that moved by delta keeps its
- *               neighbour if that neighbour's new distance is below the old lower bound of every other point's distance - delta)
- *               and searches only the queries that could not be certified;
+/* Which exact nearest-neighbour searches the batch uses for G2 / G3 (no reference counterpart: upstream fast_gicp searches a
+ * kd-tree; every setting returns the exact neighbours, ties aside -- identical transforms, tests/test_gicp_gpu.py):
+ *   1 (default) align(): the first pass and every pair whose last step moved it by more than 2 cm are searched by the round-3 kernel
+ *               (1024-point tiles / 16-point minis, candidates shared by a wave: best for broad searches); the other pairs first
+ *               CERTIFY the neighbours of the previous pass (triangle inequality: a query that moved by delta keeps its neighbour
+ *               if that neighbour's new distance is below [the old lower bound of every other point's distance] - delta) and search
+ *               only what could not be certified, on octree-cell leaves with per-query culling (csrc/nn_core.hpp).  k-NN for the
+ *               covariances: round-3 kernel;
  *   2           like 1 without certificates (every pass searches every point);
- *   3           like 1 with the round-4 kernel for the first pass as well;
- *   0           the round-3 traversal everywhere (1024-point tiles / 16-point minis, candidates shared by a whole wave), kept for A/B
- *               measurements and as a cross-check in the tests.
+ *   3           round-4 kernels everywhere (first pass and k-NN too; slower on lidar scans, kept for comparison);
+ *   0           the round-3 kernels everywhere, no certificates (A/B measurements, cross-check in the tests).
  * Invalidates cached covariances when the k-NN kernel changes. */
 int mrs_gicp_batch_set_search(mrs_gicp_batch* h, int32_t core);
 /* share of (source point, nearest-neighbour pass) of the last align() that needed a search (1.0 without certificates) */

@@ -536,7 +536,7 @@ __device__ __forceinline__ int knn_seed_home(const float4* __restrict__ pts, int
 // the LDS, and the <= KMAX + 8 collected candidates are then put in (distance, index) order by the old insertion -- a couple of dozen
 // insertions per query instead of one per candidate that beat any lane's bound.  Exactly equal distances resolve to the smaller
 // (Morton-space) index.  The whole workgroup must call it together.
-constexpr int kKnnSpare = 8;      // list slots beyond KMAX: room for candidates tied with the k-th distance
+
 // development counters (MRS_KNN_DBG=1 prints them): per wave and round -- tiles staged / candidate groups of 8 visited in pass 1 and 2, groups
 // where some lane's list changed, selection steps, query waves
 __device__ unsigned long long g_knn_dbg[8];
@@ -565,12 +565,11 @@ __device__ __forceinline__ void knn_insert_tie(float (&dk)[KMAX], int (&ik)[KMAX
 }
 
 // dk / ik: the k nearest of point i (itself included), ascending in (distance, index); slots >= the number found hold +inf / -1.
-// list: kNNThreads x (KMAX + kKnnSpare) ints of LDS, slot-major.
+// list: kNNThreads x KMAX ints of LDS, slot-major.
 template <int KMAX>
 __device__ __forceinline__ void knn_two_pass(int* __restrict__ list, const float4* __restrict__ pts, int n, const Hier& H,
                                              int i, bool live, const float4& q, int k, float (&dk)[KMAX], int (&ik)[KMAX])
 {
-    constexpr int CAP = KMAX + kKnnSpare;
 #pragma unroll
     for (int s = 0; s < KMAX; ++s) dk[s] = INFINITY;
     // pass 1: the KMAX smallest distances.  Seed: the 64 neighbours along the Morton curve (the bound is close to final before the
@@ -599,24 +598,34 @@ __device__ __forceinline__ void knn_two_pass(int* __restrict__ list, const float
                        dist_insert<KMAX>(dk, use ? dd[u] : INFINITY);
                    }
                });
-    // pass 2: every candidate within the k-th distance, home range included
-    const float tau = live ? dk[(k < KMAX ? k : KMAX) - 1] : -1.0f;
-    int cnt = 0;
+    // pass 2: every candidate within the k-th distance, home range included.  Strictly closer candidates (at most k - 1) fill the list from
+    // the bottom, exact ties with the k-th distance from slot k - 1 downwards; ties arrive in ascending index order and one is only kept
+    // while the list still has room for it (at most k - #closer can be needed), so a cluster of duplicates can neither overflow the list
+    // nor push a closer point out (round-3 review: with more than 8 ties ahead of them in Morton order closer neighbours were dropped)
+    const int kk = k < KMAX ? k : KMAX;
+    const float tau = live ? dk[kk - 1] : -1.0f;
+    int nlt = 0, ntie = 0;
     hier_visit(pts, n, H, lo, hi, wave_max(tau), q.x, q.y, q.z,
                [&](const float4& blo, const float4& bhi) { return live && box_point_d2(blo, bhi, q.x, q.y, q.z) * 0.9999f <= tau; },
                [&](int j0, const float (&dd)[8]) {
                    ++c_g2;
 #pragma unroll
-                   for (int u = 0; u < 8; ++u)
-                       if (dd[u] <= tau && dd[u] < INFINITY && cnt < CAP) {     // tau is +inf for a cloud with fewer than k points: padding stays out
-                           list[cnt * kNNThreads + (int)threadIdx.x] = j0 + u;
-                           ++cnt;
+                   for (int u = 0; u < 8; ++u) {
+                       if (dd[u] <= tau && dd[u] < INFINITY) {     // tau is +inf for a cloud with fewer than k points: padding stays out
+                           const bool tie = dd[u] == tau;
+                           if (!tie && nlt + ntie == kk && ntie > 0) --ntie;
+                           if (nlt + ntie < kk) {
+                               list[(tie ? kk - 1 - ntie : nlt) * kNNThreads + (int)threadIdx.x] = j0 + u;
+                               nlt += tie ? 0 : 1;
+                               ntie += tie ? 1 : 0;
+                           }
                        }
+                   }
                });
     // selection: (distance, index) order
 #pragma unroll
     for (int s = 0; s < KMAX; ++s) { dk[s] = INFINITY; ik[s] = -1; }
-    int most = cnt;
+    int most = max(nlt, ntie);
     for (int o = 32; o > 0; o >>= 1) most = max(most, __shfl_xor(most, o, 64));
     if (g_knn_dbg_on && (threadIdx.x & 63) == 0) {
         atomicAdd(&g_knn_dbg[1], (unsigned long long)c_g1); atomicAdd(&g_knn_dbg[2], (unsigned long long)c_ins);
@@ -624,10 +633,12 @@ __device__ __forceinline__ void knn_two_pass(int* __restrict__ list, const float
         atomicAdd(&g_knn_dbg[6], 1ull);
     }
     for (int c = 0; c < most; ++c) {
-        const bool have = c < cnt;
-        const int j = have ? list[c * kNNThreads + (int)threadIdx.x] : 0;
-        const float d = dist2(q.x, q.y, q.z, pts[j]);
-        if (have) knn_insert_tie<KMAX>(dk, ik, d, j);
+        const bool ha = c < nlt, hb = c < ntie;
+        const int ja = ha ? list[c * kNNThreads + (int)threadIdx.x] : 0;
+        const int jb = hb ? list[(kk - 1 - c) * kNNThreads + (int)threadIdx.x] : 0;
+        const float da = dist2(q.x, q.y, q.z, pts[ja]), db = dist2(q.x, q.y, q.z, pts[jb]);
+        if (ha) knn_insert_tie<KMAX>(dk, ik, da, ja);
+        if (hb) knn_insert_tie<KMAX>(dk, ik, db, jb);
     }
 }
 
@@ -636,14 +647,16 @@ __device__ __forceinline__ void knn_two_pass(int* __restrict__ list, const float
 // grid = (blocks, clouds); cloud c spans pts[offs[c] .. offs[c+1]).
 // cov out (sorted space): 6 doubles per point (xx, xy, xz, yy, yz, zz).
 // knn_out optional, ORIGINAL indexing: knn_out[(offs[c] + orig_i) * k + s] = original neighbour index.
-template <int KMAX>
-__global__ __launch_bounds__(kNNThreads) void k_knn_cov(const float4* __restrict__ pts_all,
+// SPLIT: only the selection -- the neighbours go to knn_out as cloud-local SORTED-space indices [point][k] and k_cov_from_knn does the
+// fp64 tail: without the covariance / eigenvector state the selection keeps fewer registers alive (more waves per SIMD).
+template <int KMAX, bool SPLIT = false>
+__global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(KMAX <= 16 ? 5 : 1))) void k_knn_cov(const float4* __restrict__ pts_all,
                                                         const int64_t* __restrict__ offs, const int* __restrict__ tile_base,
                                                         const float4* __restrict__ tlo, const float4* __restrict__ thi,
         const float4* __restrict__ mlo, const float4* __restrict__ mhi,
                                                         int k, double* __restrict__ cov_all, int* __restrict__ knn_out)
 {
-    __shared__ int knn_list[(KMAX + kKnnSpare) * kNNThreads];
+    __shared__ int knn_list[KMAX * kNNThreads];
     const int c = blockIdx.y;
     const int64_t o = offs[c];
     const int n = (int)(offs[c + 1] - o);
@@ -660,6 +673,12 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_cov(const float4* __restrict
         int ik[KMAX];
         knn_two_pass<KMAX>(knn_list, pts, n, H, i, live, q, k, dk, ik);
         if (!live) continue;
+        if (SPLIT) {
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s)
+                if (s < k) knn_out[(size_t)(o + i) * k + s] = ik[s];
+            continue;
+        }
         double mean[3] = {0, 0, 0};
         int cnt = 0;
 #pragma unroll
@@ -801,7 +820,7 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_features(const float4* __res
                                                              int k, int* __restrict__ knn_out, float* __restrict__ eig_out,
                                                              float* __restrict__ feat_out, float* __restrict__ feat_planes)
 {
-    __shared__ int knn_list[(KMAX + kKnnSpare) * kNNThreads];
+    __shared__ int knn_list[KMAX * kNNThreads];
     const int c = blockIdx.y;
     const int64_t o = offs[c];
     const int n = (int)(offs[c + 1] - o);
@@ -2143,11 +2162,10 @@ int mrs_gicp_batch_set_search(mrs_gicp_batch* h, int32_t core)
     MRS_REQUIRE(h, "null handle");
     MRS_REQUIRE(core >= 0 && core <= 3, "core must be 0 .. 3");
     const int base = core == 0 ? 0 : 1;
-    if (base != h->search_core) h->cov_valid[0] = h->cov_valid[1] = false;
+    if ((core == 3) != (h->search_core == 1 && h->cold_core == 1)) h->cov_valid[0] = h->cov_valid[1] = false;   // the k-NN kernel changes
     h->search_core = base;
-    h->use_certificates = core == 1;
+    h->use_certificates = core == 1 || core == 3;
     h->cold_core = core == 3 ? 1 : 0;
-    if (core == 3) h->use_certificates = true;
     return MRS_OK;
 }
 
@@ -2373,7 +2391,7 @@ int mrs_gicp_batch_compute_covariances(mrs_gicp_batch* h, int32_t which, int32_t
     for (int i = 0; i < h->n_pairs; ++i) longest = std::max(longest, h->offs[which][i + 1] - h->offs[which][i]);
     const dim3 grid((unsigned)((longest + kNNThreads - 1) / kNNThreads), h->n_pairs);
     const int k = h->prm.k;
-    if (h->search_core == 1) {
+    if (h->search_core == 1 && h->cold_core == 1) {     // setting 3: the round-4 k-NN kernel (slower than the round-3 one on the bench's scans)
         mrs::Scratch knn;
         int st = knn.alloc((size_t)h->offs[which][h->n_pairs] * k * sizeof(int), s);
         if (st != MRS_OK) return st;
@@ -2388,6 +2406,27 @@ int mrs_gicp_batch_compute_covariances(mrs_gicp_batch* h, int32_t which, int32_t
     if (mrs::dev_env("MRS_KNN_DBG")) {
         const int on = 1;
         MRS_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_knn_dbg_on), &on, sizeof(on)));
+    }
+    static const char* const split_s = mrs::dev_env("MRS_KNN_SPLIT");      // development aid: 0 = selection and covariances in one kernel
+    if (!(split_s && atoi(split_s) == 0)) {
+        mrs::Scratch knn;
+        int st = knn.alloc((size_t)h->offs[which][h->n_pairs] * k * sizeof(int), s);
+        if (st != MRS_OK) return st;
+        if (k <= 16)
+            hipLaunchKernelGGL((k_knn_cov<16, true>), grid, dim3(kNNThreads), 0, s, h->d_pts[which], h->d_offs[which], h->d_tile_base[which],
+                               h->d_tlo[which], h->d_thi[which], h->d_mlo[which], h->d_mhi[which], k, (double*)nullptr, knn.as<int>());
+        else if (k <= 20)
+            hipLaunchKernelGGL((k_knn_cov<20, true>), grid, dim3(kNNThreads), 0, s, h->d_pts[which], h->d_offs[which], h->d_tile_base[which],
+                               h->d_tlo[which], h->d_thi[which], h->d_mlo[which], h->d_mhi[which], k, (double*)nullptr, knn.as<int>());
+        else
+            hipLaunchKernelGGL((k_knn_cov<32, true>), grid, dim3(kNNThreads), 0, s, h->d_pts[which], h->d_offs[which], h->d_tile_base[which],
+                               h->d_tlo[which], h->d_thi[which], h->d_mlo[which], h->d_mhi[which], k, (double*)nullptr, knn.as<int>());
+        hipLaunchKernelGGL(k_cov_from_knn, dim3((unsigned)((longest + 255) / 256), h->n_pairs), dim3(256), 0, s, (const float4*)h->d_pts[which],
+                           (const int64_t*)h->d_offs[which], k, (const int*)knn.as<int>(), h->d_cov[which], d_knn_out);
+        MRS_HIP_TRY(hipGetLastError());
+        h->cov_valid[which] = true;
+        if (which == 1) h->vox_res_built = 0.0;
+        return MRS_OK;
     }
     if (k <= 16)
         hipLaunchKernelGGL(k_knn_cov<16>, grid, dim3(kNNThreads), 0, s, h->d_pts[which], h->d_offs[which], h->d_tile_base[which],
@@ -2738,8 +2777,8 @@ int mrs_pointfeat_batch(mrs_ctx* ctx, const float* d_points, int32_t stride_floa
         int64_t longest = 0;
         for (int i = 0; i < batch; ++i) longest = std::max(longest, h_offsets[i + 1] - h_offsets[i]);
         const dim3 grid((unsigned)((longest + kNNThreads - 1) / kNNThreads), batch);
-        static const char* const core_s = mrs::dev_env("MRS_NN_CORE");      // development aid: 0 = the round-3 kernel
-        if (!(core_s && atoi(core_s) == 0)) {
+        static const char* const core_s = mrs::dev_env("MRS_NN_CORE");      // development aid: 1 = the round-4 k-NN kernel (slower here)
+        if (core_s && atoi(core_s) == 1) {
             mrs::Scratch knn;
             st = knn.alloc((size_t)h_offsets[batch] * k * sizeof(int), s);
             if (st == MRS_OK) st = launch_knn_select(h, 0, k, knn.as<int>(), s);

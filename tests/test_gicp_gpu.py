@@ -326,15 +326,14 @@ def _knn_d2(oracle, cloud, knn):
 
 @pytest.mark.parametrize("k", [15, 20, 30])
 def test_knn_exact_on_adversarial_clouds(dev, oracle, k):
-    """Round-4 search (octree-cell leaves + query groups): the k nearest of every point against brute force -- same multiset of float
-    distances, ascending, every index valid and distinct, ties broken towards the smaller index -- on a lidar scan, uniform points, a
-    lattice (every distance tied many times over), clusters of duplicates larger than k (ties must not push closer
-    neighbours out) and clouds smaller than a leaf / than k; and against the round-3 core on the same clouds."""
+    """Both k-NN kernels (round 4: octree-cell leaves, per-query culling; round 3: the default) against the restatement's exact kd-tree
+    search: same multiset of float distances, ascending, every index valid and distinct -- on a lidar scan, uniform points, a lattice
+    (every distance tied many times over), clusters of duplicates larger than k and clouds smaller than a leaf / than k."""
     from mr_slam_amd import gicp
     for name, cloud in _clouds_for_search_tests().items():
         n = cloud.shape[0]
         res = {}
-        for core in (1, 0):
+        for core in (3, 0):          # 3: the round-4 k-NN kernel (octree-cell leaves), 0: the round-3 one (the default for k-NN)
             b = gicp.GicpBatch(1)
             b.set_search(core)
             b.set_params(k_correspondences=k)
@@ -342,18 +341,18 @@ def test_knn_exact_on_adversarial_clouds(dev, oracle, k):
             res[core] = b.compute_covariances(0, want_knn=True).cpu().numpy()
             cov = b.covariances(0)
             assert np.isfinite(cov).all(), (name, core)
-        knn = res[1]
+        knn = res[3]
         kk = min(k, n)
         assert (knn[:, kk:] == -1).all() and (knn[:, :kk] >= 0).all() and (knn[:, :kk] < n).all(), name
         assert all(len(set(r[:kk])) == kk for r in knn[:: max(1, n // 500)]), name        # no point twice
         d = _knn_d2(oracle, cloud, knn[:, :kk])
         want = _knn_d2(oracle, cloud, oracle.knn(cloud, kk))                               # the restatement's exact kd-tree search
         assert np.array_equal(d, np.sort(want, 1)), name                                   # same multiset of float distances, ascending
-        # (distance, index) order: among equal distances the indices the caller sees need not ascend (the search orders ties by its
-        # internal Morton index), but the round-3 core must agree on every distance
-        if name not in ("cluster", "same"):      # the round-3 core drops neighbours when > 8 candidates tie at the k-th distance
-            d0 = _knn_d2(oracle, cloud, res[0][:, :kk])
-            assert np.array_equal(d0, d), name
+        # both kernels are tie-safe (a cluster of more than k duplicates must neither overflow the candidate list nor push a
+        # closer point out): the round-3 kernel returns the same distances on every cloud, the duplicate clusters included
+        d0 = _knn_d2(oracle, cloud, res[0][:, :kk])
+        assert np.array_equal(d0, d), name
+        assert (res[0][:, kk:] == -1).all() and all(len(set(r[:kk])) == kk for r in res[0][:: max(1, n // 500)]), name
 
 
 def test_correspondences_agree_between_search_cores(dev, oracle):
