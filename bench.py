@@ -338,30 +338,58 @@ def gicp_leg(device_index, rank, n_pairs, iters):
 
     # cold: set_sources resets the warm-start seeds; nothing has been aligned yet
     t_cold, _, its_c, nn_c = timed(force_iterations=5)
+    s_cold = b.searched_fraction
     t_forced, _, its_f, nn_f = timed(force_iterations=iters)          # seeds now warm from the cold run (like a re-check)
+    s_forced = b.searched_fraction
     assert (its_f == iters).all() and (its_c == 5).all()
     b.set_sources(srcs)                                               # reset seeds (covariances recomputed lazily: not timed)
     b.compute_covariances(0)
-    t_nat, conv, its_n, nn_n = timed(force_iterations=0)
+    b.set_params(force_iterations=0)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    T_nat, conv, its_n = b.align()
+    torch.cuda.synchronize()
+    t_nat = time.perf_counter() - t
+    nn_n, s_nat = b.nn_passes, b.searched_fraction
+    # every kernel of an outer iteration alone between HIP events, at the converged poses (numeric rooflines)
+    kms, kcnt = b.profile(T_nat, reps=3)
+    n_src, n_corr = kcnt["source_points"], kcnt["correspondences"]
+    lin_bytes = 20 * n_src + 112 * n_corr         # every source point: 16 B point + 4 B index; every correspondence: + 48 B covariance + gathered 16 + 48 B
+    knn_bytes = n_src * (16 + 4 * 15)             # the selection's compulsory traffic (point in, 15 indices out): it is VALU-bound, not HBM-bound
+    cov_bytes = n_src * (4 * 15 + 16 + 48)        # indices + own point in, 48 B covariance out (the 15 gathered points are L2 hits)
+
+    def hbm(bytes_, ms):
+        gbs = bytes_ / (ms * 1e-3) / 1e9
+        return {"bytes": bytes_, "ms": ms, "achieved": gbs, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS}
+    roof = {
+        "k_linearize": dict(hbm(lin_bytes, kms["linearize"]), bound="hbm", note="132 B per correspondence + 20 B per unmatched source point, gathered covariances; "
+                            "launched alone at the converged poses, 256 pairs"),
+        "k_linearize_error_only": dict(hbm(lin_bytes, kms["linearize_error_only"]), bound="hbm", note="an LM trial: the same bytes, one sum instead of 28"),
+        "k_nn_scan (round-3 search, every point, warm)": {"bound": "valu", "ms": kms["search_round3_all"], "queries_per_s": n_src / kms["search_round3_all"] * 1e3,
+                                                          "note": "VALU-pipe busy fraction from the PMC pass of the same shape: profiles/*_pmc.json"},
+        "k_nn_scan_g (round-4 search, every point, warm)": {"bound": "latency", "ms": kms["search_round4_all"], "queries_per_s": n_src / kms["search_round4_all"] * 1e3},
+        "k_nn_certify (unchanged pose)": dict(hbm(n_src * 44, kms["certify"]), bound="hbm", note="16 B point + 4 B seed + 4 B bound in, 4 B index + 4 B bound out, "
+                                              "gathered 16 B neighbour: 44 B per source point"),
+        "certify + work-list search after a 1 mm step": {"ms": kms["certify_plus_worklist_1mm"], "worklist_queries": kcnt["worklist_queries_1mm"],
+                                                         "share_of_points_searched": kcnt["worklist_queries_1mm"] / max(n_src, 1)},
+        "k_knn_cov (selection)": dict(hbm(knn_bytes, kms["knn_select"]), bound="valu", clouds_per_s=n_pairs / kms["knn_select"] * 1e3),
+        "k_cov_from_knn": dict(hbm(cov_bytes, kms["cov_from_knn"]), bound="hbm+fp64", clouds_per_s=n_pairs / kms["cov_from_knn"] * 1e3),
+    }
     return {"pairs": n_pairs, "iterations": iters, "points": N_POINTS,
             "iters_per_s": n_pairs * iters / t_forced, "align_s": t_forced, "nn_passes": nn_f,
-            "nn_pass_ms": 1e3 * t_forced / (n_pairs * max(nn_f, 1)),
-            "cold": {"iterations": 5, "iters_per_s": n_pairs * 5 / t_cold, "align_s": t_cold, "nn_passes": nn_c,
+            "nn_pass_ms": 1e3 * t_forced / (n_pairs * max(nn_f, 1)), "searched_fraction": s_forced,
+            "cold": {"iterations": 5, "iters_per_s": n_pairs * 5 / t_cold, "align_s": t_cold, "nn_passes": nn_c, "searched_fraction": s_cold,
                      "note": "first 5 outer iterations from the identity guess, no warm start"},
             "natural": {"pairs_per_s": n_pairs / t_nat, "align_s": t_nat, "converged": int(conv.sum()),
                         "mean_iterations": float(np.mean(its_n)), "max_iterations": int(np.max(its_n)), "nn_passes": nn_n,
-                        "iters_per_s": float(np.sum(its_n)) / t_nat},
-            "nn_search": "exact brute force over the Morton-ordered cloud: a wave walks a two-level box hierarchy in global memory (1024-point tiles, "
-                         "16-point minis) on its own, candidates arrive as scalar loads, conservative culling; one NN pass per outer iteration, "
-                         "LM trials score the cached correspondences (upstream compute_error)",
+                        "iters_per_s": float(np.sum(its_n)) / t_nat, "searched_fraction": s_nat},
+            "nn_search": "exact: first pass and pairs that moved > 2 cm by brute force over the Morton-ordered cloud (a wave walks 1024-point tiles / 16-point "
+                         "minis, scalar candidate loads); other pairs certify last pass's neighbours by the triangle inequality (k_nn_certify) and search only "
+                         "the uncertified queries on octree-cell leaves with per-query culling (k_nn_scan_g); one NN pass per outer iteration, LM trials "
+                         "score the cached correspondences (upstream compute_error)",
             "pairs_per_s_incl_covariances": n_pairs / (t_nat + t_cov),
             "covariance_s": t_cov, "covariance_clouds_per_s": 2 * n_pairs / t_cov, "k": 15,
-            "max_correspondence_distance": 5.0,
-            "bound": {"k_linearize": "HBM: 132 B per source point and pass (16 B point + 48 B covariance + 4 B index + gathered "
-                                     "16 + 48 B); an LM trial re-reads the same bytes (Mahalanobis matrices are recomputed, not stored)",
-                      "k_knn_cov": "VALU: exact k-NN by culled brute force in two passes (the 16 smallest distances by a v_med3_f32 chain, then the "
-                                   "indices within the k-th distance); no HBM or MFMA bound applies (inputs are L2 resident)",
-                      "k_nn_scan": "VALU: ~7 lane-ops per surviving (source, target) candidate, ~1000 candidate evaluations per wave of 128 queries"}}
+            "max_correspondence_distance": 5.0, "kernel_ms": kms, "kernel_counts": kcnt, "roofline": roof}
 
 
 # ---------------------------------------------------------------------------------------------------- sweep legs
@@ -1086,6 +1114,24 @@ def main():
                                             "achieved": sa, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sa / HBM_PEAK_GBS,
                                             "ms": kern_ms["bev_standalone"], "traffic": pmc.get("k_cart_lds", {}).get("hbm_bytes"),
                                             "algorithmic_bytes_per_launch": bev_bytes}
+        if gicp_res:
+            # north_star's own targets as flat scalars of `roofline` (the driver's record keeps scalars of this block)
+            gr = gicp_res["roofline"]
+            line["roofline"].update({
+                "gicp_iters_per_s": gicp_res["iters_per_s"], "gicp_iters_per_s_cold": gicp_res["cold"]["iters_per_s"],
+                "gicp_natural_pairs_per_s": gicp_res["natural"]["pairs_per_s"], "gicp_pairs_per_s_incl_covariances": gicp_res["pairs_per_s_incl_covariances"],
+                "gicp_searched_fraction_natural": gicp_res["natural"]["searched_fraction"],
+                "gicp_linearize_ms": gr["k_linearize"]["ms"], "gicp_linearize_gbs": gr["k_linearize"]["achieved"], "gicp_linearize_frac": gr["k_linearize"]["frac"],
+                "gicp_linearize_error_only_frac": gr["k_linearize_error_only"]["frac"],
+                "gicp_nn_round3_all_ms": gicp_res["kernel_ms"]["search_round3_all"], "gicp_nn_round4_all_ms": gicp_res["kernel_ms"]["search_round4_all"],
+                "gicp_nn_certify_ms": gicp_res["kernel_ms"]["certify"], "gicp_nn_certify_frac": gr["k_nn_certify (unchanged pose)"]["frac"],
+                "gicp_nn_certified_pass_1mm_ms": gicp_res["kernel_ms"]["certify_plus_worklist_1mm"],
+                "gicp_knn_select_ms": gicp_res["kernel_ms"]["knn_select"], "gicp_cov_from_knn_ms": gicp_res["kernel_ms"]["cov_from_knn"],
+                "gicp_pairs": gicp_res["pairs"]})
+            line["roofline"]["gicp"] = gr
+        if FUSE:
+            line["roofline"]["bev_scatter_frac"] = line["roofline_bev_scatter"]["frac"]
+            line["roofline"]["bev_scatter_gbs"] = line["roofline_bev_scatter"]["achieved"]
         if dist_on:
             # bytes a rank receives per launch under either design, and the inbound rate each would need at the measured step time
             ag_launch = (world - 1) * B * (58560 if REP32 else 29280)
@@ -1145,6 +1191,8 @@ def main():
             ms = ev_ms(lambda: dst_buf.copy_(src_buf), reps=5, warm=2)
             copy_gbs = 2 * src_buf.numel() * 4 / ms / 1e6
             del dst_buf
+            line["roofline"]["polar_frac"] = line["roofline_polar"]["frac"]
+            line["roofline"]["polar_gbs"] = line["roofline_polar"]["achieved"]
             line["roofline"]["measured_copy_gbs"] = copy_gbs
             line["roofline"]["frac_of_measured_copy"] = achieved / copy_gbs
             line["roofline_polar"]["frac_of_measured_copy"] = line["roofline_polar"]["achieved"] / copy_gbs

@@ -314,6 +314,13 @@ int mrs_gicp_batch_fitness(mrs_gicp_batch* h, const double* h_poses, double max_
 /* number of brute-force NN passes the last align() issued (for iterations/s accounting) */
 double mrs_gicp_batch_last_nn_passes(const mrs_gicp_batch* h);
 
+/* Measurement hook of bench.py (no reference counterpart): every kernel of one outer iteration launched alone between HIP events on
+ * `stream`, `reps` times, at the given poses (double[n_pairs][16]).  out_ms float[8]: 0 k_linearize (28 sums), 1 k_linearize (error only:
+ * an LM trial), 2 round-3 search of every point (warm), 3 k_nn_certify at an unchanged pose, 4 round-4 search of every point (warm),
+ * 5 k-NN selection of the sources, 6 k_cov_from_knn of the sources, 7 certify + work-list search after a 1 mm step.  out_counts int64[3]:
+ * source points, correspondences at the poses, queries on the work lists of [7].  Leaves the batch's settings unchanged. */
+int mrs_gicp_batch_profile(mrs_gicp_batch* h, const double* h_poses, int32_t reps, float* out_ms, int64_t* out_counts, mrs_stream stream);
+
 /* Which exact nearest-neighbour searches the batch uses for G2 / G3 (no reference counterpart: upstream fast_gicp searches a
  * kd-tree; every setting returns the exact neighbours, ties aside -- identical transforms, tests/test_gicp_gpu.py):
  *   1 (default) align(): the first pass and every pair whose last step moved it by more than 2 cm are searched by the round-3 kernel

@@ -2679,6 +2679,160 @@ int mrs_gicp_batch_linearize(mrs_gicp_batch* h, const double* h_poses, double* h
     return MRS_OK;
 }
 
+/* Measurement hook (bench.py's GICP rooflines): every kernel of one outer iteration launched ALONE between HIP events on `stream`, at
+ * the given poses and with the batch's clouds / covariances, `reps` times each (the average goes to out_ms):
+ *   [0] k_linearize, all 28 sums (phase 0)            [1] k_linearize, error only (an LM trial)
+ *   [2] round-3 search of every point, warm           [3] k_nn_certify at an unchanged pose (everything certified)
+ *   [4] round-4 search of every point, warm           [5] k-NN selection of the sources (k_knn_cov<.., SPLIT>)
+ *   [6] k_cov_from_knn of the sources                 [7] k_nn_certify + work-list search at a pose moved by 1 mm along x
+ * out_counts: [0] source points, [1] correspondences (d^2 < max_corr^2) at the poses, [2] queries on the work lists of [7]. */
+int mrs_gicp_batch_profile(mrs_gicp_batch* h, const double* h_poses, int32_t reps, float* out_ms, int64_t* out_counts, mrs_stream stream)
+{
+    MRS_REQUIRE(h && h_poses && out_ms && out_counts, "null pointer");
+    MRS_REQUIRE(h->d_pts[0] && h->d_pts[1], "set source and target clouds first");
+    MRS_REQUIRE(h->prm.voxel_res <= 0.0, "GICP only");
+    MRS_REQUIRE(reps >= 1, "reps must be >= 1");
+    MRS_HIP_TRY(hipSetDevice(h->ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    int st;
+    for (int w = 0; w < 2; ++w)
+        if (!h->cov_valid[w]) { st = mrs_gicp_batch_compute_covariances(h, w, nullptr, stream); if (st != MRS_OK) return st; }
+    if ((st = ensure_state(h)) != MRS_OK) return st;
+    const int P = h->n_pairs;
+    std::vector<LmState> init(P);
+    auto upload = [&](int phase, double dx) -> int {
+        for (int p = 0; p < P; ++p) {
+            memset(&init[p], 0, sizeof(LmState));
+            for (int i = 0; i < 16; ++i) init[p].x[i] = init[p].xi[i] = init[p].delta[i] = h_poses[(size_t)p * 16 + i];
+            for (int i = 0; i < 16; ++i) init[p].delta[i] = (i % 5 == 0) ? 1.0 : 0.0;      // last step: none
+            init[p].x[3] += dx; init[p].xi[3] += dx;
+            init[p].active = 1; init[p].phase = phase;
+        }
+        MRS_HIP_TRY(hipMemcpyAsync(h->d_state, init.data(), init.size() * sizeof(LmState), hipMemcpyHostToDevice, s));
+        MRS_HIP_TRY(hipStreamSynchronize(s));
+        return MRS_OK;
+    };
+    hipEvent_t e0, e1;
+    MRS_HIP_TRY(hipEventCreate(&e0)); MRS_HIP_TRY(hipEventCreate(&e1));
+    auto timed = [&](float& ms, auto&& launch) -> int {
+        launch();                                     // warm
+        MRS_HIP_TRY(hipEventRecord(e0, s));
+        for (int r = 0; r < reps; ++r) launch();
+        MRS_HIP_TRY(hipEventRecord(e1, s));
+        MRS_HIP_TRY(hipEventSynchronize(e1));
+        MRS_HIP_TRY(hipGetLastError());
+        MRS_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        ms /= (float)reps;
+        return MRS_OK;
+    };
+    const dim3 lin_grid(h->max_blocks, P), wg((unsigned)((h->longest_src + kCertBlock - 1) / kCertBlock), P);
+    const int saved_core = h->search_core, saved_cold = h->cold_core;
+    const bool saved_cert = h->use_certificates;
+    h->search_core = 1; h->cold_core = 0; h->use_certificates = true;
+    auto restore = [&]() { h->search_core = saved_core; h->cold_core = saved_cold; h->use_certificates = saved_cert; };
+    auto round3 = [&]() {
+        launch_nn_scan(h->longest_src, P, h->ctx->num_cu, s, h->d_pts[0], h->d_offs[0], h->d_pts[1], h->d_offs[1], h->d_tile_base[1], h->d_tlo[1],
+                       h->d_thi[1], h->d_mlo[1], h->d_mhi[1], h->d_state, h->prm, h->d_corr, h->d_seed, (const int*)h->d_bbox[1], (float*)nullptr, 0);
+    };
+    auto round4_all = [&]() {
+        hipLaunchKernelGGL((k_nn_scan_g<false, false>), wg, dim3(kNNThreads), 0, s, (const float4*)h->d_pts[0], (const int64_t*)h->d_offs[0],
+                           (const float4*)h->d_pts[1], (const int64_t*)h->d_offs[1], h->hier(1), (const LmState*)h->d_state, h->prm, h->d_corr, h->d_seed,
+                           (const int*)h->d_bbox[1], h->cert);
+    };
+    auto certify = [&]() {
+        hipLaunchKernelGGL(k_nn_certify, wg, dim3(256), 0, s, (const float4*)h->d_pts[0], (const int64_t*)h->d_offs[0], (const float4*)h->d_pts[1],
+                           (const int64_t*)h->d_offs[1], (const LmState*)h->d_state, h->prm, h->d_corr, (const int*)h->d_seed, h->cert);
+    };
+    auto listed = [&]() {
+        hipLaunchKernelGGL((k_nn_scan_g<false, true>), wg, dim3(kNNThreads), 0, s, (const float4*)h->d_pts[0], (const int64_t*)h->d_offs[0],
+                           (const float4*)h->d_pts[1], (const int64_t*)h->d_offs[1], h->hier(1), (const LmState*)h->d_state, h->prm, h->d_corr, h->d_seed,
+                           (const int*)h->d_bbox[1], h->cert);
+    };
+    auto store_pose = [&]() {
+        hipLaunchKernelGGL(k_nn_store_pose, dim3((P + 255) / 256), dim3(256), 0, s, (const LmState*)h->d_state, P, h->cert, 0, (const int64_t*)h->d_offs[0],
+                           h->prm.motion_switch);
+    };
+    auto fail = [&](int code) { restore(); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return code; };
+    if ((st = upload(0, 0.0)) != MRS_OK) return fail(st);
+    round3();                                         // seeds + correspondences at the poses
+    if ((st = timed(out_ms[2], round3)) != MRS_OK) return fail(st);
+    if ((st = timed(out_ms[0], [&]() {
+             hipLaunchKernelGGL(k_linearize, lin_grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_cov[0], h->d_pts[1], h->d_offs[1], h->d_cov[1],
+                                h->d_state, h->d_corr, h->d_partial, h->max_blocks);
+         })) != MRS_OK) return fail(st);
+    {   // correspondences at the poses
+        std::vector<int> corr(h->n_seed);
+        MRS_HIP_TRY(hipMemcpy(corr.data(), h->d_corr, corr.size() * sizeof(int), hipMemcpyDeviceToHost));
+        int64_t c = 0;
+        for (int v : corr) c += v >= 0;
+        out_counts[0] = (int64_t)h->n_seed; out_counts[1] = c;
+    }
+    if ((st = timed(out_ms[4], round4_all)) != MRS_OK) return fail(st);      // leaves certificates at the poses
+    store_pose();
+    if ((st = timed(out_ms[3], certify)) != MRS_OK) return fail(st);
+    if ((st = upload(1, 0.0)) != MRS_OK) return fail(st);
+    if ((st = timed(out_ms[1], [&]() {
+             hipLaunchKernelGGL(k_linearize, lin_grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_cov[0], h->d_pts[1], h->d_offs[1], h->d_cov[1],
+                                h->d_state, h->d_corr, h->d_partial, h->max_blocks);
+         })) != MRS_OK) return fail(st);
+    // a pass after a 1 mm step: certify + search the work lists (the certificates are those of the unmoved poses: t_prev stays)
+    if ((st = upload(0, 1e-3)) != MRS_OK) return fail(st);
+    {
+        mrs::Scratch lb_save;
+        if ((st = lb_save.alloc(h->n_seed * sizeof(float), s)) != MRS_OK) return fail(st);
+        MRS_HIP_TRY(hipMemcpyAsync(lb_save.p, h->cert.lb, h->n_seed * sizeof(float), hipMemcpyDeviceToDevice, s));
+        float acc = 0.0f;
+        for (int r = 0; r < reps + 1; ++r) {
+            MRS_HIP_TRY(hipMemcpyAsync(h->cert.lb, lb_save.p, h->n_seed * sizeof(float), hipMemcpyDeviceToDevice, s));
+            MRS_HIP_TRY(hipEventRecord(e0, s));
+            certify(); listed();
+            MRS_HIP_TRY(hipEventRecord(e1, s));
+            MRS_HIP_TRY(hipEventSynchronize(e1));
+            float ms = 0.0f;
+            MRS_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            if (r > 0) acc += ms;
+        }
+        out_ms[7] = acc / (float)reps;
+        std::vector<int> bc((size_t)P * h->cert.nb);
+        MRS_HIP_TRY(hipMemcpy(bc.data(), h->cert.bcount, bc.size() * sizeof(int), hipMemcpyDeviceToHost));
+        int64_t q = 0;
+        for (int p = 0; p < P; ++p) {
+            const int64_t n = h->offs[0][p + 1] - h->offs[0][p];
+            for (int b = 0; b * (int64_t)kCertBlock < n; ++b) {
+                const int64_t members = std::min<int64_t>(kCertBlock, n - b * (int64_t)kCertBlock), c = bc[(size_t)p * h->cert.nb + b];
+                q += 2 * c > members ? members : c;
+            }
+        }
+        out_counts[2] = q;
+    }
+    {   // k-NN selection + covariances of the sources
+        const int k = h->prm.k;
+        mrs::Scratch knn;
+        if ((st = knn.alloc(h->n_seed * k * sizeof(int), s)) != MRS_OK) return fail(st);
+        const dim3 grid((unsigned)((h->longest_src + kNNThreads - 1) / kNNThreads), P);
+        auto select = [&]() {
+            if (k <= 16)
+                hipLaunchKernelGGL((k_knn_cov<16, true>), grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_tile_base[0], h->d_tlo[0], h->d_thi[0],
+                                   h->d_mlo[0], h->d_mhi[0], k, (double*)nullptr, knn.as<int>());
+            else if (k <= 20)
+                hipLaunchKernelGGL((k_knn_cov<20, true>), grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_tile_base[0], h->d_tlo[0], h->d_thi[0],
+                                   h->d_mlo[0], h->d_mhi[0], k, (double*)nullptr, knn.as<int>());
+            else
+                hipLaunchKernelGGL((k_knn_cov<32, true>), grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_tile_base[0], h->d_tlo[0], h->d_thi[0],
+                                   h->d_mlo[0], h->d_mhi[0], k, (double*)nullptr, knn.as<int>());
+        };
+        if ((st = timed(out_ms[5], select)) != MRS_OK) return fail(st);
+        if ((st = timed(out_ms[6], [&]() {
+                 hipLaunchKernelGGL(k_cov_from_knn, dim3((unsigned)((h->longest_src + 255) / 256), P), dim3(256), 0, s, (const float4*)h->d_pts[0],
+                                    (const int64_t*)h->d_offs[0], k, (const int*)knn.as<int>(), h->d_cov[0], (int*)nullptr);
+             })) != MRS_OK) return fail(st);
+        MRS_HIP_TRY(hipStreamSynchronize(s));
+    }
+    restore();
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return MRS_OK;
+}
+
 int mrs_gicp_batch_fitness(mrs_gicp_batch* h, const double* h_poses, double max_range, double* h_scores,
                            mrs_stream stream)
 {

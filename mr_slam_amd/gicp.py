@@ -125,6 +125,18 @@ class GicpBatch:
                                                         _lib.current_stream(self.device)))
         return e, H.reshape(P, 6, 6), b, (corr.cpu().numpy() if want_corr else None)
 
+    def profile(self, poses, reps=3):
+        """HIP-event duration of every kernel of one outer iteration, launched alone at `poses` (mrs_gicp_batch_profile).
+        Returns (dict of ms, dict of counts)."""
+        P = self.n_pairs
+        poses = np.ascontiguousarray(np.asarray(poses, dtype=np.float64).reshape(P, 16))
+        ms = np.zeros(8, np.float32); cnt = np.zeros(3, np.int64)
+        _lib.check(_lib.load().mrs_gicp_batch_profile(self._h, _lib.ptr(poses), int(reps), _lib.ptr(ms), _lib.ptr(cnt),
+                                                      _lib.current_stream(self.device)))
+        names = ("linearize", "linearize_error_only", "search_round3_all", "certify", "search_round4_all", "knn_select", "cov_from_knn",
+                 "certify_plus_worklist_1mm")
+        return {n: float(v) for n, v in zip(names, ms)}, {"source_points": int(cnt[0]), "correspondences": int(cnt[1]), "worklist_queries_1mm": int(cnt[2])}
+
     def fitness(self, poses, max_range):
         P = self.n_pairs
         poses = np.ascontiguousarray(np.asarray(poses, dtype=np.float64).reshape(P, 16))

@@ -37,6 +37,17 @@ def test_bench_line_contract():
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
     assert d["gicp"]["iterations"] == 6 and d["gicp"]["iters_per_s"] > 0 and d["gicp"]["nn_passes"] == 6
     assert d["gicp"]["cold"]["iters_per_s"] > 0 and d["gicp"]["natural"]["converged"] == 2
+    # north_star's own targets ride in the `roofline` block as scalars (the driver's record keeps those): both rasterisers' HBM fractions,
+    # the GICP rates and a numeric roofline per GICP kernel, each measured with HIP events on a launch of that kernel alone
+    for k in ("bev_scatter_frac", "polar_frac", "gicp_iters_per_s", "gicp_natural_pairs_per_s", "gicp_pairs_per_s_incl_covariances", "gicp_linearize_frac",
+              "gicp_linearize_gbs", "gicp_linearize_ms", "gicp_nn_round3_all_ms", "gicp_nn_certify_ms", "gicp_nn_certified_pass_1mm_ms", "gicp_knn_select_ms",
+              "gicp_cov_from_knn_ms"):
+        assert isinstance(r[k], float) and r[k] > 0, k
+    assert r["gicp_iters_per_s"] == d["gicp"]["iters_per_s"] and r["bev_scatter_frac"] == d["roofline_bev_scatter"]["frac"]
+    for name, blk in d["gicp"]["roofline"].items():
+        if "frac" in blk:
+            assert 0 < blk["frac"] <= 1.0 and abs(blk["achieved"] - blk["bytes"] / (blk["ms"] * 1e-3) / 1e9) < 1e-6 * blk["achieved"], name
+    assert 0 < d["gicp"]["natural"]["searched_fraction"] <= 1.0 and d["gicp"]["kernel_counts"]["correspondences"] > 0
     for leg in ("roofline_polar", "roofline_radon", "sweeps", "pipeline_shard", "dropin_latency"):
         assert leg in d, leg
     assert d["roofline_polar"]["bound"] == "hbm" and d["sweeps"]["ring_q1"]["pairs_per_s"] > 0 and d["sweeps"]["disco_q4"]["queries_per_s"] > 0

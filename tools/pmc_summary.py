@@ -36,12 +36,13 @@ def valu_cycles(mean):
     return sum(mean[k] * c for k, c in CLASS_CYCLES.items()) + max(mean["SQ_INSTS_VALU"] - known, 0.0) * REST_CYCLES
 
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
 KEYS = {"k_cart_lds": "k_cart_lds", "k_polar_lds": "k_polar_lds", "k_radon2": "k_radon2", "k_bev_radon2": "k_bev_radon2", "k_bev_radon3": "k_bev_radon3",
         "k_ring_spec_corr_pairs": "k_ring_spec_corr_pairs", "k_ring_corr_fft": "k_ring_corr_fft", "k_linearize": "k_linearize", "k_nn_scan": "k_nn_scan",
-        "k_knn_cov": "k_knn_cov", "k_knn_features": "k_knn_features"}
+        "k_knn_cov": "k_knn_cov", "k_knn_features": "k_knn_features", "k_nn_scan_g": "k_nn_scan_g", "k_nn_certify": "k_nn_certify",
+        "k_cov_from_knn": "k_cov_from_knn", "k_knn_select": "k_knn_select", "k_feat_from_knn": "k_feat_from_knn"}
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 files = newest(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))) + sorted(glob.glob(os.path.join(src, "pmc_*.csv")))   # raw passes or slimmed ones
 for f in files:

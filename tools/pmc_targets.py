@@ -35,13 +35,17 @@ for nq in (1, 4):
 idx = torch.randint(0, B, (B,), device=dev, dtype=torch.int32)
 for _ in range(3):
     ring.spectrum_corr_pairs_db(norm, spec, idx)
-srcs, tgts = bench._gicp_pairs(16, 0)
-g = gicp.GicpBatch(16, 0)
-g.set_params(k_correspondences=15, max_correspondence_distance=5.0, force_iterations=3)
+# GICP kernels at the bench's timed shape (BASELINE configs[2]: 256 pairs x 120k points): covariances, a cold / moving / settled alignment
+NP = int(os.environ.get("MRS_PMC_GICP_PAIRS", "256"))
+srcs, tgts = bench._gicp_pairs(NP, 0)
+g = gicp.GicpBatch(NP, 0)
+g.set_params(k_correspondences=15, max_correspondence_distance=5.0, force_iterations=8)
 g.set_sources(srcs); g.set_targets(tgts)
 g.align()
+del g, srcs, tgts
 from mr_slam_amd import pointfeat
-pts = whole[0, :8].permute(0, 2, 1).reshape(8 * bench.N_POINTS, 3).contiguous()
-pointfeat.point_features(pts, np.arange(9, dtype=np.int64) * bench.N_POINTS, 30, want=("planes",))      # k_knn_features (RING++ front end)
+NS = int(os.environ.get("MRS_PMC_FEAT_SCANS", "64"))
+pts = whole[0, :NS].permute(0, 2, 1).reshape(NS * bench.N_POINTS, 3).contiguous()
+pointfeat.point_features(pts, np.arange(NS + 1, dtype=np.int64) * bench.N_POINTS, 30, want=("planes",))      # k_knn_features (RING++ front end)
 torch.cuda.synchronize()
 print("pmc targets done")
