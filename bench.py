@@ -134,8 +134,8 @@ def load_pmc():
 # --------------------------------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(scans):
     """The same workload on the host cores with the oracle port (BEV restatement in C, Radon restatement in C + OpenMP,
-    fast_corr restatement on torch CPU) on a bounded sample.  Protocol of SURVEY.md 8(d): `nproc` threads (`value`, `cores`); the 16-thread
-    run of the earlier rounds rides along (`at_16_threads`: the tiny FFTs of fast_corr do not scale past a few threads)."""
+    fast_corr restatement on torch CPU) on a bounded sample, at 16 threads and at `nproc` threads; `value` / `cores` are
+    those of the faster setting, both are in `at_threads`."""
     from oracle import pyoracle as O
     from oracle import corr_oracle as K
     from concurrent.futures import ThreadPoolExecutor
@@ -149,9 +149,8 @@ def cpu_baseline(scans):
     except OSError:
         pass
     ang = np.linspace(0, 2 * np.pi, 120).astype(np.float32)
-    soas = [synth.to_soa(s) for s in scans]
 
-    def run(cores):
+    def run(cores, soas):
         torch.set_num_threads(cores)
         os.environ["OMP_NUM_THREADS"] = str(cores)
         O.set_omp_threads(cores)
@@ -168,18 +167,27 @@ def cpu_baseline(scans):
         for i in range(len(tir)):
             K.fast_corr(tir[i], tir[(i + 1) % len(tir)])
         t3 = time.perf_counter()
-        return {"value": len(scans) / (t3 - t0), "cores": cores,
-                "ms_per_pair": {"bev": 1e3 * (t1 - t0) / len(scans), "radon": 1e3 * (t2 - t1) / len(scans), "fft_corr": 1e3 * (t3 - t2) / len(scans)}}
-    full = run(nproc)
-    out = {"value": full["value"], "unit": "pairs/s", "cores": nproc, "nproc": nproc, "cpu_model": cpu_model, "kind": "port",
-           "sample": f"{len(scans)} scans x 120k pts: C BEV restatement (1 thread per scan, scans over {nproc} threads), "
-                     f"C Radon restatement (OpenMP over images), torch-CPU fast_corr ({nproc} threads)",
-           "ms_per_pair": full["ms_per_pair"]}
+        n = len(soas)
+        return {"value": n / (t3 - t0), "cores": cores, "sample_scans": n,
+                "ms_per_pair": {"bev": 1e3 * (t1 - t0) / n, "radon": 1e3 * (t2 - t1) / n, "fft_corr": 1e3 * (t3 - t2) / n}}
+    # SURVEY.md 8(d) asks for `nproc` threads.  On a 256-thread host the port is SLOWER with all of them (the correlation leg is thousands of tiny
+    # FFTs: 2.7 pairs/s at 256 threads against 1377 at 16 on an EPYC 9575F), so both settings are timed -- the all-threads one on a 32-scan
+    # slice so that the leg stays bounded -- and `value` / `cores` are those of the faster one; both are in the block.
+    all_soas = [synth.to_soa(s) for s in scans]
+    few = run(min(nproc, 16), all_soas)
+    out = {"value": few["value"], "unit": "pairs/s", "cores": few["cores"], "nproc": nproc, "cpu_model": cpu_model, "kind": "port",
+           "sample": f"{len(scans)} scans x 120k pts: C BEV restatement (1 thread per scan, scans over {few['cores']} threads), "
+                     f"C Radon restatement (OpenMP over images), torch-CPU fast_corr ({few['cores']} threads)",
+           "ms_per_pair": few["ms_per_pair"], "at_threads": {str(few["cores"]): few}}
     if nproc > 16:
-        out["at_16_threads"] = run(16)
-        out["value_at_16_threads"] = out["at_16_threads"]["value"]
-    cores = nproc
-    out["gicp"] = cpu_gicp_baseline(cores)
+        allt = run(nproc, all_soas[:32])
+        out["at_threads"][str(nproc)] = allt
+        out["value_at_nproc_threads"] = allt["value"]
+        if allt["value"] > out["value"]:
+            out.update({"value": allt["value"], "cores": nproc, "ms_per_pair": allt["ms_per_pair"],
+                        "sample": f"32 scans x 120k pts, {nproc} threads (C BEV / Radon restatements, torch-CPU fast_corr)"})
+    soas = all_soas
+    out["gicp"] = cpu_gicp_baseline(nproc)
     # the reference's own CPU rasterisers, compiled from its sources (kind "reference"): one thread, and one scan per thread on every core
     def ref_rate(fn, label):
         sample = soas[:128]

@@ -1129,34 +1129,42 @@ __global__ __launch_bounds__(256) void k_nn_certify(const float4* __restrict__ s
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int rank[4];
     bool need[4];
+    // the four points of a lane: every load of a stage is requested before the first one is used (the gathers are what the kernel waits for)
+    float4 a[4], nb[4];
+    int seed[4];
+    float lb[4];
+    bool live[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int i = b0 + j * 256 + (int)threadIdx.x;
-        const bool live = i < n;
+        live[j] = i < n;
+        a[j] = src[live[j] ? i : b0];
+        seed[j] = live[j] ? nn_seed[so + i] : -1;
+        lb[j] = live[j] ? C.lb[so + i] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) nb[j] = tgt[(seed[j] >= 0 && seed[j] < m) ? seed[j] : 0];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = b0 + j * 256 + (int)threadIdx.x;
         bool certified = false;
-        if (live) {
-            const float4 a = src[i];
-            const float qx = Tf[0] * a.x + Tf[1] * a.y + Tf[2] * a.z + Tf[3];
-            const float qy = Tf[4] * a.x + Tf[5] * a.y + Tf[6] * a.z + Tf[7];
-            const float qz = Tf[8] * a.x + Tf[9] * a.y + Tf[10] * a.z + Tf[11];
-            const float px = Tp[0] * a.x + Tp[1] * a.y + Tp[2] * a.z + Tp[3];
-            const float py = Tp[4] * a.x + Tp[5] * a.y + Tp[6] * a.z + Tp[7];
-            const float pz = Tp[8] * a.x + Tp[9] * a.y + Tp[10] * a.z + Tp[11];
-            const int seed = nn_seed[so + i];
-            const float lb = C.lb[so + i];
-            if (seed >= 0 && seed < m && lb > 0.0f) {
-                const float dx = qx - px, dy = qy - py, dz = qz - pz;
-                const float delta = sqrtf(dx * dx + dy * dy + dz * dz);
-                const float lbn = lb - delta * 1.00001f - 1e-6f;
-                const float d1sq = dist2(qx, qy, qz, tgt[seed]);
-                if (sqrtf(d1sq) * 1.00001f + 1e-6f < lbn) {       // (false for NaN)
-                    certified = true;
-                    corr[so + i] = (double)d1sq < prm.max_corr2 ? seed : -1;
-                    C.lb[so + i] = lbn;
-                }
+        if (live[j] && seed[j] >= 0 && seed[j] < m && lb[j] > 0.0f) {
+            const float qx = Tf[0] * a[j].x + Tf[1] * a[j].y + Tf[2] * a[j].z + Tf[3];
+            const float qy = Tf[4] * a[j].x + Tf[5] * a[j].y + Tf[6] * a[j].z + Tf[7];
+            const float qz = Tf[8] * a[j].x + Tf[9] * a[j].y + Tf[10] * a[j].z + Tf[11];
+            const float dx = qx - (Tp[0] * a[j].x + Tp[1] * a[j].y + Tp[2] * a[j].z + Tp[3]);
+            const float dy = qy - (Tp[4] * a[j].x + Tp[5] * a[j].y + Tp[6] * a[j].z + Tp[7]);
+            const float dz = qz - (Tp[8] * a[j].x + Tp[9] * a[j].y + Tp[10] * a[j].z + Tp[11]);
+            const float delta = sqrtf(dx * dx + dy * dy + dz * dz);
+            const float lbn = lb[j] - delta * 1.00001f - 1e-6f;
+            const float d1sq = dist2(qx, qy, qz, nb[j]);
+            if (sqrtf(d1sq) * 1.00001f + 1e-6f < lbn) {       // (false for NaN)
+                certified = true;
+                corr[so + i] = (double)d1sq < prm.max_corr2 ? seed[j] : -1;
+                C.lb[so + i] = lbn;
             }
         }
-        need[j] = live && !certified;
+        need[j] = live[j] && !certified;
         const unsigned long long mk = __ballot(need[j]);
         rank[j] = (int)__popcll(mk & ((1ull << lane) - 1ull));
         if (lane == 0) wcnt[j * 4 + wave] = (int)__popcll(mk);
@@ -2944,9 +2952,24 @@ int mrs_pointfeat_batch(mrs_ctx* ctx, const float* d_points, int32_t stride_floa
                     st = MRS_ERR_HIP;
                 }
             }
-        } else {
+        } else if (core_s && atoi(core_s) == 2) {       // development aid: the round-3 single kernel (selection + eigenvalues + features)
             hipLaunchKernelGGL(k_knn_features<32>, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_tile_base[0],
                                h->d_tlo[0], h->d_thi[0], h->d_mlo[0], h->d_mhi[0], k, d_knn, d_eigens, d_features, d_feat_planes);
+        } else {
+            // default: the round-3 selection WITHOUT the fp64 eigenvalue / feature state (fewer live registers, more waves per SIMD),
+            // the neighbour indices go through a scratch buffer to k_feat_from_knn (same arithmetic, same order)
+            mrs::Scratch knn;
+            st = knn.alloc((size_t)h_offsets[batch] * k * sizeof(int), s);
+            if (st == MRS_OK) {
+                hipLaunchKernelGGL((k_knn_cov<32, true>), grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_tile_base[0], h->d_tlo[0], h->d_thi[0],
+                                   h->d_mlo[0], h->d_mhi[0], k, (double*)nullptr, knn.as<int>());
+                hipLaunchKernelGGL(k_feat_from_knn, dim3((unsigned)((longest + 255) / 256), batch), dim3(256), 0, s, (const float4*)h->d_pts[0],
+                                   (const int64_t*)h->d_offs[0], k, (const int*)knn.as<int>(), d_knn, d_eigens, d_features, d_feat_planes);
+                if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+                    mrs::set_error("k_feat_from_knn launch failed");
+                    st = MRS_ERR_HIP;
+                }
+            }
         }
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
             mrs::set_error("k_knn_features launch failed");

@@ -1,0 +1,30 @@
+"""margin / motion-switch sweep of the round-4 GICP schedule (development aid; MRS_DEV=1 is set here)"""
+import json, os, sys, time
+os.environ["MRS_DEV"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+from mr_slam_amd import gicp
+n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+srcs, tgts = bench._gicp_pairs(n_pairs, 0)
+b = gicp.GicpBatch(n_pairs)
+b.set_params(k_correspondences=15, max_correspondence_distance=5.0)
+b.set_sources(srcs); b.set_targets(tgts)
+b.compute_covariances(0); b.compute_covariances(1)
+torch.cuda.synchronize()
+ref = None
+for margin, switch in ((0.004, 0.02), (0.002, 0.02), (0.008, 0.02), (0.004, 0.01), (0.004, 0.05), (0.004, 0.1), (0.006, 0.05), (0.003, 0.05)):
+    os.environ["MRS_CERT_MARGIN"] = str(margin); os.environ["MRS_MOTION_SWITCH"] = str(switch)
+    res = {}
+    for name, prm in (("forced20", dict(force_iterations=20)), ("natural", dict(force_iterations=0))):
+        b.set_sources(srcs); b.compute_covariances(0)           # cold seeds
+        b.set_params(**prm)
+        torch.cuda.synchronize(); t = time.perf_counter()
+        T, conv, its = b.align()
+        torch.cuda.synchronize(); dt = time.perf_counter() - t
+        res[name] = (round(1e3 * dt, 2), round(b.searched_fraction, 3))
+        if name == "natural":
+            if ref is None:
+                ref = T
+            res["same"] = bool(np.array_equal(T, ref))
+    print(margin, switch, res, flush=True)
