@@ -651,6 +651,8 @@ def main():
     ap.add_argument("--sweep-stream", choices=("main", "side"), default="side", help="N = 1: the per-launch database sweeps on the compute stream, or on "
                     "a second HIP stream so that they fill the tail of the next descriptor kernel (N > 1 with --exchange fetch always uses the "
                     "side stream); joined before the step ends")
+    ap.add_argument("--sweep-batch", type=int, choices=(0, 1), default=1, help="N = 1 with grouped correlation: the per-launch sweeps of a group (one query per "
+                    "launch, each against the database slot its launch reads) as ONE kernel launch over (query, slot) blocks instead of one launch per sweep")
     ap.add_argument("--fused-wgs", type=int, default=0, help="persistent workgroups of the descriptor kernel (0 = one per compute unit); fewer leave "
                     "compute units to the side-stream sweeps while the descriptor kernel runs")
     ap.add_argument("--sweep-join", choices=("step", "lag"), default="lag", help="--sweep-stream side: the compute stream joins the side stream at the "
@@ -773,6 +775,17 @@ def main():
         parity[0] = 0
     if SIDE_SWEEP:
         side = torch.cuda.Stream(device=device)
+    SWEEP_BATCH = bool(GROUP_CORR and RING_DB and args.sweep_batch)
+    if SWEEP_BATCH:
+        # per step parity: the pool entry of every launch's query (first new descriptor of the launch) and the first entry of the slot it sweeps
+        sw_q, sw_db = [], []
+        for par in (0, 1):
+            parity[0] = par
+            sw_q.append(torch.tensor([wslot(c) * B for c in range(CH)], dtype=torch.int64, device=device))
+            sw_db.append(torch.tensor([db_slot(c) * B for c in range(CH)], dtype=torch.int64, device=device))
+        parity[0] = 0
+        sw_d = torch.empty((FUSE, B), dtype=torch.float32, device=device)
+        sw_a = torch.empty((FUSE, B), dtype=torch.int32, device=device)
     pending = []                                       # (work, source tensor) of the exchanges still in flight, oldest first
     launch_no = [0]
     rescorer = shard.OwnerRescorer(DIST_THRESHOLD, margin=2e-3, slots=64) if (EXCH == "allgather" and not REP32) else None
@@ -815,9 +828,14 @@ def main():
             s0 = torch.cuda.Event(enable_timing=True) if record else None
             if record:
                 s0.record()
-            for cc in launches:
-                d, a = ring.corr_sweep_fft(spec32[wslot(cc), :1], spec32[db_slot(cc)])
-                torch.min(d, 1, out=(sweep_val[cc:cc + 1], sweep_row[cc:cc + 1]))
+            if SWEEP_BATCH and len(launches) > 1:
+                c0, ng = launches[0], len(launches)
+                d, a = ring.corr_sweep_fft_blocks(spec_flat, sw_q[parity[0]][c0:c0 + ng], sw_db[parity[0]][c0:c0 + ng], B, out=(sw_d[:ng], sw_a[:ng]))
+                torch.min(d, 1, out=(sweep_val[c0:c0 + ng], sweep_row[c0:c0 + ng]))
+            else:
+                for cc in launches:
+                    d, a = ring.corr_sweep_fft(spec32[wslot(cc), :1], spec32[db_slot(cc)])
+                    torch.min(d, 1, out=(sweep_val[cc:cc + 1], sweep_row[cc:cc + 1]))
             if record:
                 s1 = torch.cuda.Event(enable_timing=True); s1.record()
                 ev["sweep"].append((s0, s1, len(launches)))
@@ -1103,6 +1121,7 @@ def main():
             line["config"]["fused_launches"] = FUSE
             line["config"]["corr_launches_grouped"] = FUSE if GROUP_CORR else 1
             line["config"]["sweep_stream"] = "side" if (SIDE_SWEEP or EXCH == "fetch") else "main"
+            line["config"]["sweeps_per_launch"] = FUSE if SWEEP_BATCH else 1
             if SIDE_SWEEP:
                 line["config"]["sweep_join"] = args.sweep_join
             if args.fused_wgs > 0:

@@ -408,6 +408,11 @@ int mrs_ring_corr_fft_sweep(mrs_ctx* ctx, const float* d_query_spec, int32_t n_q
                             int32_t n_db, float* d_dist, int32_t* d_angle, float* d_corr, mrs_stream stream);
 int mrs_ring_corr_fft_pairs(mrs_ctx* ctx, const float* d_a_spec, const float* d_b_spec, int32_t n_pairs,
                             float* d_dist, int32_t* d_angle, float* d_corr, mrs_stream stream);
+/* Several sweeps in one launch (the loop of main_RING.py:133-140 for a batch of new scans, each against ITS OWN slice of one descriptor
+ * pool): query q is entry d_query_row[q] of d_spec ([entries][61][120] complex64) and sweeps the n_db entries that start at entry
+ * d_db_first[q] (device int64 arrays, n_query <= 65535); d_dist / d_angle [n_query][n_db] as in mrs_ring_corr_fft_sweep. */
+int mrs_ring_corr_fft_sweep_blocks(mrs_ctx* ctx, const float* d_spec, const int64_t* d_query_row, int32_t n_query, const int64_t* d_db_first,
+                                   int32_t n_db, float* d_dist, int32_t* d_angle, mrs_stream stream);
 
 /* One launch for the new-descriptor side of a batch of loop checks: half spectra of n_pairs freshly normalised
  * sinograms (d_half_spec and/or its fp16 replica, either may be null) and their correlation with one candidate

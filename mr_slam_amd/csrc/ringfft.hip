@@ -199,6 +199,8 @@ __device__ __forceinline__ void wave_abs_reduce_scatter(const v2f (&x)[60], floa
 struct FftCorrP {
     int nq, ndb, pairwise, channels;
     float denom;  // 0.15 * C * A * D
+    const long long* db_first;   // optional (sweeps): query q sweeps the ndb entries that start at entry db_first[q] of DB (NULL: entry 0)
+    const long long* q_row;      // optional (sweeps): query q is entry q_row[q] of Q (NULL: entry q)
 };
 
 __device__ __forceinline__ float2 load_spec(const float2* p) { return *p; }
@@ -225,7 +227,8 @@ __global__ __launch_bounds__(NSLOT* kSlotThreads) void k_ring_corr_fft(const flo
     const bool live_col = t < kD;
     const int C = MULTI ? p.channels : 1;
     const size_t entry = (size_t)C * kHalf * kD;
-    const float2* qsrc = Q + (size_t)q * entry;
+    const float2* qsrc = Q + (size_t)((!PAIRWISE && p.q_row) ? p.q_row[q] : q) * entry;
+    if (!PAIRWISE && p.db_first) DB += (size_t)p.db_first[q] * entry;
     if (QLDS) {
         for (int i = threadIdx.x; i < kHalf * kLdsStride; i += NSLOT * kSlotThreads) {
             const int k = i / kLdsStride, col = i % kLdsStride;
@@ -595,7 +598,8 @@ int mrs_ring_half_spectrum_f16(mrs_ctx* ctx, const float* d_norm_sino, int32_t n
 extern "C++" {
 template <typename DBT>
 static int corr_fft_launch(mrs_ctx* ctx, const float* d_q, int32_t n_q, const void* d_db, int32_t n_db, int32_t channels,
-                           float* d_dist, int32_t* d_angle, float* d_corr, mrs_stream stream, bool pairwise)
+                           float* d_dist, int32_t* d_angle, float* d_corr, mrs_stream stream, bool pairwise,
+                           const long long* d_db_first = nullptr, const long long* d_q_row = nullptr)
 {
     MRS_REQUIRE(ctx && d_q && d_db && d_dist && d_angle, "null pointer");
     MRS_REQUIRE(n_q > 0 && n_db > 0 && channels > 0, "counts must be positive");
@@ -603,6 +607,9 @@ static int corr_fft_launch(mrs_ctx* ctx, const float* d_q, int32_t n_q, const vo
     FftCorrP p;
     p.nq = n_q; p.ndb = n_db; p.pairwise = pairwise ? 1 : 0; p.channels = channels;
     p.denom = (float)(0.15 * channels * kA * kD);
+    p.db_first = d_db_first; p.q_row = d_q_row;
+    MRS_REQUIRE(!(d_db_first || d_q_row) || (!pairwise && channels == 1 && std::is_same<DBT, float2>::value && n_q <= mrs::kMaxGridY),
+                "per-query database blocks: single-channel fp32 sweeps of at most 65535 queries");
     constexpr int NSLOT = 2;
     hipStream_t s = (hipStream_t)stream;
     const float2* q2 = reinterpret_cast<const float2*>(d_q);
@@ -678,6 +685,15 @@ int mrs_ring_corr_fft_sweep(mrs_ctx* ctx, const float* d_query_spec, int32_t n_q
                             int32_t n_db, float* d_dist, int32_t* d_angle, float* d_corr, mrs_stream stream)
 {
     return corr_fft_launch<float2>(ctx, d_query_spec, n_query, d_db_spec, n_db, 1, d_dist, d_angle, d_corr, stream, false);
+}
+
+int mrs_ring_corr_fft_sweep_blocks(mrs_ctx* ctx, const float* d_spec, const int64_t* d_query_row, int32_t n_query, const int64_t* d_db_first,
+                                   int32_t n_db, float* d_dist, int32_t* d_angle, mrs_stream stream)
+{
+    MRS_REQUIRE(d_query_row && d_db_first, "null pointer");
+    static_assert(sizeof(long long) == sizeof(int64_t), "int64_t is long long here");
+    return corr_fft_launch<float2>(ctx, d_spec, n_query, d_spec, n_db, 1, d_dist, d_angle, nullptr, stream, false,
+                                   reinterpret_cast<const long long*>(d_db_first), reinterpret_cast<const long long*>(d_query_row));
 }
 
 int mrs_ring_corr_fft_sweep_f16(mrs_ctx* ctx, const float* d_query_spec, int32_t n_query, const void* d_db_spec_f16,

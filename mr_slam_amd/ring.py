@@ -450,6 +450,21 @@ def corr_sweep_fft(query_spec, db_spec, want_corr=False):
     return (dist, ang, corr) if want_corr else (dist, ang)
 
 
+def corr_sweep_fft_blocks(spec_pool, query_rows, db_first, n_db, out=None):
+    """Several C1 sweeps in one launch: query q = entry query_rows[q] of spec_pool ([E,61,120] complex64) against the n_db entries that start
+    at entry db_first[q] (int64 device tensors).  Returns (dist [Q,n_db], angle [Q,n_db]); bit-identical to corr_sweep_fft per query."""
+    d = _dev(spec_pool)
+    assert spec_pool.dtype == torch.complex64 and spec_pool.is_contiguous() and spec_pool.shape[1:] == (61, 120)
+    qr, df = query_rows.contiguous(), db_first.contiguous()
+    assert qr.dtype == torch.int64 and df.dtype == torch.int64 and qr.numel() == df.numel()
+    Q = qr.numel()
+    dist, ang = out if out is not None else (torch.empty((Q, n_db), dtype=torch.float32, device=spec_pool.device),
+                                             torch.empty((Q, n_db), dtype=torch.int32, device=spec_pool.device))
+    _lib.check(_lib.load().mrs_ring_corr_fft_sweep_blocks(_lib.ctx(d), _lib.ptr(torch.view_as_real(spec_pool)), _lib.ptr(qr), Q, _lib.ptr(df), int(n_db),
+                                                          _lib.ptr(dist), _lib.ptr(ang), _lib.current_stream(d)))
+    return dist, ang
+
+
 def corr_pairs_fft(a_spec, b_spec, out=None):
     """Pairwise C1/C2 on half spectra [P,61,120] (or RING++ [P,C,61,120]) complex64 -> (dist [P], angle [P])."""
     d = _dev(a_spec)

@@ -494,3 +494,23 @@ def test_multi_round_sweeps_equal_the_pairwise_kernel_bit_for_bit(dev):
             wd, wa = ring.corr_pairs_fft(qpp[qi:qi + 1].expand(len(pick), -1, -1, -1).contiguous(), spp[pick].contiguous())
             assert torch.equal(d[qi, pick], wd) and torch.equal(a[qi, pick], wa)
     assert int(torch.argmin(d[0])) == 5 and int(torch.argmin(d[1])) == n_pp - 1
+
+
+def test_blocked_sweeps_equal_single_sweeps_bit_for_bit(dev):
+    """mrs_ring_corr_fft_sweep_blocks: several (query, database slice) sweeps of one descriptor pool in ONE launch (bench.py: the 16 per-launch
+    sweeps of a group) give exactly what one mrs_ring_corr_fft_sweep per query gives -- overlapping, adjacent and repeated slices, a
+    query that lies inside its own slice, slices that end at the pool's last entry."""
+    import torch
+    from mr_slam_amd import ring
+    g = torch.Generator(device=dev).manual_seed(9)
+    n_pool, n_db = 3000, 700
+    sino = torch.rand((n_pool, 120, 120), device=dev, generator=g) * (torch.rand((n_pool, 120, 120), device=dev, generator=g) < 0.3)
+    pool = ring.half_spectrum(ring.normalize(sino[:, None])[:, 0]).contiguous()
+    qrow = torch.tensor([5, 2999, 100, 100, 1234, 0, 2300], dtype=torch.int64, device=dev)
+    first = torch.tensor([0, 2300, 50, 0, 1234, 2300, 1600], dtype=torch.int64, device=dev)
+    d, a = ring.corr_sweep_fft_blocks(pool, qrow, first, n_db)
+    assert d.shape == (7, n_db)
+    for i in range(qrow.numel()):
+        wd, wa = ring.corr_sweep_fft(pool[int(qrow[i]):int(qrow[i]) + 1], pool[int(first[i]):int(first[i]) + n_db])
+        assert torch.equal(d[i], wd[0]) and torch.equal(a[i], wa[0]), i
+    assert int(torch.argmin(d[0])) == 5 and int(torch.argmin(d[2])) == 50 and int(torch.argmin(d[4])) == 0     # the query itself where its slice holds it
