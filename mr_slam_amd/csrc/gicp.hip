@@ -2952,12 +2952,13 @@ int mrs_pointfeat_batch(mrs_ctx* ctx, const float* d_points, int32_t stride_floa
                     st = MRS_ERR_HIP;
                 }
             }
-        } else if (core_s && atoi(core_s) == 2) {       // development aid: the round-3 single kernel (selection + eigenvalues + features)
+        } else if (!(core_s && atoi(core_s) == 2)) {     // default: one kernel (selection + eigenvalues + features)
             hipLaunchKernelGGL(k_knn_features<32>, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_tile_base[0],
                                h->d_tlo[0], h->d_thi[0], h->d_mlo[0], h->d_mhi[0], k, d_knn, d_eigens, d_features, d_feat_planes);
         } else {
-            // default: the round-3 selection WITHOUT the fp64 eigenvalue / feature state (fewer live registers, more waves per SIMD),
-            // the neighbour indices go through a scratch buffer to k_feat_from_knn (same arithmetic, same order)
+            // development aid (2): the selection without the fp64 eigenvalue / feature state, neighbour indices through a scratch buffer to
+            // k_feat_from_knn (same arithmetic, same order).  Measured SLOWER for k = 30 (27.5 against 22.9 ms per 64 scans): the 32-slot
+            // selection is register-bound either way (158 VGPRs) and the index round trip adds 0.9 GB of traffic
             mrs::Scratch knn;
             st = knn.alloc((size_t)h_offsets[batch] * k * sizeof(int), s);
             if (st == MRS_OK) {
