@@ -966,7 +966,7 @@ __global__ __launch_bounds__(kNNThreads) void k_nn_scan(
 // Two poses: the Mahalanobis matrices belong to the linearisation pose S.x (upstream caches them in
 // update_correspondences), the residuals to the evaluated pose S.xi.  Phase 0: xi == x, all 28 sums
 // (FastGICP::linearize); phase 1: only the error sum (FastGICP::compute_error of an LM trial).
-__global__ __launch_bounds__(kNNThreads) void k_linearize(
+__global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_linearize(
     const float4* __restrict__ src_all, const int64_t* __restrict__ src_offs, const double* __restrict__ src_cov,
     const float4* __restrict__ tgt_all, const int64_t* __restrict__ tgt_offs, const double* __restrict__ tgt_cov,
     const LmState* __restrict__ st, const int* __restrict__ corr, double* __restrict__ partial, int max_blocks)
@@ -989,14 +989,22 @@ __global__ __launch_bounds__(kNNThreads) void k_linearize(
     for (int i = 0; i < kTerms; ++i) acc[i] = 0.0;
     const int per_block = kNNThreads * kPts;  // same point -> block mapping as the scan (fixed summation order)
     for (int base = blockIdx.x * per_block; base < n; base += gridDim.x * per_block) {
+        // software pipeline over the lane's kPts points (a rolled loop: one copy of the algebra): the correspondence index travels two
+        // points ahead, the point's own data and its gathered neighbour one point ahead of the algebra (the gathers are what the kernel
+        // waits for); the order of the sums does not change
+        auto idx_of = [&](int p) { const int i = base + p * kNNThreads + (int)threadIdx.x; return (p < kPts && i < n) ? corr[so + i] : -1; };
+        int j_cur = idx_of(0), j_nx = idx_of(1);
+        float4 a_nx = make_float4(0.f, 0.f, 0.f, 0.f), b_nx = a_nx;
+        if (j_cur >= 0) { a_nx = src[base + threadIdx.x]; b_nx = tgt[j_cur]; }
 #pragma unroll 1
         for (int p = 0; p < kPts; ++p) {
             const int i = base + p * kNNThreads + threadIdx.x;
-            if (i >= n) continue;
-            const int j = corr[so + i];
+            const int j = j_cur;
+            const float4 a = a_nx, bb = b_nx;
+            j_cur = j_nx;
+            j_nx = idx_of(p + 2);
+            if (j_cur >= 0) { a_nx = src[i + kNNThreads]; b_nx = tgt[j_cur]; }
             if (j < 0) continue;
-            const float4 a = src[i];
-            const float4 bb = tgt[j];
             const double* ca = src_cov + 6 * (size_t)(so + i);
             const double* cb = tgt_cov + 6 * (size_t)(to + j);
             const double CA[9] = {ca[0], ca[1], ca[2], ca[1], ca[3], ca[4], ca[2], ca[4], ca[5]};

@@ -4,7 +4,7 @@
 # Every step runs under its own `timeout`: one --pmc pass of round 3 hung for 37 minutes (profiler, not the kernels: the same pass took 8 s before).
 # PMC passes carry no tracing flags (gpurun refuses --pmc together with trace domains).  The raw counter CSVs of a pass hold every torch
 # kernel of the scan synthesis and exceed what gpurun copies back: only the rows of this library's kernels are kept (pmc_<group>.csv).
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -15,7 +15,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -
 for f in $(find $OUT/stats -name '*kernel_stats.csv'); do cp $f $OUT/kernel_stats.csv; done; rm -rf $OUT/stats
 fi
 slim() { d=$1; for f in $(find $d -name '*counter_collection.csv'); do (head -1 $f; grep -E 'k_[a-z_0-9]+[<(]' $f) > $d.csv; done; rm -rf $d; }
-pass() { name=$1; shift; timeout 150 rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$name -- python $R/tools/pmc_targets.py > $OUT/pmc_$name.log 2>&1; slim $OUT/pmc_$name; }
+pass() { name=$1; shift; timeout 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$name -- python $R/tools/pmc_targets.py > $OUT/pmc_$name.log 2>&1; slim $OUT/pmc_$name; }
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass valu SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
