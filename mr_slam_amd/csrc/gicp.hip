@@ -513,6 +513,7 @@ __device__ __forceinline__ void knn_insert(float (&dk)[KMAX], int (&ik)[KMAX], f
 // close to final before the first tile is scanned, which spares most of the insertions of a cold start.  The
 // tile scan then skips exactly that index range (no duplicates).
 constexpr int kHome = 64;
+constexpr int kKnnSpare = 8;      // list slots beyond KMAX: room for candidates tied with the k-th distance before the tie-safe pass is needed
 template <int KMAX>
 __device__ __forceinline__ int knn_seed_home(const float4* __restrict__ pts, int n, int i, bool live, const float4& q,
                                              float (&dk)[KMAX], int (&ik)[KMAX])
@@ -565,7 +566,7 @@ __device__ __forceinline__ void knn_insert_tie(float (&dk)[KMAX], int (&ik)[KMAX
 }
 
 // dk / ik: the k nearest of point i (itself included), ascending in (distance, index); slots >= the number found hold +inf / -1.
-// list: kNNThreads x KMAX ints of LDS, slot-major.
+// list: kNNThreads x (KMAX + kKnnSpare) ints of LDS, slot-major.
 template <int KMAX>
 __device__ __forceinline__ void knn_two_pass(int* __restrict__ list, const float4* __restrict__ pts, int n, const Hier& H,
                                              int i, bool live, const float4& q, int k, float (&dk)[KMAX], int (&ik)[KMAX])
@@ -598,30 +599,48 @@ __device__ __forceinline__ void knn_two_pass(int* __restrict__ list, const float
                        dist_insert<KMAX>(dk, use ? dd[u] : INFINITY);
                    }
                });
-    // pass 2: every candidate within the k-th distance, home range included.  Strictly closer candidates (at most k - 1) fill the list from
-    // the bottom, exact ties with the k-th distance from slot k - 1 downwards; ties arrive in ascending index order and one is only kept
-    // while the list still has room for it (at most k - #closer can be needed), so a cluster of duplicates can neither overflow the list
-    // nor push a closer point out (round-3 review: with more than 8 ties ahead of them in Morton order closer neighbours were dropped)
+    // pass 2: every candidate within the k-th distance, home range included, appended to the lane's list (KMAX + 8 slots: room for 8 exact
+    // ties with the k-th distance beyond the k - 1 strictly closer candidates).  A lane that would need more (a cluster of duplicates:
+    // round-3 review -- closer neighbours were dropped when more than 8 ties preceded them in Morton order) makes its WAVE repeat the pass
+    // with the tie-safe bookkeeping: strictly closer candidates from the bottom of the list, ties from slot k - 1 downwards (they arrive in
+    // ascending index order; one is only kept while the list still has room for it, at most k - #closer can be needed).
+    constexpr int CAP = KMAX + kKnnSpare;
     const int kk = k < KMAX ? k : KMAX;
     const float tau = live ? dk[kk - 1] : -1.0f;
-    int nlt = 0, ntie = 0;
+    int cnt = 0;
+    bool spilled = false;
     hier_visit(pts, n, H, lo, hi, wave_max(tau), q.x, q.y, q.z,
                [&](const float4& blo, const float4& bhi) { return live && box_point_d2(blo, bhi, q.x, q.y, q.z) * 0.9999f <= tau; },
                [&](int j0, const float (&dd)[8]) {
                    ++c_g2;
 #pragma unroll
-                   for (int u = 0; u < 8; ++u) {
+                   for (int u = 0; u < 8; ++u)
                        if (dd[u] <= tau && dd[u] < INFINITY) {     // tau is +inf for a cloud with fewer than k points: padding stays out
-                           const bool tie = dd[u] == tau;
-                           if (!tie && nlt + ntie == kk && ntie > 0) --ntie;
-                           if (nlt + ntie < kk) {
-                               list[(tie ? kk - 1 - ntie : nlt) * kNNThreads + (int)threadIdx.x] = j0 + u;
-                               nlt += tie ? 0 : 1;
-                               ntie += tie ? 1 : 0;
+                           if (cnt < CAP) list[cnt * kNNThreads + (int)threadIdx.x] = j0 + u;
+                           else spilled = true;
+                           ++cnt;
+                       }
+               });
+    int nlt = min(cnt, CAP), ntie = 0;       // fast path: every collected candidate goes through the (distance, index) insertion below
+    const bool safe = __any(spilled);
+    if (safe) {
+        nlt = 0;
+        hier_visit(pts, n, H, lo, hi, wave_max(tau), q.x, q.y, q.z,
+                   [&](const float4& blo, const float4& bhi) { return live && box_point_d2(blo, bhi, q.x, q.y, q.z) * 0.9999f <= tau; },
+                   [&](int j0, const float (&dd)[8]) {
+#pragma unroll
+                       for (int u = 0; u < 8; ++u) {
+                           if (dd[u] < tau) {                 // at most k - 1 of these; a tie in the way was not needed
+                               list[min(nlt, KMAX - 1) * kNNThreads + (int)threadIdx.x] = j0 + u;
+                               ++nlt;
+                               ntie = min(ntie, kk - nlt);
+                           } else if (dd[u] == tau && dd[u] < INFINITY && nlt + ntie < kk) {
+                               list[(kk - 1 - ntie) * kNNThreads + (int)threadIdx.x] = j0 + u;
+                               ++ntie;
                            }
                        }
-                   }
-               });
+                   });
+    }
     // selection: (distance, index) order
 #pragma unroll
     for (int s = 0; s < KMAX; ++s) { dk[s] = INFINITY; ik[s] = -1; }
@@ -633,12 +652,15 @@ __device__ __forceinline__ void knn_two_pass(int* __restrict__ list, const float
         atomicAdd(&g_knn_dbg[6], 1ull);
     }
     for (int c = 0; c < most; ++c) {
-        const bool ha = c < nlt, hb = c < ntie;
+        const bool ha = c < nlt, hb = safe && c < ntie;
         const int ja = ha ? list[c * kNNThreads + (int)threadIdx.x] : 0;
         const int jb = hb ? list[(kk - 1 - c) * kNNThreads + (int)threadIdx.x] : 0;
-        const float da = dist2(q.x, q.y, q.z, pts[ja]), db = dist2(q.x, q.y, q.z, pts[jb]);
+        const float da = dist2(q.x, q.y, q.z, pts[ja]);
         if (ha) knn_insert_tie<KMAX>(dk, ik, da, ja);
-        if (hb) knn_insert_tie<KMAX>(dk, ik, db, jb);
+        if (safe) {
+            const float db = dist2(q.x, q.y, q.z, pts[jb]);
+            if (hb) knn_insert_tie<KMAX>(dk, ik, db, jb);
+        }
     }
 }
 
@@ -656,7 +678,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(KMAX
         const float4* __restrict__ mlo, const float4* __restrict__ mhi,
                                                         int k, double* __restrict__ cov_all, int* __restrict__ knn_out)
 {
-    __shared__ int knn_list[KMAX * kNNThreads];
+    __shared__ int knn_list[(KMAX + kKnnSpare) * kNNThreads];
     const int c = blockIdx.y;
     const int64_t o = offs[c];
     const int n = (int)(offs[c + 1] - o);
@@ -820,7 +842,7 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_features(const float4* __res
                                                              int k, int* __restrict__ knn_out, float* __restrict__ eig_out,
                                                              float* __restrict__ feat_out, float* __restrict__ feat_planes)
 {
-    __shared__ int knn_list[KMAX * kNNThreads];
+    __shared__ int knn_list[(KMAX + kKnnSpare) * kNNThreads];
     const int c = blockIdx.y;
     const int64_t o = offs[c];
     const int n = (int)(offs[c + 1] - o);
@@ -1354,8 +1376,9 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_select(const float4* __restr
                             [&](int j, float d, bool ok) {
                                 if (!(ok && live)) return;
                                 if (d < tau) {
-                                    if (nlt + ntie == k && ntie > 0) --ntie;           // the tie with the largest index is no longer needed
-                                    if (nlt + ntie < k) { lst[nlt * kNNThreads + tid] = j; ++nlt; }
+                                    lst[min(nlt, KMAX - 1) * kNNThreads + tid] = j;     // at most k - 1 of these; a tie in the way was not needed
+                                    ++nlt;
+                                    ntie = min(ntie, k - nlt);
                                 } else if (d == tau && d < INFINITY && nlt + ntie < k) {
                                     lst[(k - 1 - ntie) * kNNThreads + tid] = j;
                                     ++ntie;
@@ -1968,6 +1991,8 @@ struct mrs_gicp_batch {
     bool use_certificates = true;   // search_core 1: certify unchanged neighbours before searching (k_nn_certify)
     CertArrays cert = {nullptr, nullptr, nullptr, nullptr, 0, nullptr};
     double last_searched = 0;       // share of (source point, pass) that needed a search in the last align()
+    bool want_leaf_hier = true;     // build the octree-cell hierarchy in set_clouds (false: RING++ front end)
+    bool hier_valid[2] = {false, false};
     int big_movers = 1;             // pairs whose last step exceeded motion_switch (counted by k_lm_update): do they need the round-3 kernel?
     HierArrays hier(int w) const
     {
@@ -2125,6 +2150,7 @@ int nn_pass(mrs_gicp_batch* h, int mode, hipStream_t s)
 {
     const dim3 wg((unsigned)((h->longest_src + kCertBlock - 1) / kCertBlock), h->n_pairs);      // one workgroup per 1024 source points
     const dim3 pg((h->n_pairs + 255) / 256);
+    MRS_REQUIRE(h->search_core == 0 || h->hier_valid[1], "target hierarchy missing: set the target clouds after choosing the search setting");
     auto round3 = [&](int gate) {
         launch_nn_scan(h->longest_src, h->n_pairs, h->ctx->num_cu, s, h->d_pts[0], h->d_offs[0], h->d_pts[1], h->d_offs[1],
                        h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_mlo[1], h->d_mhi[1], h->d_state, h->prm, h->d_corr, h->d_seed,
@@ -2373,7 +2399,13 @@ int mrs_gicp_batch_set_clouds(mrs_gicp_batch* h, int32_t which, const float* d_p
     hipLaunchKernelGGL(k_boxes, dim3(longest_tiles, h->n_pairs), dim3(256), 0, s, h->d_pts[which], h->d_offs[which],
                        h->d_tile_base[which], h->d_tlo[which], h->d_thi[which], h->d_mlo[which], h->d_mhi[which]);
     MRS_HIP_TRY(hipGetLastError());
-    if ((st = build_leaf_hier(h, which, keys_out.as<unsigned long long>(), total, s)) != MRS_OK) return st;
+    // the octree-cell hierarchy serves the round-4 searches: correspondences search the TARGETS (which == 1); the sources need it only
+    // for the round-4 k-NN kernel (setting 3); the RING++ front end (want_leaf_hier = false) not at all
+    h->hier_valid[which] = false;
+    if (h->want_leaf_hier && (which == 1 || (h->search_core == 1 && h->cold_core == 1))) {
+        if ((st = build_leaf_hier(h, which, keys_out.as<unsigned long long>(), total, s)) != MRS_OK) return st;
+        h->hier_valid[which] = true;
+    }
     MRS_HIP_TRY(hipStreamSynchronize(s));
     return MRS_OK;
 }
@@ -2408,6 +2440,7 @@ int mrs_gicp_batch_compute_covariances(mrs_gicp_batch* h, int32_t which, int32_t
     const dim3 grid((unsigned)((longest + kNNThreads - 1) / kNNThreads), h->n_pairs);
     const int k = h->prm.k;
     if (h->search_core == 1 && h->cold_core == 1) {     // setting 3: the round-4 k-NN kernel (slower than the round-3 one on the bench's scans)
+        MRS_REQUIRE(h->hier_valid[which], "search setting 3 was selected after set_clouds: set the clouds again");
         mrs::Scratch knn;
         int st = knn.alloc((size_t)h->offs[which][h->n_pairs] * k * sizeof(int), s);
         if (st != MRS_OK) return st;
@@ -2941,6 +2974,11 @@ int mrs_pointfeat_batch(mrs_ctx* ctx, const float* d_points, int32_t stride_floa
     mrs_gicp_batch* h = nullptr;   // reuse the Morton-ordered cloud container of the GICP front-end
     int st = mrs_gicp_batch_create(ctx, batch, &h);
     if (st != MRS_OK) return st;
+    {
+        const char* cs = mrs::dev_env("MRS_NN_CORE");
+        h->want_leaf_hier = cs && atoi(cs) == 1;
+        if (h->want_leaf_hier) { h->search_core = 1; h->cold_core = 1; }
+    }
     st = mrs_gicp_batch_set_clouds(h, 0, d_points, stride_floats, h_offsets, stream);
     if (st == MRS_OK) {
         hipStream_t s = (hipStream_t)stream;
