@@ -23,7 +23,10 @@ def timeit(fn, n=10):
     return a.elapsed_time(b) / n
 
 
-out = []
+import hashlib
+d, a = ring.corr_sweep_fft(sq[:4], sdb)[:2]
+digest = hashlib.sha1(d.cpu().numpy().tobytes() + a.cpu().numpy().tobytes()).hexdigest()[:12]      # same bits across variants?
+out = [f"sha {digest}"]
 for nq in (1, 2, 4, 8):
     ms = timeit(lambda: ring.corr_sweep_fft(sq[:nq], sdb))
     ms16 = timeit(lambda: ring.corr_sweep_fft(sq[:nq], sdb16))
