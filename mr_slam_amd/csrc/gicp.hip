@@ -672,7 +672,7 @@ __device__ __forceinline__ void knn_two_pass(int* __restrict__ list, const float
 // SPLIT: only the selection -- the neighbours go to knn_out as cloud-local SORTED-space indices [point][k] and k_cov_from_knn does the
 // fp64 tail: without the covariance / eigenvector state the selection keeps fewer registers alive (more waves per SIMD).
 template <int KMAX, bool SPLIT = false>
-__global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(KMAX <= 16 ? 5 : 1))) void k_knn_cov(const float4* __restrict__ pts_all,
+__global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(KMAX <= 16 ? (SPLIT ? 6 : 5) : (SPLIT ? 4 : 1)))) void k_knn_cov(const float4* __restrict__ pts_all,
                                                         const int64_t* __restrict__ offs, const int* __restrict__ tile_base,
                                                         const float4* __restrict__ tlo, const float4* __restrict__ thi,
         const float4* __restrict__ mlo, const float4* __restrict__ mhi,
@@ -1456,7 +1456,7 @@ __global__ __launch_bounds__(256) void k_cov_from_knn(const float4* __restrict__
 }
 
 // N1 tail: covariance / eigenvalues / the 13 features of every point from its k neighbours (k_knn_features' arithmetic, same order)
-__global__ __launch_bounds__(256) void k_feat_from_knn(const float4* __restrict__ pts_all, const int64_t* __restrict__ offs, int k,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_feat_from_knn(const float4* __restrict__ pts_all, const int64_t* __restrict__ offs, int k,
                                                       const int* __restrict__ knn, int* __restrict__ knn_out, float* __restrict__ eig_out,
                                                       float* __restrict__ feat_out, float* __restrict__ feat_planes)
 {
@@ -2998,13 +2998,13 @@ int mrs_pointfeat_batch(mrs_ctx* ctx, const float* d_points, int32_t stride_floa
                     st = MRS_ERR_HIP;
                 }
             }
-        } else if (!(core_s && atoi(core_s) == 2)) {     // default: one kernel (selection + eigenvalues + features)
+        } else if (core_s && atoi(core_s) == 2) {     // development aid: one kernel (selection + eigenvalues + features), the round-3 form
             hipLaunchKernelGGL(k_knn_features<32>, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_tile_base[0],
                                h->d_tlo[0], h->d_thi[0], h->d_mlo[0], h->d_mhi[0], k, d_knn, d_eigens, d_features, d_feat_planes);
         } else {
-            // development aid (2): the selection without the fp64 eigenvalue / feature state, neighbour indices through a scratch buffer to
-            // k_feat_from_knn (same arithmetic, same order).  Measured SLOWER for k = 30 (27.5 against 22.9 ms per 64 scans): the 32-slot
-            // selection is register-bound either way (158 VGPRs) and the index round trip adds 0.9 GB of traffic
+            // default: the selection without the fp64 eigenvalue / feature state (k_knn_cov<32, SPLIT>: capped at 128 VGPRs = 4 waves per SIMD, the
+            // traversal is latency-bound), neighbour indices through a scratch buffer to k_feat_from_knn (same arithmetic, same order as the fused
+            // kernel).  64 scans: 20.1 ms against 26.6 for the one-kernel form (236 VGPRs, 2 waves per SIMD); split at 2 / 3 waves per SIMD: 27.5 / 22.5
             mrs::Scratch knn;
             st = knn.alloc((size_t)h_offsets[batch] * k * sizeof(int), s);
             if (st == MRS_OK) {

@@ -15,7 +15,7 @@ for rep in range(2):
     torch.cuda.synchronize(); t = time.perf_counter() - t0
     print(f"covariances: {2 * P} clouds in {t * 1e3:.1f} ms = {1e3 * t / (2 * P) * 256:.1f} ms per 256 clouds, {2 * P / t:.0f} clouds/s", flush=True)
     b.set_sources(srcs); b.set_targets(tgts)
-S = 32
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 pts = torch.from_numpy(np.concatenate([s for s in srcs[:S]])).cuda()
 offs = np.arange(S + 1, dtype=np.int64) * srcs[0].shape[0]
 for rep in range(2):
