@@ -13,7 +13,10 @@ b.set_sources(srcs); b.set_targets(tgts)
 b.compute_covariances(0); b.compute_covariances(1)
 torch.cuda.synchronize()
 ref = None
-for margin, switch in ((0.004, 0.02), (0.002, 0.02), (0.008, 0.02), (0.004, 0.01), (0.004, 0.05), (0.004, 0.2)):
+sweep = ((0.004, 0.02), (0.002, 0.02), (0.008, 0.02), (0.004, 0.01), (0.004, 0.05), (0.004, 0.2))
+if len(sys.argv) > 2 and sys.argv[2] == "default":      # three runs at the defaults (A/B of kernel changes)
+    sweep = ((0.004, 0.02),) * 3
+for margin, switch in sweep:
     os.environ["MRS_CERT_MARGIN"] = str(margin); os.environ["MRS_MOTION_SWITCH"] = str(switch)
     res = {}
     for name, prm in (("cold5", dict(force_iterations=5)), ("forced20", dict(force_iterations=20)), ("natural", dict(force_iterations=0))):
@@ -27,4 +30,4 @@ for margin, switch in ((0.004, 0.02), (0.002, 0.02), (0.008, 0.02), (0.004, 0.01
             if ref is None:
                 ref = T
             res["same"] = bool(np.array_equal(T, ref))
-    print("margin", margin, "switch", switch, res, flush=True)
+    print("margin", margin, "switch", switch, res, "sum|T|", float(np.abs(T).sum()), flush=True)
