@@ -53,6 +53,10 @@ for f in files:
         k = m.group(1)
         if k == "k_ring_corr_fft":
             k += "@grid%s" % r["Grid_Size"]
+        if k == "k_knn_cov":                       # k = 15 covariances (16 slots) and the k = 30 point-feature selection (32 slots) are different kernels
+            t = re.search(r"k_knn_cov<\s*(\d+)", r["Kernel_Name"])
+            if t:
+                k += "<%s>" % t.group(1)
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for k, c in sorted(acc.items()):
