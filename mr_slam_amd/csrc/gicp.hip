@@ -159,9 +159,10 @@ __device__ __forceinline__ float wave_max(float v)
 //   * a hit mini is then tested exactly (`need`: any lane whose own ball touches the box, current bounds) and its 16 candidates are
 //     read with wave-uniform addresses (scalar / broadcast loads out of L2) as two groups of 8 squared distances handed to `visit`.
 // Conservative at every level (0.9999 slack on the box distances), so the neighbours found are the exact ones.
-template <class Need, class Visit>
+struct NoRec { __device__ __forceinline__ void operator()(int) const {} };
+template <class Need, class Visit, class Rec = NoRec>
 __device__ __forceinline__ void hier_visit(const float4* __restrict__ pts, int n, const Hier& H, const float (&wlo)[3], const float (&whi)[3],
-                                           float reach, float qx, float qy, float qz, Need need, Visit visit)
+                                           float reach, float qx, float qy, float qz, Need need, Visit visit, Rec rec = Rec())
 {
     const int lane = threadIdx.x & 63;
     for (int tb = 0; tb < H.ntiles; tb += 64) {
@@ -179,6 +180,7 @@ __device__ __forceinline__ void hier_visit(const float4* __restrict__ pts, int n
                 mmask &= mmask - 1;
                 const float4 lo = H.mlo[tt * 64 + m], hi = H.mhi[tt * 64 + m];
                 if (!__any(need(lo, hi))) continue;
+                rec(tt * 64 + m);
                 const int j0 = tt * kTile + m * 16;
                 float4 c[16];          // all 16 candidates requested before the first use (wave-uniform addresses: scalar loads)
 #pragma unroll
@@ -194,6 +196,32 @@ __device__ __forceinline__ void hier_visit(const float4* __restrict__ pts, int n
                     visit(j0 + 8 * h, dd);
                 }
             }
+        }
+    }
+}
+
+// The minis a previous walk of the same wave visited (ids 64 tile + mini, ascending), without the tile / mini box tests of a second walk
+template <class Need, class Visit>
+__device__ __forceinline__ void mini_list_visit(const float4* __restrict__ pts, int n, const Hier& H, const int* __restrict__ ids, int n_ids,
+                                                float qx, float qy, float qz, Need need, Visit visit)
+{
+    for (int r = 0; r < n_ids; ++r) {
+        const int id = __builtin_amdgcn_readfirstlane(ids[r]);
+        const float4 lo = H.mlo[id], hi = H.mhi[id];
+        if (!__any(need(lo, hi))) continue;
+        const int j0 = id * 16;
+        float4 c[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) c[u] = j0 + u < n ? pts[j0 + u] : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float dd[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float dx = qx - c[8 * h + u].x, dy = qy - c[8 * h + u].y, dz = qz - c[8 * h + u].z;
+                dd[u] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            }
+            visit(j0 + 8 * h, dd);
         }
     }
 }
@@ -513,7 +541,7 @@ __device__ __forceinline__ void knn_insert(float (&dk)[KMAX], int (&ik)[KMAX], f
 // close to final before the first tile is scanned, which spares most of the insertions of a cold start.  The
 // tile scan then skips exactly that index range (no duplicates).
 constexpr int kHome = 64;
-constexpr int kKnnSpare = 8;      // list slots beyond KMAX: room for candidates tied with the k-th distance before the tie-safe pass is needed
+constexpr int kKnnSpare = 8;      // (7 for 32 slots, so that list + kKnnRec ints per wave stay within 40 KB: four workgroups per compute unit) list slots beyond KMAX: room for candidates tied with the k-th distance before the tie-safe pass is needed
 template <int KMAX>
 __device__ __forceinline__ int knn_seed_home(const float4* __restrict__ pts, int n, int i, bool live, const float4& q,
                                              float (&dk)[KMAX], int (&ik)[KMAX])
@@ -567,9 +595,12 @@ __device__ __forceinline__ void knn_insert_tie(float (&dk)[KMAX], int (&ik)[KMAX
 
 // dk / ik: the k nearest of point i (itself included), ascending in (distance, index); slots >= the number found hold +inf / -1.
 // list: kNNThreads x (KMAX + kKnnSpare) ints of LDS, slot-major.
+__host__ __device__ constexpr int knn_spare(int kmax) { return kmax > 20 ? kKnnSpare - 1 : kKnnSpare; }
+constexpr int kKnnRec = 64;       // minis a wave can note in pass 1 for pass 2 (more: pass 2 walks the hierarchy again)
 template <int KMAX>
 __device__ __forceinline__ void knn_two_pass(int* __restrict__ list, const float4* __restrict__ pts, int n, const Hier& H,
-                                             int i, bool live, const float4& q, int k, float (&dk)[KMAX], int (&ik)[KMAX])
+                                             int i, bool live, const float4& q, int k, float (&dk)[KMAX], int (&ik)[KMAX],
+                                             int* __restrict__ rec_ids = nullptr /* wave-private, kKnnRec ints of LDS */)
 {
 #pragma unroll
     for (int s = 0; s < KMAX; ++s) dk[s] = INFINITY;
@@ -586,6 +617,7 @@ __device__ __forceinline__ void knn_two_pass(int* __restrict__ list, const float
     float hi[3] = {live ? q.x : -INFINITY, live ? q.y : -INFINITY, live ? q.z : -INFINITY};
     wave_bbox(lo, hi);
     int c_g1 = 0, c_ins = 0, c_g2 = 0;
+    int nrec = 0;       // wave-uniform
     hier_visit(pts, n, H, lo, hi, wave_max(live ? dk[KMAX - 1] : 0.0f), q.x, q.y, q.z,
                [&](const float4& blo, const float4& bhi) { return live && box_point_d2(blo, bhi, q.x, q.y, q.z) * 0.9999f <= dk[KMAX - 1]; },
                [&](int j0, const float (&dd)[8]) {
@@ -598,29 +630,38 @@ __device__ __forceinline__ void knn_two_pass(int* __restrict__ list, const float
                        const bool use = live && (unsigned)(j0 + u - home) >= (unsigned)kHome && dd[u] == dd[u];
                        dist_insert<KMAX>(dk, use ? dd[u] : INFINITY);
                    }
+               },
+               [&](int id) {       // every mini within some lane's bound of the moment (a superset of the minis within the final bounds)
+                   if (rec_ids && nrec < kKnnRec && (threadIdx.x & 63) == 0) rec_ids[nrec] = id;
+                   ++nrec;
                });
     // pass 2: every candidate within the k-th distance, home range included, appended to the lane's list (KMAX + 8 slots: room for 8 exact
     // ties with the k-th distance beyond the k - 1 strictly closer candidates).  A lane that would need more (a cluster of duplicates:
     // round-3 review -- closer neighbours were dropped when more than 8 ties preceded them in Morton order) makes its WAVE repeat the pass
     // with the tie-safe bookkeeping: strictly closer candidates from the bottom of the list, ties from slot k - 1 downwards (they arrive in
     // ascending index order; one is only kept while the list still has room for it, at most k - #closer can be needed).
-    constexpr int CAP = KMAX + kKnnSpare;
+    constexpr int CAP = KMAX + knn_spare(KMAX);
     const int kk = k < KMAX ? k : KMAX;
     const float tau = live ? dk[kk - 1] : -1.0f;
     int cnt = 0;
     bool spilled = false;
-    hier_visit(pts, n, H, lo, hi, wave_max(tau), q.x, q.y, q.z,
-               [&](const float4& blo, const float4& bhi) { return live && box_point_d2(blo, bhi, q.x, q.y, q.z) * 0.9999f <= tau; },
-               [&](int j0, const float (&dd)[8]) {
-                   ++c_g2;
+    auto need2 = [&](const float4& blo, const float4& bhi) { return live && box_point_d2(blo, bhi, q.x, q.y, q.z) * 0.9999f <= tau; };
+    auto visit2 = [&](int j0, const float (&dd)[8]) {
+        ++c_g2;
 #pragma unroll
-                   for (int u = 0; u < 8; ++u)
-                       if (dd[u] <= tau && dd[u] < INFINITY) {     // tau is +inf for a cloud with fewer than k points: padding stays out
-                           if (cnt < CAP) list[cnt * kNNThreads + (int)threadIdx.x] = j0 + u;
-                           else spilled = true;
-                           ++cnt;
-                       }
-               });
+        for (int u = 0; u < 8; ++u)
+            if (dd[u] <= tau && dd[u] < INFINITY) {     // tau is +inf for a cloud with fewer than k points: padding stays out
+                if (cnt < CAP) list[cnt * kNNThreads + (int)threadIdx.x] = j0 + u;
+                else spilled = true;
+                ++cnt;
+            }
+    };
+    if (rec_ids && nrec <= kKnnRec) {       // the minis pass 1 visited, in the same order, without walking the hierarchy again
+        nnc::wave_lds_sync();
+        mini_list_visit(pts, n, H, rec_ids, nrec, q.x, q.y, q.z, need2, visit2);
+    } else {
+        hier_visit(pts, n, H, lo, hi, wave_max(tau), q.x, q.y, q.z, need2, visit2);
+    }
     int nlt = min(cnt, CAP), ntie = 0;       // fast path: every collected candidate goes through the (distance, index) insertion below
     const bool safe = __any(spilled);
     if (safe) {
@@ -678,7 +719,8 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(KMAX
         const float4* __restrict__ mlo, const float4* __restrict__ mhi,
                                                         int k, double* __restrict__ cov_all, int* __restrict__ knn_out)
 {
-    __shared__ int knn_list[(KMAX + kKnnSpare) * kNNThreads];
+    __shared__ int knn_list[(KMAX + knn_spare(KMAX)) * kNNThreads];
+    __shared__ int knn_rec[kNNThreads / 64][kKnnRec];
     const int c = blockIdx.y;
     const int64_t o = offs[c];
     const int n = (int)(offs[c + 1] - o);
@@ -693,7 +735,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(KMAX
         const float4 q = pts[live ? i : 0];
         float dk[KMAX];
         int ik[KMAX];
-        knn_two_pass<KMAX>(knn_list, pts, n, H, i, live, q, k, dk, ik);
+        knn_two_pass<KMAX>(knn_list, pts, n, H, i, live, q, k, dk, ik, SPLIT ? knn_rec[threadIdx.x >> 6] : nullptr);
         if (!live) continue;
         if (SPLIT) {
 #pragma unroll
@@ -842,7 +884,7 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_features(const float4* __res
                                                              int k, int* __restrict__ knn_out, float* __restrict__ eig_out,
                                                              float* __restrict__ feat_out, float* __restrict__ feat_planes)
 {
-    __shared__ int knn_list[(KMAX + kKnnSpare) * kNNThreads];
+    __shared__ int knn_list[(KMAX + knn_spare(KMAX)) * kNNThreads];
     const int c = blockIdx.y;
     const int64_t o = offs[c];
     const int n = (int)(offs[c + 1] - o);
