@@ -1217,7 +1217,22 @@ def main():
             dst_buf = torch.empty_like(src_buf)
             ms = ev_ms(lambda: dst_buf.copy_(src_buf), reps=5, warm=2)
             copy_gbs = 2 * src_buf.numel() * 4 / ms / 1e6
+            ms_fill = ev_ms(lambda: dst_buf.zero_(), reps=5, warm=2)
+            fill_gbs = src_buf.numel() * 4 / ms_fill / 1e6
             del dst_buf
+            # the polar rasteriser writes 21 % of its bytes (384 KB of cells per scan); this memory system streams writes slower than reads, so its
+            # bound is the mix of the two stream rates measured on this box: the read-mostly Cartesian rasteriser's rate for the points, a fill's
+            # rate for the cells
+            rp = line["roofline_polar"]
+            read_gbs = line.get("roofline_bev_scatter", {}).get("achieved")
+            if read_gbs:
+                rd, wr = B * 12 * N_POINTS, B * 4 * pcells
+                mix = (rd + wr) / (rd / read_gbs + wr / fill_gbs)
+                rp.update({"read_stream_gbs": read_gbs, "write_stream_gbs": fill_gbs, "write_share": wr / (rd + wr), "mix_bound_gbs": mix,
+                           "frac_of_mix_bound": rp["achieved"] / mix})
+                line["roofline"]["polar_frac_of_rw_mix_bound"] = rp["achieved"] / mix
+            line["roofline"]["measured_fill_gbs"] = fill_gbs
+            line["roofline"]["polar_frac_of_measured_copy"] = rp["achieved"] / copy_gbs
             line["roofline"]["polar_frac"] = line["roofline_polar"]["frac"]
             line["roofline"]["polar_gbs"] = line["roofline_polar"]["achieved"]
             line["roofline"]["measured_copy_gbs"] = copy_gbs
