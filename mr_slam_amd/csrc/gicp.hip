@@ -570,6 +570,7 @@ __device__ __forceinline__ int knn_seed_home(const float4* __restrict__ pts, int
 // where some lane's list changed, selection steps, query waves
 __device__ unsigned long long g_knn_dbg[8];
 __device__ int g_knn_dbg_on;       // set by the host when MRS_KNN_DBG is in the environment
+__device__ int g_knn_norec;        // development aid (MRS_KNN_REC=0): pass 2 walks the hierarchy again instead of revisiting pass 1's minis
 
 template <int KMAX>
 __device__ __forceinline__ void dist_insert(float (&dk)[KMAX], float d)
@@ -735,7 +736,7 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(KMAX
         const float4 q = pts[live ? i : 0];
         float dk[KMAX];
         int ik[KMAX];
-        knn_two_pass<KMAX>(knn_list, pts, n, H, i, live, q, k, dk, ik, SPLIT ? knn_rec[threadIdx.x >> 6] : nullptr);
+        knn_two_pass<KMAX>(knn_list, pts, n, H, i, live, q, k, dk, ik, (SPLIT && !g_knn_norec) ? knn_rec[threadIdx.x >> 6] : nullptr);
         if (!live) continue;
         if (SPLIT) {
 #pragma unroll
@@ -2497,6 +2498,16 @@ int mrs_gicp_batch_compute_covariances(mrs_gicp_batch* h, int32_t which, int32_t
     if (mrs::dev_env("MRS_KNN_DBG")) {
         const int on = 1;
         MRS_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_knn_dbg_on), &on, sizeof(on)));
+    }
+    {
+        const char* const e = mrs::dev_env("MRS_KNN_REC");      // development aid, read per call (the tests flip it): 0 = no mini list
+        const int off = (e && atoi(e) == 0) ? 1 : 0;
+        static int cur = 0;
+        if (off != cur) {
+            MRS_HIP_TRY(hipStreamSynchronize(s));
+            MRS_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_knn_norec), &off, sizeof(off)));
+            cur = off;
+        }
     }
     static const char* const split_s = mrs::dev_env("MRS_KNN_SPLIT");      // development aid: 0 = selection and covariances in one kernel
     if (!(split_s && atoi(split_s) == 0)) {

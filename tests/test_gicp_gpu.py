@@ -355,6 +355,32 @@ def test_knn_exact_on_adversarial_clouds(dev, oracle, k):
         assert (res[0][:, kk:] == -1).all() and all(len(set(r[:kk])) == kk for r in res[0][:: max(1, n // 500)]), name
 
 
+@pytest.mark.parametrize("k", [15, 30])
+def test_knn_second_pass_forms_agree(dev, k):
+    """Pass 2 of the k-NN selection revisits the minis pass 1 noted (wave-private list, 64 entries; a wave that noted more walks the hierarchy
+    again).  Both forms must return the same neighbour INDICES on every cloud: the development switch MRS_KNN_REC=0 forces the walk."""
+    import os
+    from mr_slam_amd import gicp
+    old = {v: os.environ.get(v) for v in ("MRS_DEV", "MRS_KNN_REC")}
+    try:
+        for name, cloud in _clouds_for_search_tests().items():
+            res = []
+            for rec in ("1", "0"):
+                os.environ["MRS_DEV"] = "1"; os.environ["MRS_KNN_REC"] = rec
+                b = gicp.GicpBatch(1)
+                b.set_params(k_correspondences=k)
+                b.set_sources([cloud])
+                res.append(b.compute_covariances(0, want_knn=True).cpu().numpy())
+            assert np.array_equal(res[0], res[1]), name
+    finally:
+        for v, x in old.items():
+            if x is None:
+                os.environ.pop(v, None)
+            else:
+                os.environ[v] = x
+        b = gicp.GicpBatch(1); b.set_sources([_clouds_for_search_tests()["seventeen"]]); b.compute_covariances(0)      # back to the default form
+
+
 def test_correspondences_agree_between_search_cores(dev, oracle):
     """k_nn_scan_g (round 4) and k_nn_scan (round 3) on the same pairs and poses: the same squared distance for every source point
     (indices may differ only at exact ties), cold and warm-started, with and without a correspondence threshold."""
