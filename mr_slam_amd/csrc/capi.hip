@@ -181,6 +181,8 @@ int mrs_ctx_destroy(mrs_ctx* ctx)
     }
     for (auto& kv : ctx->twiddles)
         if (kv.second) (void)hipFree(kv.second);
+    if (ctx->pointfeat_free)
+        for (auto& kv : ctx->pointfeat_cache) ctx->pointfeat_free(kv.second);
     delete ctx;
     return MRS_OK;
 }

@@ -88,4 +88,10 @@ struct mrs_ctx {
     std::map<int, mrs::SectorLut> sector_luts;  // keyed by num_sector
     // device-resident constant tables for the correlation / Radon kernels (lazily built)
     std::map<int, float*> twiddles;             // keyed by FFT length
+    // mrs_pointfeat_batch keeps its Morton-ordered cloud container between calls (keyed by the number of scans per call, at most 4 sizes):
+    // creating and freeing ~1.5 GB of device buffers per call cost as much as the kernels on some boxes.  One caller at a time uses a cached
+    // container (try_lock); a concurrent caller works on a temporary one.
+    std::mutex pointfeat_mu;
+    std::map<int, void*> pointfeat_cache;
+    void (*pointfeat_free)(void*) = nullptr;    // set by gicp.hip when it caches a container
 };

@@ -2035,6 +2035,7 @@ struct mrs_gicp_batch {
     CertArrays cert = {nullptr, nullptr, nullptr, nullptr, 0, nullptr};
     double last_searched = 0;       // share of (source point, pass) that needed a search in the last align()
     bool want_leaf_hier = true;     // build the octree-cell hierarchy in set_clouds (false: RING++ front end)
+    bool no_cov = false;            // RING++ front end: no covariance buffers
     bool hier_valid[2] = {false, false};
     int big_movers = 1;             // pairs whose last step exceeded motion_switch (counted by k_lm_update): do they need the round-3 kernel?
     HierArrays hier(int w) const
@@ -2376,7 +2377,7 @@ int mrs_gicp_batch_set_clouds(mrs_gicp_batch* h, int32_t which, const float* d_p
         const int capt = tiles + tiles / 8 + 1;
         MRS_HIP_TRY(hipMalloc(&h->d_offs[which], (h->n_pairs + 1) * sizeof(int64_t)));
         MRS_HIP_TRY(hipMalloc(&h->d_pts[which], (size_t)cap * sizeof(float4)));
-        MRS_HIP_TRY(hipMalloc(&h->d_cov[which], (size_t)cap * 6 * sizeof(double)));
+        if (!h->no_cov) MRS_HIP_TRY(hipMalloc(&h->d_cov[which], (size_t)cap * 6 * sizeof(double)));
         MRS_HIP_TRY(hipMalloc(&h->d_tile_base[which], h->n_pairs * sizeof(int)));
         MRS_HIP_TRY(hipMalloc(&h->d_tlo[which], (size_t)capt * sizeof(float4)));
         MRS_HIP_TRY(hipMalloc(&h->d_thi[which], (size_t)capt * sizeof(float4)));
@@ -3024,9 +3025,25 @@ int mrs_pointfeat_batch(mrs_ctx* ctx, const float* d_points, int32_t stride_floa
     MRS_REQUIRE(batch > 0, "batch must be positive");
     MRS_REQUIRE(k >= 2 && k <= 32, "k must be in [2, 32]");
     MRS_REQUIRE(d_knn || d_eigens || d_features || d_feat_planes, "no output requested");
-    mrs_gicp_batch* h = nullptr;   // reuse the Morton-ordered cloud container of the GICP front-end
-    int st = mrs_gicp_batch_create(ctx, batch, &h);
-    if (st != MRS_OK) return st;
+    // the Morton-ordered cloud container of the GICP front end, kept per context and batch size between calls (see mrs_ctx::pointfeat_cache)
+    mrs_gicp_batch* h = nullptr;
+    bool cached = false;
+    int st = MRS_OK;
+    std::unique_lock<std::mutex> lk(ctx->pointfeat_mu, std::try_to_lock);
+    if (lk.owns_lock()) {
+        auto it = ctx->pointfeat_cache.find(batch);
+        if (it != ctx->pointfeat_cache.end()) { h = static_cast<mrs_gicp_batch*>(it->second); cached = true; }
+    }
+    if (!h) {
+        st = mrs_gicp_batch_create(ctx, batch, &h);
+        if (st != MRS_OK) return st;
+        h->no_cov = true;          // no covariance buffer (48 B per point) for the feature front end
+        if (lk.owns_lock() && ctx->pointfeat_cache.size() < 4) {
+            ctx->pointfeat_cache[batch] = h;
+            ctx->pointfeat_free = [](void* p) { (void)mrs_gicp_batch_destroy(static_cast<mrs_gicp_batch*>(p)); };
+            cached = true;
+        }
+    }
     {
         const char* cs = mrs::dev_env("MRS_NN_CORE");
         h->want_leaf_hier = cs && atoi(cs) == 1;
@@ -3076,7 +3093,7 @@ int mrs_pointfeat_batch(mrs_ctx* ctx, const float* d_points, int32_t stride_floa
             st = MRS_ERR_HIP;
         }
     }
-    mrs_gicp_batch_destroy(h);
+    if (!cached) mrs_gicp_batch_destroy(h);
     return st;
 }
 

@@ -83,3 +83,39 @@ def test_generate_ringplusplus_end_to_end(dev, oracle):
     np.testing.assert_allclose(sino.numpy(), want_sino, rtol=1e-6, atol=1e-6)
     want_t, _ = K.forward_row_fft(want_sino)
     np.testing.assert_allclose(tiring.numpy(), want_t.numpy(), rtol=1e-4, atol=1e-4 * want_t.numpy().max())
+
+
+def test_cached_container_reuse_and_concurrent_callers(dev):
+    """mrs_pointfeat_batch keeps its cloud container per context between calls (grow-only buffers) and hands a concurrent caller a temporary
+    one: repeated calls with growing / shrinking clouds and two threads at once must return what a fresh call returns, bit for bit."""
+    import threading
+    import torch
+    from mr_slam_amd import pointfeat, synth
+    sizes = [3000, 9000, 1200, 9000, 6000]
+    clouds = [synth.lidar_scan(60 + i, n) for i, n in enumerate(sizes)]
+
+    def run(pc, stream=None):
+        pts = torch.from_numpy(pc).to(dev)
+        offs = np.array([0, pc.shape[0]], np.int64)
+        if stream is None:
+            out = pointfeat.point_features(pts, offs, 30, want=("knn", "features"))
+        else:
+            with torch.cuda.stream(stream):
+                out = pointfeat.point_features(pts, offs, 30, want=("knn", "features"))
+            stream.synchronize()
+        return out["knn"].cpu().numpy(), out["features"].cpu().numpy()
+
+    first = [run(pc) for pc in clouds]                 # one container (batch of 1), grown and re-used
+    again = [run(pc) for pc in reversed(clouds)][::-1]
+    for (k0, f0), (k1, f1) in zip(first, again):
+        assert np.array_equal(k0, k1) and np.array_equal(f0.view(np.int32), f1.view(np.int32))
+    res = [None] * len(clouds)
+
+    def worker(i):
+        res[i] = run(clouds[i], torch.cuda.Stream())
+    for rep in range(3):
+        ths = [threading.Thread(target=worker, args=(i,)) for i in range(len(clouds))]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        for (k0, f0), (k1, f1) in zip(first, res):
+            assert np.array_equal(k0, k1) and np.array_equal(f0.view(np.int32), f1.view(np.int32))
