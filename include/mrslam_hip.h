@@ -386,7 +386,9 @@ int mrs_pointfeat_from_neighbors_host(mrs_ctx* ctx, const float* h_points, int32
  * int64[batch+1].  Outputs (each optional) in the caller's point order: d_knn int32[N][k],
  * d_eigens float[N][5], d_features float[N][13], d_feat_planes float[9*N]: per scan the channel-major
  * planes x,y,z,C,O,E,L2,dZ,vZ, i.e. exactly the input of mrs_bev_feat_batch with featsize 9.
- * Synchronises `stream`. */
+ * Synchronises `stream`.  The Morton-ordered working copy of the clouds (~60 B per point) stays in the context between calls, per value of
+ * `batch` (at most four) and grow-only, and is released by mrs_ctx_destroy; calls from several threads are safe (one of them uses the kept
+ * buffers, the others temporary ones). */
 int mrs_pointfeat_batch(mrs_ctx* ctx, const float* d_points, int32_t stride_floats, const int64_t* h_offsets,
                         int32_t batch, int32_t k, int32_t* d_knn, float* d_eigens, float* d_features,
                         float* d_feat_planes, mrs_stream stream);
