@@ -15,6 +15,10 @@ bench.make_shard(B, G, 0, dev)
 whole = bench.make_shard.whole
 offs = torch.arange(G * B + 1, dtype=torch.int64, device=dev) * bench.N_POINTS
 out = torch.empty((G * B, 120, 120), dtype=torch.float32, device=dev)
+if os.environ.get("PMC_FUSED_GRID"):       # fewer persistent workgroups than compute units (tools/run_pmc_raster.sh)
+    plan = ring.ring_plan(0)
+    plan.set_option(plan.OPT_FUSED_GRID, int(os.environ["PMC_FUSED_GRID"]))
+    plan.set_option(plan.OPT_FUSED_STAGGER_US, 0)
 for _ in range(3):
     ring.ring_descriptors_fused(whole.view(-1), offs, raw=False, normalized=True, out_norm=out)
 torch.cuda.synchronize()
