@@ -416,6 +416,17 @@ int mrs_ring_corr_fft_pairs(mrs_ctx* ctx, const float* d_a_spec, const float* d_
 int mrs_ring_corr_fft_sweep_blocks(mrs_ctx* ctx, const float* d_spec, const int64_t* d_query_row, int32_t n_query, const int64_t* d_db_first,
                                    int32_t n_db, float* d_dist, int32_t* d_angle, mrs_stream stream);
 
+/* DMA-tiled database entries: the 7 320 complex values of a half spectrum permuted so that every 1-KiB LDS-DMA wave-instruction of the
+ * one-query sweep (gfx950 `global_load_lds_dwordx4`) reads ONE contiguous, 128-byte aligned block (csrc/ringfft.hip: kTiledEntryBytes):
+ * 58 624 bytes per entry (58 560 + 64 of padding).  The array must be followed by at least 1 KiB of readable memory (row 30 is a half block).
+ * mrs_ring_spec_to_tiled: d_half_spec [n][61][120] complex64 -> d_tiled [n][58 624 B].
+ * mrs_ring_corr_fft_sweep_tiled: ONE query (row layout, [channels][61][120] complex64) against n_db entries of `channels` tiled planes each
+ * (channels = 1: RING; 6: RING++); outputs as mrs_ring_corr_fft_sweep / _mc, bit-identical to them.  This is the sweep behind mrs_loopdb_query (the node's loop, main_RING.py:133-140). */
+#define MRS_RING_TILED_ENTRY_BYTES 58624
+int mrs_ring_spec_to_tiled(mrs_ctx* ctx, const float* d_half_spec, int32_t n, float* d_tiled, mrs_stream stream);
+int mrs_ring_corr_fft_sweep_tiled(mrs_ctx* ctx, const float* d_query_spec, const float* d_db_tiled, int32_t n_db, int32_t channels, float* d_dist,
+                                  int32_t* d_angle, mrs_stream stream);
+
 /* One launch for the new-descriptor side of a batch of loop checks: half spectra of n_pairs freshly normalised
  * sinograms (d_half_spec and/or its fp16 replica, either may be null) and their correlation with one candidate
  * spectrum each (d_cand_spec [n_pairs][61][120] complex64).  Results are bitwise those of mrs_ring_half_spectrum
@@ -491,6 +502,55 @@ int mrs_voxel_downsample_approx_host(mrs_ctx* ctx, const void* h_points, int32_t
 int mrs_crop_scale_batch(mrs_ctx* ctx, const void* d_points, int32_t is_double, int32_t stride,
                          const int64_t* d_raw_offsets, const int64_t* h_raw_offsets, int32_t batch,
                          float* d_xyz_soa, int64_t* d_out_offsets, mrs_stream stream);
+
+/* ------------------------------------------------------------------------------------
+ * Loop database: the per-robot descriptor lists of the LoopDetection nodes, resident on the device
+ * ---------------------------------------------------------------------------------- */
+
+/* The reference keeps one Python list of descriptors per robot, appends one entry per callback and scores every new scan
+ * against every entry of the other robots' lists in a Python loop:
+ *   RING   : TIRING<k>.append(pc_TIRING) / `for idx in range(len(pc_candidates)): fast_corr(TIRING_current, TIRING_candidates[idx])`
+ *            (RING_ros/main_RING.py:284-288, 126-140)
+ *   RING++ : the same with fast_corr_RINGplusplus (RING_ros/main_RINGplusplus.py:126-134)
+ *   DiSCO  : DiSCO<k>.append / FFT<k>.append, `KDTree(np.array(DiSCO_candidates)).query(DiSCO_current, k=1)` + phase_corr of the winner
+ *            (disco_ros/main.py:276-291, 356-360)
+ * A mrs_loopdb is that list on the device: entries are stored in the format the sweep kernels stream (RING: DMA-tiled half spectra,
+ * RING++: [C][61][120] half spectra of the jointly normalised channels, DiSCO: 1024-d signatures + 40 x 120 spectra), an append writes
+ * ONE slot (amortised doubling, nothing is re-uploaded), a query is ONE sweep over all entries.  Thread-safe (one lock per handle; the
+ * reference's callbacks run on concurrent rospy threads); all device work of a handle runs on the handle's own stream, `stream` is the
+ * stream that produced a DEVICE argument (the handle waits for it; for appends it is made to wait until the argument has been consumed). */
+typedef struct mrs_loopdb mrs_loopdb;
+enum mrs_loopdb_kind { MRS_LOOPDB_RING = 0, MRS_LOOPDB_RINGPP = 1, MRS_LOOPDB_DISCO = 2 };
+/* where / what a RING or RING++ descriptor argument is:
+ *   HOST / DEVICE : the reference's own object -- RING: pc_TIRING, complex64 [1][120][120] (util.py:198; its first 61 rows are what is
+ *                   kept); RING++: pc_TIRING, float32 [C][120][120] magnitudes (util.py:247-250; normalised jointly + transformed along the
+ *                   angle axis here, once, instead of at every comparison as util.py:339-343 does)
+ *   DEVICE_SPEC   : half spectra in the product's row layout, complex64 [C][61][120] (mrs_ring_half_spectrum / mrs_ring_spectrum_corr_pairs) */
+enum mrs_loopdb_form { MRS_LOOPDB_FORM_HOST = 0, MRS_LOOPDB_FORM_DEVICE = 1, MRS_LOOPDB_FORM_DEVICE_SPEC = 2 };
+
+/* channels: 1 for RING, C (6 in the reference) for RING++, ignored for DiSCO; capacity_hint: entries to allocate up front (>= 1) */
+int mrs_loopdb_create(mrs_ctx* ctx, int32_t kind, int32_t channels, int32_t capacity_hint, mrs_loopdb** out);
+int mrs_loopdb_destroy(mrs_loopdb* db);
+int mrs_loopdb_size(mrs_loopdb* db, int32_t* out_n);
+int mrs_loopdb_reserve(mrs_loopdb* db, int32_t capacity);
+int mrs_loopdb_clear(mrs_loopdb* db);
+/* `TIRING<k>.append(descriptor)`.  count > 1 only with DEVICE_SPEC (a batch producer appending `count` consecutive half spectra). */
+int mrs_loopdb_append(mrs_loopdb* db, const void* descriptor, int32_t form, int32_t count, mrs_stream stream);
+/* The candidate loop of detect_loop_icp (main_RING.py:133-140): scores `descriptor` against every entry with one sweep and returns, in
+ * index order, the entries with dist < dist_threshold (float32 comparison): h_index / h_dist / h_angle [max_out] and *h_count (the number
+ * that qualified; when it exceeds max_out only the first max_out were written).  h_all_dist / h_all_angle (optional, [size]) receive the
+ * score of every entry.  Blocking; an empty database returns *h_count = 0 without device work. */
+int mrs_loopdb_query(mrs_loopdb* db, const void* descriptor, int32_t form, float dist_threshold, int32_t max_out, int32_t* h_index,
+                     float* h_dist, int32_t* h_angle, int32_t* h_count, float* h_all_dist, int32_t* h_all_angle, mrs_stream stream);
+/* DiSCO: signature float32 [1024], spectrum complex64 [40][120] (DiSCO.forward's two outputs, disco_ros/models/DiSCO.py:315-334). */
+int mrs_loopdb_append_disco(mrs_loopdb* db, const float* signature, const float* spectrum, int32_t on_device, mrs_stream stream);
+/* disco_ros/main.py:284-291 in two launches: nearest signature (squared L2, ties to the lower index) and phase_corr(FFT_candidates[idx],
+ * fft_current): *h_index (-1 for an empty database), *h_dist2, *h_flat_argmax = flat index of the first maximum of the shifted magnitude
+ * map (the reference takes it `% num_sector`).  Blocking. */
+int mrs_loopdb_query_disco(mrs_loopdb* db, const float* signature, const float* spectrum, int32_t on_device, int32_t* h_index, float* h_dist2,
+                           int32_t* h_flat_argmax, mrs_stream stream);
+/* the entries as they lie on the device (tests, exchange): valid until the next append that grows the capacity */
+int mrs_loopdb_device_entries(mrs_loopdb* db, const float** d_entries, const float** d_signatures, int32_t* out_n, int64_t* entry_floats);
 
 /* ------------------------------------------------------------------------------------
  * Mapping-side DiSCO matcher

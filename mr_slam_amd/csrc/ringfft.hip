@@ -16,6 +16,7 @@
 // ([C][61][120]) are swept channel-outer (k_ring_sweep_mc); fp16 replicas of the database are accepted as well.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 
 #include <hip/hip_fp16.h>
@@ -201,6 +202,7 @@ struct FftCorrP {
     float denom;  // 0.15 * C * A * D
     const long long* db_first;   // optional (sweeps): query q sweeps the ndb entries that start at entry db_first[q] of DB (NULL: entry 0)
     const long long* q_row;      // optional (sweeps): query q is entry q_row[q] of Q (NULL: entry q)
+    float2* mc_partial;          // k_ring_sweep_dma<MC>: per-lane |corr| sums of every (channel, candidate, half): [C][ndb][128]
 };
 
 __device__ __forceinline__ float2 load_spec(const float2* p) { return *p; }
@@ -377,6 +379,350 @@ __global__ __launch_bounds__(NSLOT* kSlotThreads) __attribute__((amdgpu_waves_pe
         }
         __syncthreads();  // xbuf reuse
         cand = next;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One-query database sweep with the candidate staged by LDS-DMA (gfx950 `global_load_lds_dwordx4`) instead of in registers.
+//
+// ONE workgroup per compute unit; the query's half spectrum lies in LDS once ([61][120] complex64, compact rows + a
+// 64-byte zero tail) and every WAVE is its own pipeline: it owns a ring of kRing 1-KiB LDS slots that the DMA engine fills
+// with (row J, row 60 - J) x 64 columns of its candidate -- 16 B per lane, lanes 0-31 row J, lanes 32-63 row 60 - J -- while
+// the wave transforms what has landed.  A wave-instruction moves 1 KiB without touching a VGPR, stays in flight across
+// everything the wave does (only the issuing wave's vmcnt orders it), and the 122 registers per lane that held the
+// pre-requested column in k_ring_corr_fft are gone: the kernel needs the 120 registers of the in-register transform plus a few
+// frequency pairs of LDS look-ahead, so three waves per SIMD fit without spills and there is no workgroup barrier after the query
+// has been staged.
+//
+// Work unit = (candidate, column half h): columns h * 64 .. h * 64 + 63 (h = 1: 56 live columns; the dead lanes fetch a
+// duplicate of columns 118-119 and are switched off in the first step of the sum over detectors by a per-lane 0 / 1 factor, one
+// FMA in place of the ADD).  A unit is a stream of kElems = 32 elements: the 30 frequency pairs, row 30, and one filler, so that
+// element e always lives in ring slot e % kRing and every LDS offset is an immediate.  The element kRing ahead is requested as
+// soon as an element has been consumed -- across units, so the ring is full while the wave runs the 60-point transform and
+// the |.|-sum; exactly one DMA per element (fillers fetch one 16-byte piece) keeps the `s_waitcnt vmcnt(N)` counts static.
+// SPLIT = false: a wave runs both halves of its candidate in turn and adds them in registers.  SPLIT = true: waves 2 i and
+// 2 i + 1 take the two halves of the same candidate (half the quantisation loss when a wave has only a few candidates); the
+// second to finish reads the partner's per-lane sums from LDS and writes the result -- no barrier, two LDS counters per pair.
+// Arithmetic per column, the transform, the sum over lanes and the order (half 0 + half 1) are those of k_ring_corr_fft:
+// the outputs are bit-identical.
+constexpr int kRing = 8;
+constexpr int kElems = 32;
+constexpr int kSlotBytes = 1024;
+// DMA-tiled database entry (mrs_ring_spec_to_tiled): the same 7 320 complex values as the [61][120] half spectrum, permuted so that the 2 x 64 (h = 0)
+// or 2 x 56 (h = 1) values of stream element e of half h are ONE contiguous, 128-byte aligned block:
+//   h = 0: bytes [1024 e, 1024 e + 512) = row e, columns 0-63;   [1024 e + 512, 1024 (e + 1)) = row 60 - e, columns 0-63   (e < 30; e = 30: row 30 only)
+//   h = 1: bytes 31 232 + [896 e, 896 e + 448) = row e, columns 64-119;  the next 448 = row 60 - e, columns 64-119        (e < 30; e = 30: row 30 only)
+// 58 560 bytes + 64 of padding: entries are 58 624 bytes apart, every DMA reads whole 128-byte lines that nobody else needs.
+constexpr int kTiledHalf1 = 30 * 1024 + 512;            // byte offset of the h = 1 blocks
+constexpr int kTiledEntryBytes = 58624;
+constexpr int kTiledEntry = kTiledEntryBytes / 8;       // in complex values
+
+
+// POL: cache policy of the DMA load -- 0 default, 1 nt (streaming: the entry is read once), 2 sc1, 3 sc0 sc1, 4 sc1 nt, 5 sc0 sc1 nt
+#define MRS_GLDS(MOD) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" MOD "\n\ts_mov_b32 m0, %0" \
+                                   : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory")
+template <int POL>
+__device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigned lds_dst)
+{
+    unsigned keep;   // M0 = LDS destination of the wave-instruction (lane l lands at M0 + 16 l); written in the statement that reads it
+    if (POL == 1) MRS_GLDS(" nt");
+    else if (POL == 2) MRS_GLDS(" sc1");
+    else if (POL == 3) MRS_GLDS(" sc0 sc1");
+    else if (POL == 4) MRS_GLDS(" sc1 nt");
+    else if (POL == 5) MRS_GLDS(" sc0 sc1 nt");
+    else MRS_GLDS("");
+}
+#undef MRS_GLDS
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// wave_abs_reduce_scatter with the second operand of step 0 scaled by `m` (1: live, 0: this lane's partner / this lane is
+// past the last detector): fma(|b|, 1, |a|) rounds exactly like |a| + |b|
+__device__ __forceinline__ void wave_abs_reduce_scatter_masked(const v2f (&x)[60], float m, float& w0, float& w1)
+{
+    const int lane = threadIdx.x & 63;
+    float w[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        const int j = 64 + i;
+        const float lo_v = (i & 1) ? x[i >> 1].y : x[i >> 1].x;
+        const float hi_v = j < 120 ? ((j & 1) ? x[j >> 1].y : x[j >> 1].x) : 0.0f;
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo_v), __float_as_uint(hi_v), false, false);
+        w[i] = __builtin_fmaf(fabsf(__uint_as_float(r[1])), m, fabsf(__uint_as_float(r[0])));
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) w[i] = swap16_add(w[i], w[32 + i]);
+#pragma unroll
+    for (int step = 2; step < 6; ++step) {
+        const int keep = 64 >> step;
+        const int mask = 32 >> step;
+        const bool hi = (lane & mask) != 0;
+#pragma unroll
+        for (int i = 0; i < keep; ++i) {
+            const float send = hi ? w[i] : w[keep + i];
+            const float mine = hi ? w[keep + i] : w[i];
+            w[i] = mine + __shfl_xor(send, mask, 64);
+        }
+    }
+    w0 = w[0];
+    w1 = w[1];
+}
+
+// fftshift + first maximum in shifted order + dist / angle (util.py:367-374); s0, s1 = this lane's samples n = 2 lane, 2 lane + 1
+__device__ __forceinline__ void sweep_epilogue(float s0, float s1, int lane, float denom, float* dist_o, int* angle_o)
+{
+    const int n0 = 2 * lane, n1 = 2 * lane + 1;
+    const int m0 = n0 < 60 ? n0 + 60 : n0 - 60, m1 = n1 < 60 ? n1 + 60 : n1 - 60;
+    float best = -1.0f;
+    int bm = 1 << 30;
+    if (lane < 60) {
+        best = s0; bm = m0;
+        if (s1 > best || (s1 == best && m1 < bm)) { best = s1; bm = m1; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int om = __shfl_xor(bm, off, 64);
+        if (ob > best || (ob == best && om < bm)) { best = ob; bm = om; }
+    }
+    if (lane == 0) {
+        *dist_o = 1.0f - best / denom;
+        *angle_o = kA / 2 - bm;
+    }
+}
+
+struct DmaUnit {            // one (candidate, half) as the DMA sees it; wave-uniform
+    const float2* base;     // first value of the candidate (SGPR pair)
+    int half;               // 0 / 1
+    bool live;              // false: past the end of this wave's work (fillers only)
+};
+
+template <int WAVES, bool SPLIT, int NT, int RING = kRing, bool QDMA = true, bool TILED = false, bool PRIO = false, bool MC = false, int PF = 2>
+__global__ __launch_bounds__(WAVES * 64) void k_ring_sweep_dma(const float2* __restrict__ Q, const float2* __restrict__ DB, FftCorrP p,
+                                                               float* __restrict__ dist, int* __restrict__ angle)
+{
+    // LDS: ring [WAVES][RING][1 KiB] | query [61 * 120 + 8] v2f | SPLIT: partial [WAVES / 2][2 halves][64] v2f, counters
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    v2f* const qs = reinterpret_cast<v2f*>(smem + WAVES * RING * kSlotBytes);
+    constexpr int kQueryVals = kHalf * kD + 8;
+    v2f* const partial = qs + kQueryVals;                                        // SPLIT only
+    unsigned* const counters = reinterpret_cast<unsigned*>(partial + (WAVES / 2) * 2 * 64);   // [WAVES / 2][arrived, done]
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned ring_lds = lds0 + wave * (RING * kSlotBytes);               // wave-uniform LDS byte address of this wave's ring
+    const v2f* const ring = reinterpret_cast<const v2f*>(smem + wave * (RING * kSlotBytes)) + lane;
+
+    const size_t plane = TILED ? (size_t)kTiledEntry : (size_t)kHalf * kD;      // float2 values of one channel of an entry
+    const size_t entry = (MC ? (size_t)p.channels : (size_t)1) * plane;          // ... from one candidate to the next
+    const size_t qentry = (size_t)kHalf * kD;                                   // the query is always in row layout
+    const int ncand = p.ndb;
+    // this wave's candidates: c0, c0 + cstride, ...
+    // MC (RING++, C channels): a workgroup keeps ONE channel for its lifetime (its query plane is staged once, no barrier ever after) and
+    // shares the candidates with the other workgroups of that channel; the per-lane sums go to p.mc_partial and k_ring_mc_finish adds
+    // the channels in order, so the bits are those of the channel-outer kernel (k_ring_sweep_mc).
+    const int C = MC ? p.channels : 1;
+    const int ch = MC ? (int)(blockIdx.x % C) : 0;
+    const int slice = MC ? (int)(blockIdx.x / C) : (int)blockIdx.x;
+    const int nslices = MC ? ((int)gridDim.x - ch + C - 1) / C : (int)gridDim.x;
+    const int c0 = SPLIT ? slice * (WAVES / 2) + (wave >> 1) : slice * WAVES + wave;
+    const int cstride = nslices * (SPLIT ? WAVES / 2 : WAVES);
+    const int my_half = SPLIT ? (wave & 1) : 0;
+
+    // per-lane pieces of a DMA: lanes 0-31 row J, lanes 32-63 row 60 - J; 16 B = 2 columns per lane.
+    // Row layout ([61][120]): the two rows are 960 (60 - 2 J) bytes apart and a half-row starts on a 64-byte boundary.
+    // Tiled layout (mrs_ring_spec_to_tiled): the 1024 (h = 0) / 896 (h = 1) bytes of an element are contiguous and 128-byte aligned.
+    const int piece = lane & 31;
+    const bool upper = lane >= 32;
+    const unsigned voff_h0 = TILED ? (unsigned)lane * 16u : (upper ? 60u * 960u : 0u) + (unsigned)piece * 16u;
+    const unsigned voff_h1 = TILED ? (unsigned)kTiledHalf1 + (upper ? 448u : 0u) + (unsigned)min(piece, 27) * 16u
+                                   : (upper ? 60u * 960u : 0u) + 512u + (unsigned)min(piece, 27) * 16u;   // pieces 28-31 would leave the row
+    const int vdelta = upper ? -960 : 960;
+    // The byte offset of the next DMA is a RUNNING register (+- 960 per element; row 30 needs no case of its own: both half-waves
+    // arrive at it), re-read through an empty asm at every unit: written as base + e * delta it is loop-invariant where a wave keeps
+    // its half, and the 31 offsets of a unit become 31 registers spilled to scratch -- whose reloads share vmcnt with the DMAs.
+    unsigned run = 0;
+    auto start_unit = [&](const DmaUnit& u) {
+        run = u.half ? voff_h1 : voff_h0;
+        asm volatile("" : "+v"(run));
+    };
+    auto issue = [&](const DmaUnit& u, int e) {          // e: element index 0..31 (compile-time after unrolling), strictly in stream order
+        if (e == 0) start_unit(u);
+        const unsigned voff = (!u.live || e == kElems - 1) ? 0u : run;             // filler: one 16-byte piece for all lanes
+        glds16<NT>(u.base, voff, ring_lds + (e % RING) * kSlotBytes);
+        if (TILED) run += u.half ? 896u : 1024u;
+        else run += (unsigned)vdelta;
+    };
+    auto unit_of = [&](int c, int h) {
+        DmaUnit u;
+        u.live = c < ncand;
+        u.base = DB + (size_t)(u.live ? c : 0) * entry + (size_t)ch * plane;
+        u.half = h;
+        return u;
+    };
+
+    const float2* const qsrc = Q + (size_t)(MC ? ch : (int)blockIdx.y) * qentry;
+    if (QDMA) {
+        // the query rides the same engine: 58 pieces of 1 KiB dealt to the waves (the last one 192 B: lanes 0-11), then the unit's
+        // first RING elements behind them -- the barrier below needs only the former (vmcnt(RING)), the latter stay in flight across it
+        constexpr int kPieces = (kHalf * kD * 8 + kSlotBytes - 1) / kSlotBytes;    // 58
+        const unsigned q_lds = lds0 + WAVES * (RING * kSlotBytes);
+        if (threadIdx.x < 8) qs[kHalf * kD + threadIdx.x] = (v2f){0.0f, 0.0f};      // zero tail (read by the dead lanes of row 60)
+        for (int pc = wave; pc < kPieces; pc += WAVES)
+            if (pc * kSlotBytes + lane * 16 < kHalf * kD * 8) glds16<0>(qsrc, (unsigned)(pc * kSlotBytes + lane * 16), q_lds + pc * kSlotBytes);
+    }
+    DmaUnit cur = unit_of(c0, my_half);
+#pragma unroll
+    for (int e = 0; e < RING; ++e) issue(cur, e);        // in flight while the query is staged
+    if (QDMA) {
+        wait_vmcnt<RING>();
+        if (SPLIT && threadIdx.x < (WAVES / 2) * 2) counters[threadIdx.x] = 0;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {   // query -> LDS through registers (compact rows), zero tail; counters
+        for (int i = threadIdx.x; i < kQueryVals; i += WAVES * 64) {
+            v2f v = {0.0f, 0.0f};
+            if (i < kHalf * kD) { const float2 g = qsrc[i]; v = (v2f){g.x, g.y}; }
+            qs[i] = v;
+        }
+        if (SPLIT && threadIdx.x < (WAVES / 2) * 2) counters[threadIdx.x] = 0;
+        __syncthreads();
+    }
+
+    // PF = LDS look-ahead in elements
+    int c = c0;
+    int round = 0;
+    float accA0 = 0.0f, accA1 = 0.0f;                    // !SPLIT: sums of half 0 while half 1 runs
+    while (cur.live) {
+        DmaUnit nxt;
+        if (SPLIT) nxt = unit_of(c + cstride, my_half);
+        else nxt = cur.half == 0 ? unit_of(c, 1) : unit_of(c + cstride, 0);
+        const int h = cur.half;
+        const v2f* const qcol = qs + h * 64 + lane;
+        const float m = (h == 1 && piece >= 24) ? 0.0f : 1.0f;
+
+        v2f x[60];
+        v2f qa[PF + 1][2], cb[PF + 1][2];                // element e lives in [e % (PF + 1)]
+        auto read_elem = [&](int e) {
+            const int J = e;
+            qa[e % (PF + 1)][0] = qcol[J * kD];
+            cb[e % (PF + 1)][0] = ring[(e % RING) * 128];
+            if (e < 30) {
+                qa[e % (PF + 1)][1] = qcol[(60 - J) * kD];
+                cb[e % (PF + 1)][1] = ring[(e % RING) * 128 + 64];
+            }
+        };
+        if (PRIO) __builtin_amdgcn_s_setprio(1);      // the phase that hands ring slots back to the DMA engine goes first
+        // elements 0 .. PF - 1 of this unit: their DMAs are followed by RING - 1 - e younger ones
+        wait_vmcnt<RING - 1>(); read_elem(0);
+        if (PF > 1) { wait_vmcnt<RING - 2>(); read_elem(1); }
+#pragma unroll
+        for (int e = 0; e < kElems; ++e) {
+            if (e + PF <= 30) {
+                wait_vmcnt<RING - 1 - PF>();            // element e + PF has landed: RING - 1 - PF younger DMAs may be in flight
+                read_elem(e + PF);
+            }
+            if (e < 30) {
+                v2f zj, zp;
+                irfft_pre_pair(e, cmul_conj(qa[e % (PF + 1)][0], cb[e % (PF + 1)][0]), cmul_conj(qa[e % (PF + 1)][1], cb[e % (PF + 1)][1]), zj, zp);
+                x[e] = zj;
+                if (e != 0) x[60 - e] = zp;
+            } else if (e == 30) {
+                const v2f pm = cmul_conj(qa[e % (PF + 1)][0], cb[e % (PF + 1)][0]);
+                v2f unused;
+                irfft_pre_pair(30, pm, pm, x[30], unused);
+            }
+            __builtin_amdgcn_sched_barrier(0);           // the slot's values are in registers before the slot is handed back
+            if (e + RING < kElems) issue(cur, e + RING);
+            else issue(nxt, e + RING - kElems);
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        cfft60_inv(x);
+        float w0, w1;
+        wave_abs_reduce_scatter_masked(x, m, w0, w1);
+
+        if (MC) {
+            static_assert(!MC || !SPLIT, "the multi-channel form keeps both halves of a candidate on one wave");
+            p.mc_partial[((size_t)ch * p.ndb + c) * 128 + h * 64 + lane] = make_float2(w0, w1);
+            if (h == 1) c += cstride;
+        } else if (!SPLIT) {
+            if (h == 0) { accA0 = w0; accA1 = w1; }
+            else {
+                const float s0 = (accA0 + w0) * kOrtho120, s1 = (accA1 + w1) * kOrtho120;
+                const size_t o = (size_t)blockIdx.y * p.ndb + c;
+                sweep_epilogue(s0, s1, lane, p.denom, dist + o, angle + o);
+                c += cstride;
+            }
+        } else {
+            const int pi = wave >> 1;
+            v2f* const mine = partial + (pi * 2 + h) * 64 + lane;
+            const v2f* const theirs = partial + (pi * 2 + (1 - h)) * 64 + lane;
+            unsigned* const arrived = counters + pi * 2;
+            unsigned* const done = arrived + 1;
+            // one slot per pair: the sums of the previous round have been read by whoever finished it second
+            while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)round) __builtin_amdgcn_s_sleep(2);
+            *mine = (v2f){w0, w1};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            unsigned old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (old & 1u) {                               // the partner's sums are there: half 0 + half 1, as the two-wave slot adds them
+                const v2f t = *theirs;
+                const float a0 = h == 0 ? w0 : t.x, a1 = h == 0 ? w1 : t.y;
+                const float b0 = h == 0 ? t.x : w0, b1 = h == 0 ? t.y : w1;
+                const float s0 = (a0 + b0) * kOrtho120, s1 = (a1 + b1) * kOrtho120;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const size_t o = (size_t)blockIdx.y * p.ndb + c;
+                sweep_epilogue(s0, s1, lane, p.denom, dist + o, angle + o);
+            }
+            c += cstride;
+            ++round;
+        }
+        cur = nxt;
+    }
+    wait_vmcnt<0>();                                     // no DMA may land in LDS that the next workgroup owns
+}
+
+// RING++: channel sums of k_ring_sweep_dma<MC> in channel order (((0 + w_0) + w_1) + ...), the two column halves, fftshift, maximum.
+// One wave per candidate.
+__global__ __launch_bounds__(256) void k_ring_mc_finish(const float2* __restrict__ partial, int ndb, int C, float denom, float* __restrict__ dist,
+                                                        int* __restrict__ angle)
+{
+    const int cand = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (cand >= ndb) return;
+    float2 lo = make_float2(0.0f, 0.0f), hi = make_float2(0.0f, 0.0f);
+    for (int c = 0; c < C; ++c) {
+        const float2 a = partial[((size_t)c * ndb + cand) * 128 + lane], b = partial[((size_t)c * ndb + cand) * 128 + 64 + lane];
+        lo.x += a.x; lo.y += a.y; hi.x += b.x; hi.y += b.y;
+    }
+    sweep_epilogue((lo.x + hi.x) * kOrtho120, (lo.y + hi.y) * kOrtho120, lane, denom, dist + cand, angle + cand);
+}
+
+// [n][61][120] half spectra (row layout) -> the DMA-tiled entries above; grid = entries, 256 lanes
+__global__ __launch_bounds__(256) void k_ring_spec_to_tiled(const float2* __restrict__ src, float2* __restrict__ dst)
+{
+    const float2* s = src + (size_t)blockIdx.x * kHalf * kD;
+    float2* d = dst + (size_t)blockIdx.x * kTiledEntry;
+    for (int i = threadIdx.x; i < kTiledEntry; i += 256) {
+        float2 v = make_float2(0.0f, 0.0f);
+        if (i < kHalf * kD) {
+            int row, col;
+            if (i < kTiledHalf1 / 8) {                   // h = 0: 128 values per element (64 of row e, 64 of row 60 - e)
+                const int e = i / 128, r = i % 128;
+                row = r < 64 ? e : 60 - e;
+                col = r % 64;
+            } else {                                     // h = 1: 112 values per element
+                const int j = i - kTiledHalf1 / 8;
+                const int e = j / 112, r = j % 112;
+                row = r < 56 ? e : 60 - e;
+                col = 64 + r % 56;
+            }
+            v = s[row * kD + col];
+        }
+        d[i] = v;
     }
 }
 
@@ -596,6 +942,52 @@ int mrs_ring_half_spectrum_f16(mrs_ctx* ctx, const float* d_norm_sino, int32_t n
 }
 
 extern "C++" {
+constexpr int kSweepDmaDefault = 11008;
+constexpr int kSweepDmaTiledDefault = 11008;
+template <int WAVES, bool SPLIT, int NT, bool TILED, bool PRIO, bool MC = false>
+static hipError_t sweep_dma_launch_t(int num_cu, hipStream_t s, const float2* q, const float2* db, const FftCorrP& p, float* dist, int* angle)
+{
+    const size_t lds = (size_t)WAVES * kRing * kSlotBytes + (size_t)(kHalf * kD + 8) * sizeof(v2f) +
+                       (SPLIT ? (size_t)(WAVES / 2) * 2 * 64 * sizeof(v2f) + (WAVES / 2) * 2 * sizeof(unsigned) : 0);
+    auto kern = k_ring_sweep_dma<WAVES, SPLIT, NT, kRing, true, TILED, PRIO, MC>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int per_wg = SPLIT ? WAVES / 2 : WAVES;
+    int blocks = std::max(1, std::min(num_cu, (p.ndb + per_wg - 1) / per_wg));
+    if (MC) blocks = std::max(p.channels, std::min(num_cu, p.channels * ((p.ndb + per_wg - 1) / per_wg)));   // every channel needs a workgroup
+    hipLaunchKernelGGL(kern, dim3(blocks, 1), dim3(WAVES * 64), lds, s, q, db, p, dist, angle);
+    return hipGetLastError();
+}
+// variant = waves per workgroup (8 / 12) + 100 (the halves of a candidate on two waves) + 1000 (non-temporal DMA loads: the entry is read
+// once) + 10000 (s_setprio 1 while a wave consumes / re-requests ring slots)
+static hipError_t sweep_dma_launch(int variant, int num_cu, hipStream_t s, const float2* q, const float2* db, const FftCorrP& p, float* dist, int* angle, bool tiled = false)
+{
+    const bool prio = (variant / 10000) % 10 != 0, split = (variant / 100) % 10 != 0, nt = (variant / 1000) % 10 != 0;
+    const int waves = variant % 100;
+#define MRS_DMA_1(W, S, N, T, P) if (tiled == T && waves == W && split == S && nt == (N != 0) && prio == P) return sweep_dma_launch_t<W, S, N, T, P>(num_cu, s, q, db, p, dist, angle);
+#define MRS_DMA_4(N, T, P) MRS_DMA_1(8, false, N, T, P) MRS_DMA_1(8, true, N, T, P) MRS_DMA_1(12, false, N, T, P) MRS_DMA_1(12, true, N, T, P)
+    MRS_DMA_4(0, false, false) MRS_DMA_4(1, false, false) MRS_DMA_4(0, false, true) MRS_DMA_4(1, false, true)
+    MRS_DMA_4(0, true, false) MRS_DMA_4(1, true, false) MRS_DMA_4(0, true, true) MRS_DMA_4(1, true, true)
+#undef MRS_DMA_4
+#undef MRS_DMA_1
+    return hipErrorInvalidValue;
+}
+
+// RING++ (C channels), one query: channel-per-workgroup DMA sweep into per-lane partial sums + the finishing kernel
+static int sweep_dma_mc(mrs_ctx* ctx, hipStream_t s, const float2* q, const float2* db, FftCorrP p, float* dist, int* angle, bool tiled)
+{
+    mrs::Scratch part;
+    int st = part.alloc((size_t)p.channels * p.ndb * 128 * sizeof(float2), s);
+    if (st != MRS_OK) return st;
+    p.mc_partial = part.as<float2>();
+    const int num_cu = ctx->num_cu > 0 ? ctx->num_cu : 256;
+    if (tiled) MRS_HIP_TRY((sweep_dma_launch_t<8, false, 1, true, true, true>(num_cu, s, q, db, p, dist, angle)));
+    else MRS_HIP_TRY((sweep_dma_launch_t<8, false, 1, false, true, true>(num_cu, s, q, db, p, dist, angle)));
+    hipLaunchKernelGGL(k_ring_mc_finish, dim3((p.ndb + 3) / 4), dim3(256), 0, s, p.mc_partial, p.ndb, p.channels, p.denom, dist, angle);
+    MRS_HIP_TRY(hipGetLastError());
+    return MRS_OK;
+}
+
 template <typename DBT>
 static int corr_fft_launch(mrs_ctx* ctx, const float* d_q, int32_t n_q, const void* d_db, int32_t n_db, int32_t channels,
                            float* d_dist, int32_t* d_angle, float* d_corr, mrs_stream stream, bool pairwise,
@@ -607,7 +999,7 @@ static int corr_fft_launch(mrs_ctx* ctx, const float* d_q, int32_t n_q, const vo
     FftCorrP p;
     p.nq = n_q; p.ndb = n_db; p.pairwise = pairwise ? 1 : 0; p.channels = channels;
     p.denom = (float)(0.15 * channels * kA * kD);
-    p.db_first = d_db_first; p.q_row = d_q_row;
+    p.db_first = d_db_first; p.q_row = d_q_row; p.mc_partial = nullptr;
     MRS_REQUIRE(!(d_db_first || d_q_row) || (!pairwise && channels == 1 && std::is_same<DBT, float2>::value && n_q <= mrs::kMaxGridY),
                 "per-query database blocks: single-channel fp32 sweeps of at most 65535 queries");
     constexpr int NSLOT = 2;
@@ -643,6 +1035,17 @@ static int corr_fft_launch(mrs_ctx* ctx, const float* d_q, int32_t n_q, const vo
                 // registers per value) swept by one or two queries (the HBM-side regime): the NEXT round's candidate is already
                 // in flight during this round's arithmetic
                 bool launched = false;
+                if constexpr (std::is_same<DBT, float2>::value) {
+                    // one query, exact entries (the node's loop: main_RING.py:133): the LDS-DMA pipeline, one workgroup per compute unit
+                    if (n_q == 1 && !d_corr && !d_db_first && !d_q_row) {
+                        int variant = kSweepDmaDefault;
+                        if (const char* v = mrs::dev_env("MRS_SWEEP_VARIANT")) variant = atoi(v);
+                        if (variant > 0) {
+                            MRS_HIP_TRY(sweep_dma_launch(variant, ctx->num_cu > 0 ? ctx->num_cu : 256, s, qq, dd, p, dist_c, angle_c));
+                            launched = true;
+                        }
+                    }
+                }
                 if constexpr (std::is_same<DBT, __half2>::value) {
                     if (n_q <= 2) {
                         auto kern = k_ring_sweep_pipe<NSLOT, DBT, 2>;
@@ -656,6 +1059,10 @@ static int corr_fft_launch(mrs_ctx* ctx, const float* d_q, int32_t n_q, const vo
                     MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                     hipLaunchKernelGGL(kern, dim3(blocks, nq), dim3(NSLOT * kSlotThreads), lds, s, qq, dd, p, dist_c, angle_c, corr_c);
                 }
+            } else if (std::is_same<DBT, float2>::value && n_q == 1 && !d_corr && !(mrs::dev_env("MRS_SWEEP_VARIANT") && atoi(mrs::dev_env("MRS_SWEEP_VARIANT")) == 0)) {
+                // one query (the node's loop, main_RINGplusplus.py:131-134): LDS-DMA pipeline, one channel per workgroup
+                const int st = sweep_dma_mc(ctx, s, qq, reinterpret_cast<const float2*>(dd), p, dist_c, angle_c, false);
+                if (st != MRS_OK) return st;
             } else {
                 constexpr int MAXR = 8;
                 // chunks = a whole number of "waves" of resident workgroups (two per CU, shared by the queries of the launch), the
@@ -685,6 +1092,37 @@ int mrs_ring_corr_fft_sweep(mrs_ctx* ctx, const float* d_query_spec, int32_t n_q
                             int32_t n_db, float* d_dist, int32_t* d_angle, float* d_corr, mrs_stream stream)
 {
     return corr_fft_launch<float2>(ctx, d_query_spec, n_query, d_db_spec, n_db, 1, d_dist, d_angle, d_corr, stream, false);
+}
+
+int mrs_ring_spec_to_tiled(mrs_ctx* ctx, const float* d_half_spec, int32_t n, float* d_tiled, mrs_stream stream)
+{
+    MRS_REQUIRE(ctx && d_half_spec && d_tiled, "null pointer");
+    MRS_REQUIRE(n > 0, "n must be positive");
+    MRS_HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_ring_spec_to_tiled, dim3(n), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float2*>(d_half_spec),
+                       reinterpret_cast<float2*>(d_tiled));
+    MRS_HIP_TRY(hipGetLastError());
+    return MRS_OK;
+}
+
+int mrs_ring_corr_fft_sweep_tiled(mrs_ctx* ctx, const float* d_query_spec, const float* d_db_tiled, int32_t n_db, int32_t channels, float* d_dist,
+                                  int32_t* d_angle, mrs_stream stream)
+{
+    MRS_REQUIRE(ctx && d_query_spec && d_db_tiled && d_dist && d_angle, "null pointer");
+    MRS_REQUIRE(n_db > 0 && channels > 0, "counts must be positive");
+    MRS_HIP_TRY(hipSetDevice(ctx->device));
+    FftCorrP p;
+    p.nq = 1; p.ndb = n_db; p.pairwise = 0; p.channels = channels;
+    p.denom = (float)(0.15 * channels * kA * kD);
+    p.db_first = nullptr; p.q_row = nullptr; p.mc_partial = nullptr;
+    if (channels > 1)
+        return sweep_dma_mc(ctx, (hipStream_t)stream, reinterpret_cast<const float2*>(d_query_spec), reinterpret_cast<const float2*>(d_db_tiled), p, d_dist,
+                            d_angle, true);
+    int variant = kSweepDmaTiledDefault;
+    if (const char* v = mrs::dev_env("MRS_SWEEP_VARIANT")) variant = atoi(v) > 0 ? atoi(v) : variant;
+    MRS_HIP_TRY(sweep_dma_launch(variant, ctx->num_cu > 0 ? ctx->num_cu : 256, (hipStream_t)stream, reinterpret_cast<const float2*>(d_query_spec),
+                                 reinterpret_cast<const float2*>(d_db_tiled), p, d_dist, d_angle, true));
+    return MRS_OK;
 }
 
 int mrs_ring_corr_fft_sweep_blocks(mrs_ctx* ctx, const float* d_spec, const int64_t* d_query_row, int32_t n_query, const int64_t* d_db_first,

@@ -450,6 +450,38 @@ def corr_sweep_fft(query_spec, db_spec, want_corr=False):
     return (dist, ang, corr) if want_corr else (dist, ang)
 
 
+TILED_ENTRY_FLOATS = 58624 // 4     # MRS_RING_TILED_ENTRY_BYTES: one DMA-tiled database entry
+
+
+def spec_to_tiled(spec):
+    """[n,61,120] (RING) or [n,C,61,120] (RING++) complex64 half spectra -> the DMA-tiled database format of the one-query sweep: float32
+    [n + 1, C * 14656], n entries of C planes of 58 624 B and one entry of zero slack behind them (include/mrslam_hip.h: mrs_ring_spec_to_tiled)."""
+    d = _dev(spec)
+    x = spec.contiguous()
+    assert x.dtype == torch.complex64 and x.shape[-2:] == (61, 120) and x.dim() in (3, 4)
+    n = x.shape[0]
+    planes = x.numel() // (61 * 120)
+    out = torch.zeros((n + 1, (planes // n) * TILED_ENTRY_FLOATS), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().mrs_ring_spec_to_tiled(_lib.ctx(d), _lib.ptr(torch.view_as_real(x)), planes, _lib.ptr(out), _lib.current_stream(d)))
+    return out
+
+
+def corr_sweep_fft_tiled(query_spec, tiled, n_db=None):
+    """One query ([C,61,120] / [1,C,61,120] / [61,120] complex64, row layout) against a DMA-tiled database (spec_to_tiled): (dist [n], angle [n]),
+    bit-identical to corr_sweep_fft(query, db)[...][0]."""
+    d = _dev(query_spec)
+    q = query_spec.contiguous()
+    channels = tiled.shape[1] // TILED_ENTRY_FLOATS
+    assert q.dtype == torch.complex64 and q.numel() == channels * 61 * 120 and tiled.dtype == torch.float32 and tiled.is_contiguous()
+    n = int(n_db if n_db is not None else tiled.shape[0] - 1)
+    assert 0 < n < tiled.shape[0], "the tiled array needs one entry of slack behind the last one"
+    dist = torch.empty(n, dtype=torch.float32, device=q.device)
+    ang = torch.empty(n, dtype=torch.int32, device=q.device)
+    _lib.check(_lib.load().mrs_ring_corr_fft_sweep_tiled(_lib.ctx(d), _lib.ptr(torch.view_as_real(q)), _lib.ptr(tiled), n, int(channels), _lib.ptr(dist), _lib.ptr(ang),
+                                                         _lib.current_stream(d)))
+    return dist, ang
+
+
 def corr_sweep_fft_blocks(spec_pool, query_rows, db_first, n_db, out=None):
     """Several C1 sweeps in one launch: query q = entry query_rows[q] of spec_pool ([E,61,120] complex64) against the n_db entries that start
     at entry db_first[q] (int64 device tensors).  Returns (dist [Q,n_db], angle [Q,n_db]); bit-identical to corr_sweep_fft per query."""

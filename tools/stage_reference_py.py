@@ -4,7 +4,8 @@
 the built .so files, is never committed and is never imported by the product.  Run by __graft_entry__.build() wherever the reference
 tree is present.  Files (read where they lie, copied byte for byte, same relative layout so that tests/golden/ref_import.py finds them):
   LoopDetection/src/RING_ros/{util.py, config.py}            generate_RING, generate_RINGplusplus, fast_corr, ...
-  LoopDetection/src/disco_ros/{config.py, main.py, models/DiSCO.py}   DiSCO.forward, phase_corr"""
+  LoopDetection/src/disco_ros/{config.py, main.py, models/DiSCO.py}   DiSCO.forward, phase_corr, detect_loop_icp
+  LoopDetection/src/RING_ros/{main_RING.py, main_RINGplusplus.py}     detect_loop_icp (tests/test_node_gpu.py: the node's loop against its twin)"""
 import os
 import shutil
 import sys
@@ -12,7 +13,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.environ.get("MRSLAM_REFERENCE", "/root/reference")
 FILES = ["LoopDetection/src/RING_ros/util.py", "LoopDetection/src/RING_ros/config.py", "LoopDetection/src/disco_ros/config.py",
-         "LoopDetection/src/disco_ros/main.py", "LoopDetection/src/disco_ros/models/DiSCO.py"]
+         "LoopDetection/src/disco_ros/main.py", "LoopDetection/src/disco_ros/models/DiSCO.py",
+         "LoopDetection/src/RING_ros/main_RING.py", "LoopDetection/src/RING_ros/main_RINGplusplus.py"]
 
 
 def stage(quiet=False):
