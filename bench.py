@@ -356,6 +356,13 @@ def gicp_leg(device_index, rank, n_pairs, iters):
     t_forced, _, its_f, nn_f = timed(force_iterations=iters)          # seeds now warm from the cold run (like a re-check)
     s_forced = b.searched_fraction
     assert (its_f == iters).all() and (its_c == 5).all()
+    # the headline protocol: `iters` forced iterations from the identity guess with NOTHING carried over (seeds, certificates and the neighbour
+    # cache reset by handing the clouds over again; covariances recomputed outside the clock)
+    b.set_sources(srcs); b.set_targets(tgts)
+    b.compute_covariances(0); b.compute_covariances(1)
+    t_cold_full, _, its_cf, nn_cf = timed(force_iterations=iters)
+    s_cold_full = b.searched_fraction
+    assert (its_cf == iters).all()
     b.set_sources(srcs)                                               # reset seeds (covariances recomputed lazily: not timed)
     b.compute_covariances(0)
     b.set_params(force_iterations=0)
@@ -383,15 +390,19 @@ def gicp_leg(device_index, rank, n_pairs, iters):
                                                           "note": "VALU-pipe busy fraction from the PMC pass of the same shape: profiles/*_pmc.json"},
         "k_nn_scan_g (round-4 search, every point, warm)": {"bound": "latency", "ms": kms["search_round4_all"], "queries_per_s": n_src / kms["search_round4_all"] * 1e3},
         "k_nn_certify (unchanged pose)": dict(hbm(n_src * 44, kms["certify"]), bound="hbm", note="16 B point + 4 B seed + 4 B bound in, 4 B index + 4 B bound out, "
-                                              "gathered 16 B neighbour: 44 B per source point"),
+                                              "16 B neighbour (round 5: streamed from the copy k_linearize keeps beside the source point, index in .w): 44 B per source point"),
         "certify + work-list search after a 1 mm step": {"ms": kms["certify_plus_worklist_1mm"], "worklist_queries": kcnt["worklist_queries_1mm"],
                                                          "share_of_points_searched": kcnt["worklist_queries_1mm"] / max(n_src, 1)},
         "k_knn_cov (selection)": dict(hbm(knn_bytes, kms["knn_select"]), bound="valu", clouds_per_s=n_pairs / kms["knn_select"] * 1e3),
         "k_cov_from_knn": dict(hbm(cov_bytes, kms["cov_from_knn"]), bound="hbm+fp64", clouds_per_s=n_pairs / kms["cov_from_knn"] * 1e3),
     }
     return {"pairs": n_pairs, "iterations": iters, "points": N_POINTS,
-            "iters_per_s": n_pairs * iters / t_forced, "align_s": t_forced, "nn_passes": nn_f,
-            "nn_pass_ms": 1e3 * t_forced / (n_pairs * max(nn_f, 1)), "searched_fraction": s_forced,
+            "iters_per_s": n_pairs * iters / t_cold_full, "align_s": t_cold_full, "nn_passes": nn_cf,
+            "nn_pass_ms": 1e3 * t_cold_full / (n_pairs * max(nn_cf, 1)), "searched_fraction": s_cold_full,
+            "protocol": f"{iters} forced outer iterations from the identity guess, cold start (no seeds / certificates / cached neighbours carried over)",
+            "warm": {"iters_per_s": n_pairs * iters / t_forced, "align_s": t_forced, "nn_passes": nn_f, "searched_fraction": s_forced,
+                     "note": f"the same {iters} forced iterations started with the nearest-neighbour seeds of a previous 5-iteration run of the same pairs "
+                             "(a re-check of a known pair): the figure earlier rounds reported as iters_per_s"},
             "cold": {"iterations": 5, "iters_per_s": n_pairs * 5 / t_cold, "align_s": t_cold, "nn_passes": nn_c, "searched_fraction": s_cold,
                      "note": "first 5 outer iterations from the identity guess, no warm start"},
             "natural": {"pairs_per_s": n_pairs / t_nat, "align_s": t_nat, "converged": int(conv.sum()),
@@ -410,27 +421,50 @@ def gicp_leg(device_index, rank, n_pairs, iters):
 def sweep_legs(device, spec_pool, n_db=10_000):
     """BASELINE configs[3] shape on one GPU: databases of 10 000 descriptors, 1 and 4 queries per launch.
     Bandwidth = database bytes streamed once per launch / launch time (the queries of a launch share the entry through
-    L2, so the rate is the same number for 1 and 4 queries only if the kernel is bandwidth bound)."""
-    from mr_slam_amd import disco
+    L2, so the rate is the same number for 1 and 4 queries only if the kernel is bandwidth bound).
+    One query (the node's loop, main_RING.py:133): the database in its resident format (DMA-tiled entries, what mrs_loopdb keeps) swept by the
+    LDS-DMA kernel; `*_q1_row_layout` = the same query over [61][120] row-layout entries (mrs_ring_corr_fft_sweep[_mc])."""
+    from mr_slam_amd import disco, node
     out = {}
     idx = torch.arange(n_db, device=device) % spec_pool.shape[0]
     db = spec_pool[idx].contiguous()                                   # RING: [n_db][61][120] complex64 = 58 560 B each
-    for nq in (1, 4):
-        q = spec_pool[:nq].contiguous()
-        ms = ev_ms(lambda: ring.corr_sweep_fft(q, db))
-        out[f"ring_q{nq}"] = {"pairs_per_s": nq * n_db / ms * 1e3, "ms": ms, "db_entries": n_db, "bytes_per_entry": 58560,
-                              "db_gbs": n_db * 58560 / ms / 1e6, "hbm_frac": n_db * 58560 / ms / 1e6 / HBM_PEAK_GBS}
+
+    def entry(nq, ms, bytes_per_entry, **kw):
+        return dict({"pairs_per_s": nq * n_db / ms * 1e3, "ms": ms, "db_entries": n_db, "bytes_per_entry": bytes_per_entry,
+                     "db_gbs": n_db * bytes_per_entry / ms / 1e6, "hbm_frac": n_db * bytes_per_entry / ms / 1e6 / HBM_PEAK_GBS}, **kw)
+    tiled = ring.spec_to_tiled(db)
+    q1 = spec_pool[:1].contiguous()
+    out["ring_q1"] = entry(1, ev_ms(lambda: ring.corr_sweep_fft_tiled(q1, tiled), reps=10, warm=3), 58560, layout="dma-tiled (mrs_loopdb)")
+    out["ring_q1_row_layout"] = entry(1, ev_ms(lambda: ring.corr_sweep_fft(q1, db), reps=10, warm=3), 58560)
+    del tiled
+    q = spec_pool[:4].contiguous()
+    out["ring_q4"] = entry(4, ev_ms(lambda: ring.corr_sweep_fft(q, db)), 58560)
     db6 = torch.stack([db.roll(k, 0) for k in range(6)], 1).contiguous()   # RING++: [n_db][6][61][120] = 351 360 B each
-    for nq in (1, 4):
-        q = db6[:nq].contiguous()
-        ms = ev_ms(lambda: ring.corr_sweep_fft(q, db6), reps=3, warm=1)
-        out[f"ringpp_q{nq}"] = {"pairs_per_s": nq * n_db / ms * 1e3, "ms": ms, "db_entries": n_db, "bytes_per_entry": 351360,
-                                "db_gbs": n_db * 351360 / ms / 1e6, "hbm_frac": n_db * 351360 / ms / 1e6 / HBM_PEAK_GBS}
+    tiled6 = ring.spec_to_tiled(db6)
+    q1 = db6[:1].contiguous()
+    out["ringpp_q1"] = entry(1, ev_ms(lambda: ring.corr_sweep_fft_tiled(q1, tiled6), reps=3, warm=1), 351360, layout="dma-tiled (mrs_loopdb)")
+    del tiled6
+    out["ringpp_q1_row_layout"] = entry(1, ev_ms(lambda: ring.corr_sweep_fft(q1, db6), reps=3, warm=1), 351360)
+    q = db6[:4].contiguous()
+    out["ringpp_q4"] = entry(4, ev_ms(lambda: ring.corr_sweep_fft(q, db6), reps=3, warm=1), 351360)
     del db6
     # DiSCO (disco_ros/main.py:284-291): nearest 1024-d signature over the database, then ONE phase correlation
     g = torch.Generator(device=device).manual_seed(3)
     sig_db = torch.rand((n_db, 1024), generator=g, device=device)
     spec_db = torch.view_as_complex(torch.randn((n_db, 1, 40, 120, 2), generator=g, device=device))
+    ddb = node.DiscoDatabase(capacity=n_db)
+    for i in range(n_db):
+        ddb.append(sig_db[i], spec_db[i])
+    qs, qf = (sig_db[0] + 0.01).contiguous(), spec_db[0].contiguous()
+    ddb.query(qs, qf)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        ddb.query(qs, qf)
+    ms = 1e3 * (time.perf_counter() - t0) / 20
+    out["disco_q1"] = {"queries_per_s": 1e3 / ms, "pairs_per_s": n_db / ms * 1e3, "ms": ms, "db_entries": n_db, "bytes_per_entry": 4096,
+                       "db_gbs": n_db * 4096 / ms / 1e6,
+                       "note": "mrs_loopdb_query_disco, host wall time of the blocking call (device arguments): nearest signature + phase_corr of "
+                               "the winner in two launches"}
     for nq in (1, 4):
         qs = sig_db[:nq].contiguous() + 0.01
 
@@ -438,9 +472,58 @@ def sweep_legs(device, spec_pool, n_db=10_000):
             i, _ = disco.signature_search(qs, sig_db)
             return disco.phase_corr(spec_db[:nq], spec_db[i.long()])
         ms = ev_ms(disco_query)
-        out[f"disco_q{nq}"] = {"queries_per_s": nq / ms * 1e3, "pairs_per_s": nq * n_db / ms * 1e3, "ms": ms, "db_entries": n_db,
-                               "bytes_per_entry": 4096, "db_gbs": n_db * 4096 / ms / 1e6,
-                               "note": "signature search over the whole database + phase_corr with the best entry"}
+        out[f"disco_q{nq}_multi_kernel"] = {"queries_per_s": nq / ms * 1e3, "pairs_per_s": nq * n_db / ms * 1e3, "ms": ms, "db_entries": n_db,
+                                            "bytes_per_entry": 4096, "db_gbs": n_db * 4096 / ms / 1e6,
+                                            "note": "signature search over the whole database + rocFFT phase_corr with the best entry (batched form)"}
+    return out
+
+
+def node_shape_leg(device, spec_pool, n_db=10_000, n_loop=1000):
+    """The LoopDetection node's own shape (main_RING.py:126-140, 284-288): one descriptor appended per callback, every new scan scored against
+    every stored entry.  (i) the reference's loop as written, through the drop-in (`fast_corr` per entry on host tensors), (ii) its twin:
+    mrs_loopdb append + ONE query, host wall time of the Python call included.  `spec_pool`: half spectra [>= 256,61,120] (device)."""
+    from mr_slam_amd import node
+    half = spec_pool[:256]
+    pool = torch.cat([half, half[:, 1:60].flip(1).conj()], 1).contiguous()   # TIRING as generate_RING returns it (util.py:198): complex64 [256,120,120], rows 61.. Hermitian
+    host = [pool[i:i + 1].cpu() for i in range(256)]
+    TIRING = [host[i % 256] for i in range(n_db)]
+    cur = host[3]
+    out = {"db_entries": n_db}
+    # (i) the unchanged loop
+    t0 = time.perf_counter()
+    hits = 0
+    for idx in range(n_loop):
+        dist, angle = ring.fast_corr(cur, TIRING[idx])
+        if dist < 0.48:
+            hits += 1
+    t = time.perf_counter() - t0
+    out["reference_loop_through_dropin"] = {"pairs_per_s": n_loop / t, "ms_per_pair": 1e3 * t / n_loop, "entries_timed": n_loop,
+                                            "what": "for idx in range(len(candidates)): fast_corr(TIRING_current, TIRING_candidates[idx]) on host tensors"}
+    # (ii) the twin
+    db = node.LoopDatabase("ring", capacity=1024)
+    t0 = time.perf_counter()
+    for i in range(n_db):
+        db.append(TIRING[i])
+    torch.cuda.synchronize()
+    t_app = time.perf_counter() - t0
+    out["append"] = {"entries_per_s": n_db / t_app, "us_per_entry": 1e6 * t_app / n_db, "what": "TIRING<k>.append(pc_TIRING) from the host tensor, growth included"}
+    cur_dev = pool[3:4].contiguous()
+    cur_spec = cur_dev[:, :61].contiguous()
+    for name, qarg in (("query_host_tiring", cur), ("query_device_tiring", cur_dev), ("query_device_half_spectrum", cur_spec)):
+        db.query(qarg, 0.48)
+        ts = []
+        for _ in range(30):
+            t0 = time.perf_counter()
+            idxs, dists, angles = db.query(qarg, 0.48)
+            ts.append(time.perf_counter() - t0)
+        t = float(np.median(ts))
+        out[name] = {"pairs_per_s": n_db / t, "ms": 1e3 * t, "ms_min": 1e3 * min(ts), "entries_under_threshold": int(len(idxs))}
+    out["twin_pairs_per_s"] = out["query_host_tiring"]["pairs_per_s"]
+    out["speedup_vs_reference_loop"] = out["twin_pairs_per_s"] / out["reference_loop_through_dropin"]["pairs_per_s"]
+    _, _, _, alld, alla = db.query(cur, 0.48, want_all=True)
+    d_ref = np.array([float(ring.fast_corr(cur, TIRING[i])[0]) for i in range(64)], np.float32)
+    a_ref = np.array([int(ring.fast_corr(cur, TIRING[i])[1]) for i in range(64)])
+    out["matches_pairwise"] = bool(np.array_equal(alla[:64], a_ref) and np.abs(alld[:64] - d_ref).max() < 1e-5)
     return out
 
 
@@ -1011,7 +1094,7 @@ def main():
         fence()
         gicp_res = gicp_leg(local_rank, rank, args.gicp_pairs, args.gicp_iters)
         if dist_on:   # whole-job GICP rate: all ranks' iterations / slowest rank's time
-            t = torch.tensor([gicp_res["align_s"]], dtype=torch.float64, device=device)
+            t = torch.tensor([gicp_res["align_s"]], dtype=torch.float64, device=device)    # the cold-start forced protocol
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             gicp_res["iters_per_s"] = world * args.gicp_pairs * args.gicp_iters / float(t.item())
             gicp_res["pairs"] = world * args.gicp_pairs
@@ -1152,7 +1235,8 @@ def main():
             # north_star's own targets as flat scalars of `roofline` (the driver's record keeps scalars of this block)
             gr = gicp_res["roofline"]
             line["roofline"].update({
-                "gicp_iters_per_s": gicp_res["iters_per_s"], "gicp_iters_per_s_cold": gicp_res["cold"]["iters_per_s"],
+                "gicp_iters_per_s": gicp_res["iters_per_s"], "gicp_iters_per_s_warm": gicp_res["warm"]["iters_per_s"],
+                "gicp_iters_per_s_cold5": gicp_res["cold"]["iters_per_s"],
                 "gicp_natural_pairs_per_s": gicp_res["natural"]["pairs_per_s"], "gicp_pairs_per_s_incl_covariances": gicp_res["pairs_per_s_incl_covariances"],
                 "gicp_searched_fraction_natural": gicp_res["natural"]["searched_fraction"],
                 "gicp_linearize_ms": gr["k_linearize"]["ms"], "gicp_linearize_gbs": gr["k_linearize"]["achieved"], "gicp_linearize_frac": gr["k_linearize"]["frac"],
@@ -1246,6 +1330,7 @@ def main():
             line["roofline"]["frac_of_measured_copy"] = achieved / copy_gbs
             line["roofline_polar"]["frac_of_measured_copy"] = line["roofline_polar"]["achieved"] / copy_gbs
             line["sweeps"] = sweep_legs(device, spec32[:CH].reshape(-1, 61, 120))
+            line["node_shape"] = node_shape_leg(device, spec32[:CH].reshape(-1, 61, 120))
             line["pipeline_shard"] = pipeline_shard_leg(device, spec32[:CH].reshape(-1, 61, 120), gicp_res)
             line["builds"] = build_legs(device, chunks)
             line["dropin_latency"] = dropin_latency_leg(host_scans(chunks[0][0], 1)[0])

@@ -98,6 +98,7 @@ public:
         mrs_gicp_batch_destroy(h_);
         h_ = nullptr;
         ctx_ = c;
+        uploaded_[0] = uploaded_[1] = nullptr;
         check(mrs_gicp_batch_create(ctx_, 1, &h_), "mrs_gicp_batch_create");
     }
     int getDevice() const { return mrs_ctx_device(ctx_); }
@@ -112,15 +113,22 @@ public:
         if (m != RegularizationMethod::PLANE) throw std::invalid_argument("only PLANE regularisation is implemented");
     }
 
+    // like upstream (fast_gicp_impl.hpp: `if (input_ == cloud) return;`): handing over the SAME cloud object again keeps what is on the
+    // device -- sorted points, box hierarchy and covariances; the Mapping node re-checks candidate pairs against the submap it already
+    // holds (global_manager.cpp:2016-2021)
     void setInputSource(const PointCloudSourceConstPtr& cloud) override
     {
+        if (cloud && this->input_ == cloud && uploaded_[0] == cloud.get()) return;
         Base::setInputSource(cloud);
         upload(0, *cloud);
+        uploaded_[0] = cloud.get();
     }
     void setInputTarget(const PointCloudTargetConstPtr& cloud) override
     {
+        if (cloud && this->target_ == cloud && uploaded_[1] == cloud.get()) return;
         Base::setInputTarget(cloud);
         upload(1, *cloud);
+        uploaded_[1] = cloud.get();
     }
 
     // pcl::Registration::getFitnessScore(max_range): routed to the GPU NN pass (G6)
@@ -185,6 +193,7 @@ private:
     mrs_gicp_batch* h_ = nullptr;
     mrs_gicp_params prm_;
     double hessian_[36] = {0};
+    const void* uploaded_[2] = {nullptr, nullptr};   // the cloud objects whose points are on the device (source, target)
 };
 
 // Drop-in for fast_gicp::FastVGICPCuda (the launch-file default `registration_method=FAST_VGICP_CUDA`,

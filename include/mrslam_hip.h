@@ -173,7 +173,8 @@ enum mrs_radon_option {
     MRS_RADON_OPT_FUSED_STAGGER_US = 1, /* odd workgroups start this many microseconds late (default 70, 0 = off) */
     MRS_RADON_OPT_FUSED_PREFETCH = 2,   /* 16-byte load triplets in flight per lane while rasterising: 2, 4 or 6 */
     MRS_RADON_OPT_FUSED_GRID = 3,       /* persistent workgroups (0 = one per compute unit)                      */
-    MRS_RADON_OPT_FUSED_VARIANT = 4     /* 1: rays dealt to lanes by length (slot tables), rolled ray loop; 0: (angle, detector) order */
+    MRS_RADON_OPT_FUSED_VARIANT = 4     /* 2 (default): rays dealt to lanes by length (slot tables), raw sums in registers, the sinogram written
+                                           once; 1: the same with the raw sums parked in the output buffer; 0: (angle, detector) order */
 };
 int mrs_radon_plan_set_option(mrs_radon_plan* plan, int32_t option, int32_t value);
 
@@ -286,6 +287,14 @@ int mrs_gicp_batch_set_clouds(mrs_gicp_batch* h, int32_t which, const float* d_p
  * the C++ adapter, pygicp.FastGICP.set_input_*): staged through the library's scratch cache, synchronous. */
 int mrs_gicp_batch_set_clouds_host(mrs_gicp_batch* h, int32_t which, const float* h_points, int32_t stride_floats,
                                    const int64_t* h_offsets);
+/* Submap store: a second batch used as a container of UNIQUE clouds (mrs_gicp_batch_create(ctx, n_clouds), set_clouds(which = 1, ...),
+ * compute_covariances(1)).  Pair i's cloud of side `which` := cloud h_ids[i] of side `store_which` of `store`: the sorted points, the
+ * covariances, the boxes and the octree-cell hierarchy are copied on the device, nothing is rebuilt -- a submap that takes part in several
+ * pairs (a new scan checked against several stored candidates: main_RING.py:81-104, global_manager.cpp:2016-2021, where fast_gicp itself
+ * recomputes both clouds' covariances for every pair) is sorted and gets its covariances once.  Same results as set_clouds with the same
+ * points (tests/test_gicp_gpu.py).  Both batches must use the same k_correspondences. */
+int mrs_gicp_batch_set_clouds_from(mrs_gicp_batch* h, int32_t which, mrs_gicp_batch* store, int32_t store_which, const int32_t* h_ids,
+                                   mrs_stream stream);
 
 /* G2: FastGICP::calculate_covariances (brute-force kNN, PLANE regularisation).  Called lazily
  * by align; exposed so that it can be timed / cached per submap.  d_knn_out (optional, may be

@@ -1165,7 +1165,9 @@ struct CertArrays {
     int* work;             // [source points] per pair (at the pair's source offset): source indices that need a search
     int* bcount;           // [pairs][nb] entries in the work list of each block of 1024 consecutive source points (its list starts at the block)
     int nb;                // blocks of the longest source cloud
-    unsigned long long* searched;   // [2] statistics of an align(): queries searched, queries due (points of the pairs that searched, per pass)
+    unsigned long long* searched;   // [pairs][kStatStride] statistics of an align(), slots 0 / 1 of every pair: queries searched, queries due (points of the
+                                    // pairs that searched, per pass).  One 128-byte line per pair: 30 000 workgroups adding to ONE word serialise in its L2
+                                    // channel (~12 ns each: 0.7 ms of a 0.77 ms k_nn_certify); the host sums the pairs
 };
 
 __device__ __forceinline__ void pose_f(const LmState& S, float (&Tf)[12])
@@ -1174,6 +1176,7 @@ __device__ __forceinline__ void pose_f(const LmState& S, float (&Tf)[12])
     for (int i = 0; i < 12; ++i) Tf[i] = (float)S.x[i];
 }
 
+constexpr int kStatStride = 16;    // unsigned long longs per pair in CertArrays::searched (128 bytes)
 constexpr int kCertBlock = 1024;   // consecutive source points whose uncertified members form one work list (searched by one workgroup)
 
 // One workgroup per 1024 consecutive source points of every pair that is about to search: certify the old neighbour or put the point on
@@ -1254,8 +1257,8 @@ __global__ __launch_bounds__(256) void k_nn_certify(const float4* __restrict__ s
         for (int u = 0; u < 16; ++u) total += wcnt[u];
         C.bcount[(size_t)pair * C.nb + blockIdx.x] = total;
         const int members = min(kCertBlock, n - b0);
-        atomicAdd(&C.searched[0], (unsigned long long)(2 * total > members ? members : total));
-        atomicAdd(&C.searched[1], (unsigned long long)members);
+        atomicAdd(&C.searched[(size_t)pair * kStatStride], (unsigned long long)(2 * total > members ? members : total));
+        atomicAdd(&C.searched[(size_t)pair * kStatStride + 1], (unsigned long long)members);
     }
 }
 
@@ -1273,8 +1276,8 @@ __global__ void k_nn_store_pose(const LmState* __restrict__ st, int n_pairs, Cer
     for (int i = 0; i < 12; ++i) C.t_prev[12 * pair + i] = Tf[i];
     const int n_src = (int)(src_offs[pair + 1] - src_offs[pair]);
     if (worklists && !(pair_motion(S) > motion_switch)) return;        // counted block by block in k_nn_certify
-    atomicAdd(&C.searched[0], (unsigned long long)n_src);
-    atomicAdd(&C.searched[1], (unsigned long long)n_src);
+    C.searched[(size_t)pair * kStatStride] += (unsigned long long)n_src;      // this pair's own line, one thread per pair, stream-ordered
+    C.searched[(size_t)pair * kStatStride + 1] += (unsigned long long)n_src;
 }
 
 // G3a, round 4: exact 1-NN of every (float-)transformed source point.  One query per lane; semantics of k_nn_scan (corr = target index in
@@ -2028,6 +2031,7 @@ struct mrs_gicp_batch {
     int* d_tile_first[2] = {nullptr, nullptr};
     int* d_super_first[2] = {nullptr, nullptr};
     int cap_leaves[2] = {0, 0}, cap_tiles2[2] = {0, 0}, cap_supers[2] = {0, 0};
+    std::vector<int> h_leaf_first[2], h_tile_first[2], h_super_first[2];   // host copies (set_clouds_from re-bases them)
     int n_leaves[2] = {0, 0};
     int search_core = 1;            // 1: octree leaves + query groups (round 4), 0: round-3 wave-shared traversal (A/B, cross-check)
     int cold_core = 0;              // search_core 1: kernel of the FIRST pass of an align() (0: round-3 kernel, 1: round-4 kernel)
@@ -2045,6 +2049,15 @@ struct mrs_gicp_batch {
 };
 
 namespace {
+
+// dst[seg.dst + i] = src[seg.src + i], i < seg.count, for every segment (one per pair; blockIdx.y): how set_clouds_from moves a stored cloud's
+// arrays into a pair's slot.  seg = {src offset, dst offset, count} in units of T.
+template <class T>
+__global__ void k_copy_segments(const T* __restrict__ src, T* __restrict__ dst, const int64_t* __restrict__ seg, int64_t scale)
+{
+    const int64_t so = seg[3 * blockIdx.y] * scale, dofs = seg[3 * blockIdx.y + 1] * scale, n = seg[3 * blockIdx.y + 2] * scale;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[dofs + i] = src[so + i];
+}
 
 void free_cloud(mrs_gicp_batch* h, int w)
 {
@@ -2138,6 +2151,7 @@ int build_leaf_hier(mrs_gicp_batch* h, int w, const unsigned long long* d_keys, 
         most_supers = std::max(most_supers, ns);
     }
     h->n_leaves[w] = lf[P];
+    h->h_leaf_first[w] = lf; h->h_tile_first[w] = tf; h->h_super_first[w] = sf;
     auto grow = [](float4*& a, float4*& b, int& cap, int need) -> hipError_t {
         if (need <= cap && a) return hipSuccess;
         if (a) (void)hipFree(a);
@@ -2241,6 +2255,78 @@ int launch_knn_select(mrs_gicp_batch* h, int w, int k, int* d_knn, hipStream_t s
 
 }  // namespace
 
+// Everything of set_clouds that does not look at the points: checks, (re)allocation of the side's buffers, offsets and tile bases, reset of
+// the warm-start seeds.  longest / longest_tiles: the largest cloud of the side.
+static int prepare_side(mrs_gicp_batch* h, int32_t which, const int64_t* h_offsets, hipStream_t s, int64_t& longest, int& longest_tiles)
+{
+    MRS_REQUIRE(h && h_offsets, "null pointer");
+    MRS_REQUIRE(which == 0 || which == 1, "which must be 0 (source) or 1 (target)");
+    MRS_REQUIRE(h_offsets[0] == 0, "offsets[0] must be 0");
+    for (int i = 0; i < h->n_pairs; ++i) {
+        MRS_REQUIRE(h_offsets[i + 1] > h_offsets[i], "every cloud needs at least one point");
+        MRS_REQUIRE(h_offsets[i + 1] - h_offsets[i] < (1ll << 28), "cloud too large (2^28 points at most)");
+    }
+    MRS_HIP_TRY(hipSetDevice(h->ctx->device));
+    const int64_t total = h_offsets[h->n_pairs];
+    MRS_REQUIRE(total < (1ll << 31), "more than 2^31 points in one batch");
+    MRS_REQUIRE(h->n_pairs < (1 << 21), "too many pairs for the 64-bit sort key");
+    h->offs[which].assign(h_offsets, h_offsets + h->n_pairs + 1);
+    std::vector<int> tile_base(h->n_pairs);
+    int tiles = 0;
+    longest_tiles = 0;
+    longest = 0;
+    for (int i = 0; i < h->n_pairs; ++i) {
+        const int64_t n = h_offsets[i + 1] - h_offsets[i];
+        const int nt = (int)((n + kTile - 1) / kTile);
+        tile_base[i] = tiles;
+        tiles += nt;
+        longest_tiles = std::max(longest_tiles, nt);
+        longest = std::max(longest, n);
+    }
+    h->max_tiles[which] = longest_tiles;
+    h->cov_valid[which] = false;
+    // a registration object is fed a new cloud per loop candidate (ICPCheck, global_manager.cpp:2018-2019): keep the device
+    // buffers and only grow them (each hipFree synchronises the device, each hipMalloc costs tens of microseconds)
+    if (total > h->cap_points[which] || tiles > h->cap_tiles[which] || !h->d_offs[which]) {
+        free_cloud(h, which);
+        const int64_t cap = total + total / 8;
+        const int capt = tiles + tiles / 8 + 1;
+        MRS_HIP_TRY(hipMalloc(&h->d_offs[which], (h->n_pairs + 1) * sizeof(int64_t)));
+        MRS_HIP_TRY(hipMalloc(&h->d_pts[which], (size_t)cap * sizeof(float4)));
+        if (!h->no_cov) MRS_HIP_TRY(hipMalloc(&h->d_cov[which], (size_t)cap * 6 * sizeof(double)));
+        MRS_HIP_TRY(hipMalloc(&h->d_tile_base[which], h->n_pairs * sizeof(int)));
+        MRS_HIP_TRY(hipMalloc(&h->d_tlo[which], (size_t)capt * sizeof(float4)));
+        MRS_HIP_TRY(hipMalloc(&h->d_thi[which], (size_t)capt * sizeof(float4)));
+        MRS_HIP_TRY(hipMalloc(&h->d_mlo[which], (size_t)capt * 64 * sizeof(float4)));
+        MRS_HIP_TRY(hipMalloc(&h->d_mhi[which], (size_t)capt * 64 * sizeof(float4)));
+        MRS_HIP_TRY(hipMalloc(&h->d_bbox[which], (size_t)h->n_pairs * 6 * sizeof(int)));
+        h->cap_points[which] = cap; h->cap_tiles[which] = capt;
+        if (which == 0) {
+            if (h->d_corr) (void)hipFree(h->d_corr);
+            if (h->d_seed) (void)hipFree(h->d_seed);
+            h->d_corr = nullptr; h->d_seed = nullptr;
+            MRS_HIP_TRY(hipMalloc(&h->d_corr, (size_t)cap * sizeof(int)));
+            MRS_HIP_TRY(hipMalloc(&h->d_seed, (size_t)cap * sizeof(int)));
+            if (h->cert.lb) (void)hipFree(h->cert.lb);
+            if (h->cert.work) (void)hipFree(h->cert.work);
+            h->cert.lb = nullptr; h->cert.work = nullptr;
+            MRS_HIP_TRY(hipMalloc(&h->cert.lb, (size_t)cap * sizeof(float)));
+            MRS_HIP_TRY(hipMalloc(&h->cert.work, ((size_t)cap + kCertBlock) * sizeof(int)));
+            if (!h->cert.t_prev) {
+                MRS_HIP_TRY(hipMalloc(&h->cert.t_prev, (size_t)h->n_pairs * 12 * sizeof(float)));
+
+                MRS_HIP_TRY(hipMalloc(&h->cert.searched, (size_t)h->n_pairs * kStatStride * sizeof(unsigned long long)));
+            }
+        }
+    }
+    if (which == 0) h->n_seed = (size_t)total;
+    if (h->d_seed) MRS_HIP_TRY(hipMemsetAsync(h->d_seed, 0xff, h->n_seed * sizeof(int), s));  // -1: no warm start across clouds
+    MRS_HIP_TRY(hipMemcpyAsync(h->d_offs[which], h_offsets, (h->n_pairs + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    MRS_HIP_TRY(hipMemcpyAsync(h->d_tile_base[which], tile_base.data(), h->n_pairs * sizeof(int), hipMemcpyHostToDevice, s));
+    MRS_HIP_TRY(hipStreamSynchronize(s));   // tile_base and h_offsets are temporaries
+    return MRS_OK;
+}
+
 extern "C" {
 
 int mrs_gicp_batch_set_search(mrs_gicp_batch* h, int32_t core)
@@ -2343,74 +2429,16 @@ int mrs_gicp_batch_set_clouds(mrs_gicp_batch* h, int32_t which, const float* d_p
                               const int64_t* h_offsets, mrs_stream stream)
 {
     MRS_REQUIRE(h && d_points && h_offsets, "null pointer");
-    MRS_REQUIRE(which == 0 || which == 1, "which must be 0 (source) or 1 (target)");
     MRS_REQUIRE(stride_floats >= 3, "stride_floats must be >= 3");
-    MRS_REQUIRE(h_offsets[0] == 0, "offsets[0] must be 0");
-    for (int i = 0; i < h->n_pairs; ++i) {
-        MRS_REQUIRE(h_offsets[i + 1] > h_offsets[i], "every cloud needs at least one point");
-        MRS_REQUIRE(h_offsets[i + 1] - h_offsets[i] < (1ll << 28), "cloud too large (2^28 points at most)");
-    }
-    MRS_HIP_TRY(hipSetDevice(h->ctx->device));
     hipStream_t s = (hipStream_t)stream;
-    const int64_t total = h_offsets[h->n_pairs];
-    MRS_REQUIRE(total < (1ll << 31), "more than 2^31 points in one batch");
-    MRS_REQUIRE(h->n_pairs < (1 << 21), "too many pairs for the 64-bit sort key");
-    h->offs[which].assign(h_offsets, h_offsets + h->n_pairs + 1);
-    std::vector<int> tile_base(h->n_pairs);
-    int tiles = 0, longest_tiles = 0;
     int64_t longest = 0;
-    for (int i = 0; i < h->n_pairs; ++i) {
-        const int64_t n = h_offsets[i + 1] - h_offsets[i];
-        const int nt = (int)((n + kTile - 1) / kTile);
-        tile_base[i] = tiles;
-        tiles += nt;
-        longest_tiles = std::max(longest_tiles, nt);
-        longest = std::max(longest, n);
-    }
-    h->max_tiles[which] = longest_tiles;
-    h->cov_valid[which] = false;
-    // a registration object is fed a new cloud per loop candidate (ICPCheck, global_manager.cpp:2018-2019): keep the device
-    // buffers and only grow them (each hipFree synchronises the device, each hipMalloc costs tens of microseconds)
-    if (total > h->cap_points[which] || tiles > h->cap_tiles[which] || !h->d_offs[which]) {
-        free_cloud(h, which);
-        const int64_t cap = total + total / 8;
-        const int capt = tiles + tiles / 8 + 1;
-        MRS_HIP_TRY(hipMalloc(&h->d_offs[which], (h->n_pairs + 1) * sizeof(int64_t)));
-        MRS_HIP_TRY(hipMalloc(&h->d_pts[which], (size_t)cap * sizeof(float4)));
-        if (!h->no_cov) MRS_HIP_TRY(hipMalloc(&h->d_cov[which], (size_t)cap * 6 * sizeof(double)));
-        MRS_HIP_TRY(hipMalloc(&h->d_tile_base[which], h->n_pairs * sizeof(int)));
-        MRS_HIP_TRY(hipMalloc(&h->d_tlo[which], (size_t)capt * sizeof(float4)));
-        MRS_HIP_TRY(hipMalloc(&h->d_thi[which], (size_t)capt * sizeof(float4)));
-        MRS_HIP_TRY(hipMalloc(&h->d_mlo[which], (size_t)capt * 64 * sizeof(float4)));
-        MRS_HIP_TRY(hipMalloc(&h->d_mhi[which], (size_t)capt * 64 * sizeof(float4)));
-        MRS_HIP_TRY(hipMalloc(&h->d_bbox[which], (size_t)h->n_pairs * 6 * sizeof(int)));
-        h->cap_points[which] = cap; h->cap_tiles[which] = capt;
-        if (which == 0) {
-            if (h->d_corr) (void)hipFree(h->d_corr);
-            if (h->d_seed) (void)hipFree(h->d_seed);
-            h->d_corr = nullptr; h->d_seed = nullptr;
-            MRS_HIP_TRY(hipMalloc(&h->d_corr, (size_t)cap * sizeof(int)));
-            MRS_HIP_TRY(hipMalloc(&h->d_seed, (size_t)cap * sizeof(int)));
-            if (h->cert.lb) (void)hipFree(h->cert.lb);
-            if (h->cert.work) (void)hipFree(h->cert.work);
-            h->cert.lb = nullptr; h->cert.work = nullptr;
-            MRS_HIP_TRY(hipMalloc(&h->cert.lb, (size_t)cap * sizeof(float)));
-            MRS_HIP_TRY(hipMalloc(&h->cert.work, ((size_t)cap + kCertBlock) * sizeof(int)));
-            if (!h->cert.t_prev) {
-                MRS_HIP_TRY(hipMalloc(&h->cert.t_prev, (size_t)h->n_pairs * 12 * sizeof(float)));
-
-                MRS_HIP_TRY(hipMalloc(&h->cert.searched, 2 * sizeof(unsigned long long)));
-            }
-        }
-    }
-    if (which == 0) h->n_seed = (size_t)total;
-    if (h->d_seed) MRS_HIP_TRY(hipMemsetAsync(h->d_seed, 0xff, h->n_seed * sizeof(int), s));  // -1: no warm start across clouds
-    MRS_HIP_TRY(hipMemcpyAsync(h->d_offs[which], h_offsets, (h->n_pairs + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
-    MRS_HIP_TRY(hipMemcpyAsync(h->d_tile_base[which], tile_base.data(), h->n_pairs * sizeof(int), hipMemcpyHostToDevice, s));
+    int longest_tiles = 0;
+    int st = prepare_side(h, which, h_offsets, s, longest, longest_tiles);
+    if (st != MRS_OK) return st;
+    const int64_t total = h_offsets[h->n_pairs];
 
     // Morton order: per-cloud bounding box -> 64-bit keys (cloud id | Morton code) -> stable radix sort
     mrs::Scratch keys_in, keys_out, vals_in, vals_out, tmp;
-    int st;
     int* const bbox_p = h->d_bbox[which];
     if ((st = keys_in.alloc((size_t)total * 8, s)) != MRS_OK) return st;
     if ((st = keys_out.alloc((size_t)total * 8, s)) != MRS_OK) return st;
@@ -2451,6 +2479,119 @@ int mrs_gicp_batch_set_clouds(mrs_gicp_batch* h, int32_t which, const float* d_p
         h->hier_valid[which] = true;
     }
     MRS_HIP_TRY(hipStreamSynchronize(s));
+    return MRS_OK;
+}
+
+/* Pair i's cloud of side `which` := cloud h_ids[i] of side `store_which` of `store` (a batch used as a container of unique submaps):
+ * sorted points, covariances, tile / mini boxes and the octree-cell hierarchy are COPIED on the device (a few MB per cloud) instead of
+ * being rebuilt -- a submap that takes part in several pairs (the node checks a new scan against several stored candidates,
+ * main_RING.py:81-104, global_manager.cpp:2016-2021) pays for its Morton sort and its covariances once. */
+int mrs_gicp_batch_set_clouds_from(mrs_gicp_batch* h, int32_t which, mrs_gicp_batch* store, int32_t store_which, const int32_t* h_ids,
+                                   mrs_stream stream)
+{
+    MRS_REQUIRE(h && store && h_ids, "null pointer");
+    MRS_REQUIRE(h != store, "a batch cannot be its own store");
+    MRS_REQUIRE(which == 0 || which == 1, "which must be 0 (source) or 1 (target)");
+    MRS_REQUIRE(store_which == 0 || store_which == 1, "store_which must be 0 or 1");
+    MRS_REQUIRE(h->ctx->device == store->ctx->device, "batch and store live on different devices");
+    MRS_REQUIRE(store->d_pts[store_which] != nullptr, "the store holds no clouds on that side");
+    MRS_REQUIRE(!h->no_cov && !store->no_cov, "covariance-free containers cannot take part");
+    MRS_REQUIRE(h->prm.k == store->prm.k, "batch and store use different k_correspondences");
+    const int sw = store_which, P = h->n_pairs, U = store->n_pairs;
+    for (int i = 0; i < P; ++i) MRS_REQUIRE(h_ids[i] >= 0 && h_ids[i] < U, "cloud id outside the store");
+    const bool need_hier = h->want_leaf_hier && (which == 1 || (h->search_core == 1 && h->cold_core == 1));
+    MRS_REQUIRE(!need_hier || store->hier_valid[sw], "the store side has no octree-cell hierarchy (store the clouds as targets)");
+    MRS_HIP_TRY(hipSetDevice(h->ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    int st;
+    if (!store->cov_valid[sw] && (st = mrs_gicp_batch_compute_covariances(store, sw, nullptr, stream)) != MRS_OK) return st;
+    const std::vector<int64_t>& so = store->offs[sw];
+    std::vector<int64_t> offs(P + 1, 0);
+    for (int i = 0; i < P; ++i) offs[i + 1] = offs[i] + (so[h_ids[i] + 1] - so[h_ids[i]]);
+    int64_t longest = 0;
+    int longest_tiles = 0;
+    if ((st = prepare_side(h, which, offs.data(), s, longest, longest_tiles)) != MRS_OK) return st;
+    // segment tables {source offset, destination offset, count}: points, 1024-point tiles, and the three levels of the hierarchy
+    std::vector<int> stile(U + 1, 0);
+    for (int u = 0; u < U; ++u) stile[u + 1] = stile[u] + (int)((so[u + 1] - so[u] + kTile - 1) / kTile);
+    std::vector<int64_t> seg((size_t)5 * 3 * P);
+    std::vector<int> lf(P + 1, 0), tf(P + 1, 0), sf(P + 1, 0);
+    int dtile = 0;
+    int64_t most[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < P; ++i) {
+        const int u = h_ids[i];
+        const int64_t cnt[5] = {so[u + 1] - so[u], stile[u + 1] - stile[u],
+                                need_hier ? store->h_leaf_first[sw][u + 1] - store->h_leaf_first[sw][u] : 0,
+                                need_hier ? store->h_tile_first[sw][u + 1] - store->h_tile_first[sw][u] : 0,
+                                need_hier ? store->h_super_first[sw][u + 1] - store->h_super_first[sw][u] : 0};
+        const int64_t from[5] = {so[u], stile[u], need_hier ? store->h_leaf_first[sw][u] : 0, need_hier ? store->h_tile_first[sw][u] : 0,
+                                 need_hier ? store->h_super_first[sw][u] : 0};
+        const int64_t to[5] = {offs[i], dtile, lf[i], tf[i], sf[i]};
+        for (int a = 0; a < 5; ++a) {
+            seg[((size_t)a * P + i) * 3] = from[a]; seg[((size_t)a * P + i) * 3 + 1] = to[a]; seg[((size_t)a * P + i) * 3 + 2] = cnt[a];
+            most[a] = std::max(most[a], cnt[a]);
+        }
+        dtile += (int)cnt[1];
+        lf[i + 1] = lf[i] + (int)cnt[2]; tf[i + 1] = tf[i] + (int)cnt[3]; sf[i + 1] = sf[i] + (int)cnt[4];
+    }
+    mrs::Scratch dseg;
+    if ((st = dseg.alloc(seg.size() * sizeof(int64_t), s)) != MRS_OK) return st;
+    MRS_HIP_TRY(hipMemcpyAsync(dseg.p, seg.data(), seg.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    auto table = [&](int a) { return dseg.as<int64_t>() + (size_t)a * P * 3; };
+    auto copy4 = [&](const float4* src, float4* dst, int a, int64_t scale) {
+        const unsigned bx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((most[a] * scale + 1023) / 1024, 256));
+        hipLaunchKernelGGL(k_copy_segments<float4>, dim3(bx, P), dim3(256), 0, s, src, dst, (const int64_t*)table(a), scale);
+    };
+    copy4(store->d_pts[sw], h->d_pts[which], 0, 1);
+    copy4(reinterpret_cast<const float4*>(store->d_cov[sw]), reinterpret_cast<float4*>(h->d_cov[which]), 0, 3);      // 6 doubles = 3 x 16 bytes
+    copy4(store->d_tlo[sw], h->d_tlo[which], 1, 1);
+    copy4(store->d_thi[sw], h->d_thi[which], 1, 1);
+    copy4(store->d_mlo[sw], h->d_mlo[which], 1, 64);
+    copy4(store->d_mhi[sw], h->d_mhi[which], 1, 64);
+    {   // the clouds' bounding boxes (the Morton grids): 6 ints per cloud
+        std::vector<int64_t> bseg((size_t)3 * P);
+        for (int i = 0; i < P; ++i) { bseg[3 * i] = 6 * (int64_t)h_ids[i]; bseg[3 * i + 1] = 6 * (int64_t)i; bseg[3 * i + 2] = 6; }
+        mrs::Scratch dbs;
+        if ((st = dbs.alloc(bseg.size() * sizeof(int64_t), s)) != MRS_OK) return st;
+        MRS_HIP_TRY(hipMemcpyAsync(dbs.p, bseg.data(), bseg.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_copy_segments<int>, dim3(1, P), dim3(64), 0, s, (const int*)store->d_bbox[sw], h->d_bbox[which], (const int64_t*)dbs.p, (int64_t)1);
+        MRS_HIP_TRY(hipStreamSynchronize(s));     // bseg / dbs are temporaries
+    }
+    h->hier_valid[which] = false;
+    if (need_hier) {
+        if (!h->d_leaf_first[which]) {
+            MRS_HIP_TRY(hipMalloc(&h->d_leaf_first[which], (size_t)(P + 1) * sizeof(int)));
+            MRS_HIP_TRY(hipMalloc(&h->d_tile_first[which], (size_t)(P + 1) * sizeof(int)));
+            MRS_HIP_TRY(hipMalloc(&h->d_super_first[which], (size_t)(P + 1) * sizeof(int)));
+        }
+        auto grow = [](float4*& a, float4*& b, int& cap, int need) -> hipError_t {
+            if (need <= cap && a) return hipSuccess;
+            if (a) (void)hipFree(a);
+            if (b) (void)hipFree(b);
+            a = b = nullptr;
+            cap = need + need / 8 + 1;
+            hipError_t e = hipMalloc(&a, (size_t)cap * sizeof(float4));
+            return e != hipSuccess ? e : hipMalloc(&b, (size_t)cap * sizeof(float4));
+        };
+        MRS_HIP_TRY(grow(h->d_llo[which], h->d_lhi[which], h->cap_leaves[which], lf[P]));
+        MRS_HIP_TRY(grow(h->d_t2lo[which], h->d_t2hi[which], h->cap_tiles2[which], tf[P]));
+        MRS_HIP_TRY(grow(h->d_slo[which], h->d_shi[which], h->cap_supers[which], sf[P]));
+        MRS_HIP_TRY(hipMemcpyAsync(h->d_leaf_first[which], lf.data(), lf.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        MRS_HIP_TRY(hipMemcpyAsync(h->d_tile_first[which], tf.data(), tf.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        MRS_HIP_TRY(hipMemcpyAsync(h->d_super_first[which], sf.data(), sf.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        copy4(store->d_llo[sw], h->d_llo[which], 2, 1);
+        copy4(store->d_lhi[sw], h->d_lhi[which], 2, 1);
+        copy4(store->d_t2lo[sw], h->d_t2lo[which], 3, 1);
+        copy4(store->d_t2hi[sw], h->d_t2hi[which], 3, 1);
+        copy4(store->d_slo[sw], h->d_slo[which], 4, 1);
+        copy4(store->d_shi[sw], h->d_shi[which], 4, 1);
+        h->n_leaves[which] = lf[P];
+        h->h_leaf_first[which] = lf; h->h_tile_first[which] = tf; h->h_super_first[which] = sf;
+        h->hier_valid[which] = true;
+    }
+    MRS_HIP_TRY(hipGetLastError());
+    MRS_HIP_TRY(hipStreamSynchronize(s));         // the tables are temporaries
+    h->cov_valid[which] = true;
     return MRS_OK;
 }
 
@@ -2684,7 +2825,7 @@ int mrs_gicp_batch_align(mrs_gicp_batch* h, const double* h_guess, double* h_fin
         S.lambda = -1.0; S.nu = 2.0; S.active = 1;
     }
     MRS_HIP_TRY(hipMemcpyAsync(h->d_state, init.data(), init.size() * sizeof(LmState), hipMemcpyHostToDevice, s));
-    if (h->cert.searched) MRS_HIP_TRY(hipMemsetAsync(h->cert.searched, 0, 2 * sizeof(unsigned long long), s));
+    if (h->cert.searched) MRS_HIP_TRY(hipMemsetAsync(h->cert.searched, 0, (size_t)h->n_pairs * kStatStride * sizeof(unsigned long long), s));
     const dim3 grid(h->max_blocks, h->n_pairs);
     const int limit = h->prm.force_iters > 0 ? h->prm.force_iters : h->prm.max_iter;
     const long max_ticks = (long)limit * (h->prm.lm_max_iter + 1) + 1;
@@ -2714,8 +2855,10 @@ int mrs_gicp_batch_align(mrs_gicp_batch* h, const double* h_guess, double* h_fin
     h->last_nn_passes = (double)nn_ticks;
     h->last_searched = 1.0;
     if (h->search_core == 1 && h->cert.searched && h->prm.voxel_res <= 0.0 && nn_ticks > 0) {
+        std::vector<unsigned long long> stat((size_t)h->n_pairs * kStatStride);
+        MRS_HIP_TRY(hipMemcpy(stat.data(), h->cert.searched, stat.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         unsigned long long q[2] = {0, 0};
-        MRS_HIP_TRY(hipMemcpy(q, h->cert.searched, sizeof(q), hipMemcpyDeviceToHost));
+        for (int p = 0; p < h->n_pairs; ++p) { q[0] += stat[(size_t)p * kStatStride]; q[1] += stat[(size_t)p * kStatStride + 1]; }
         if (q[1]) h->last_searched = (double)q[0] / (double)q[1];
     }
     MRS_HIP_TRY(hipMemcpy(init.data(), h->d_state, init.size() * sizeof(LmState), hipMemcpyDeviceToHost));

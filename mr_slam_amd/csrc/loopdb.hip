@@ -11,6 +11,7 @@
 // All work of a handle runs on the handle's own stream; calls are serialised by a mutex (the reference's callbacks run on
 // concurrent rospy threads, each appending to its own list and reading the other robots').
 #include "common.hpp"
+#include "fft_codelets.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -57,61 +58,74 @@ __global__ __launch_bounds__(256) void k_sig_nearest(const float* __restrict__ q
 }
 
 // phase_corr(a = candidate, b = current) for the ONE candidate the search picked (disco_ros/main.py:260-272, 288-291):
-// corr = ifft2(a conj(b), ortho), |corr| (+ 1e-15 under the root), fftshift2d, first maximum.  One workgroup; the R x S
-// product sits in LDS and both passes are direct DFTs with an exact-angle table (R S (R + S) complex multiply-adds: 0.8 M for
-// 40 x 120 -- a few microseconds, no plan, no second launch).
-__global__ __launch_bounds__(1024) void k_disco_phase_one(const float2* __restrict__ spectra, const unsigned long long* __restrict__ best,
-                                                          const float2* __restrict__ cur, int R, int S, const float2* __restrict__ tw,
-                                                          int* __restrict__ out_index, float* __restrict__ out_d2, int* __restrict__ out_arg)
+// corr = ifft2(a conj(b), ortho), |corr| (+ 1e-15 under the root), fftshift2d, first maximum.  One workgroup, everything in LDS, 40 x 120:
+// rows: 120-point inverse transforms as two in-register 60-point codelets (even / odd samples; 80 lanes) + one radix-2 step;
+// columns: 40-point direct transforms (192 k complex multiply-adds spread over 960 work items, the lane's 40 inputs in registers).
+constexpr int kPR = 40, kPS = 120, kPhaseThreads = 512;
+__global__ __launch_bounds__(kPhaseThreads) void k_disco_phase_one(const float2* __restrict__ spectra, const unsigned long long* __restrict__ best,
+                                                                   const float2* __restrict__ cur, const float2* __restrict__ tw,
+                                                                   int* __restrict__ out_index, float* __restrict__ out_d2, int* __restrict__ out_arg)
 {
-    extern __shared__ float2 sm[];        // prod [R][S] | tmp [R][S] | twiddles [S] (exp(+2 pi i k / S)) | [R]
-    float2* prod = sm;
-    float2* tmp = sm + R * S;
-    float2* twS = tmp + R * S;
-    float2* twR = twS + S;
-    __shared__ float bv[16];
-    __shared__ int bi[16];
+    extern __shared__ float2 sm[];        // A [R][S] | B [R][S] | twiddles exp(+2 pi i k / S), k < S | exp(+2 pi i k / R), k < R
+    float2* A = sm;
+    float2* B = sm + kPR * kPS;
+    float2* twS = B + kPR * kPS;
+    float2* twR = twS + kPS;
+    __shared__ float bv[kPhaseThreads / 64];
+    __shared__ int bi[kPhaseThreads / 64];
+    const int t = threadIdx.x;
     const int idx = (int)(unsigned)(*best & 0xffffffffull);
-    const float2* a = spectra + (size_t)idx * R * S;
-    for (int i = threadIdx.x; i < R * S; i += 1024) {
+    const float2* a = spectra + (size_t)idx * kPR * kPS;
+    for (int i = t; i < kPR * kPS; i += kPhaseThreads) {
         const float2 x = a[i], y = cur[i];                     // x conj(y)
-        prod[i] = make_float2(x.x * y.x + x.y * y.y, x.y * y.x - x.x * y.y);
+        A[i] = make_float2(x.x * y.x + x.y * y.y, x.y * y.x - x.x * y.y);
     }
-    for (int i = threadIdx.x; i < S; i += 1024) twS[i] = tw[i];
-    for (int i = threadIdx.x; i < R; i += 1024) twR[i] = tw[S + i];
+    for (int i = t; i < kPS; i += kPhaseThreads) twS[i] = tw[i];
+    for (int i = t; i < kPR; i += kPhaseThreads) twR[i] = tw[kPS + i];
     __syncthreads();
-    for (int o = threadIdx.x; o < R * S; o += 1024) {          // inverse DFT along the sector axis
-        const int r = o / S, n = o - r * S;
-        float re = 0.0f, im = 0.0f;
-        int k = 0;
-        for (int s = 0; s < S; ++s) {
-            const float2 v = prod[r * S + s], w = twS[k];
-            re = __builtin_fmaf(v.x, w.x, __builtin_fmaf(-v.y, w.y, re));
-            im = __builtin_fmaf(v.x, w.y, __builtin_fmaf(v.y, w.x, im));
-            k += n; if (k >= S) k -= S;
-        }
-        tmp[o] = make_float2(re, im);
+    if (t < 2 * kPR) {                                         // E / O: 60-point inverse transforms of a row's even / odd samples
+        const int r = t >> 1, par = t & 1;
+        v2f x[60];
+#pragma unroll
+        for (int m = 0; m < 60; ++m) { const float2 v = A[r * kPS + 2 * m + par]; x[m] = (v2f){v.x, v.y}; }
+        cfft60_inv(x);
+#pragma unroll
+        for (int k = 0; k < 60; ++k) B[r * kPS + par * 60 + k] = make_float2(x[k].x, x[k].y);
     }
     __syncthreads();
-    const float scale = 1.0f / sqrtf((float)(R * S));
+    for (int o = t; o < kPR * kPS; o += kPhaseThreads) {      // X[n] = E[n mod 60] + w^n O[n mod 60]
+        const int r = o / kPS, n = o - r * kPS, k = n >= 60 ? n - 60 : n;
+        const float2 e = B[r * kPS + k], od = B[r * kPS + 60 + k], w = twS[n];
+        A[o] = make_float2(e.x + (w.x * od.x - w.y * od.y), e.y + (w.x * od.y + w.y * od.x));
+    }
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)(kPR * kPS));
     float bestv = -1.0f;
     int bidx = 0x7fffffff;
-    for (int m = threadIdx.x; m < R * S; m += 1024) {          // m: index in the SHIFTED map; inverse DFT along the ring axis at its source
-        const int r = m / S, s = m - r * S;
-        const int sr = (r + (R + 1) / 2) % R, ss = (s + (S + 1) / 2) % S;
-        float re = 0.0f, im = 0.0f;
-        int k = 0;
-        for (int j = 0; j < R; ++j) {
-            const float2 v = tmp[j * S + ss], w = twR[k];
-            re = __builtin_fmaf(v.x, w.x, __builtin_fmaf(-v.y, w.y, re));
-            im = __builtin_fmaf(v.x, w.y, __builtin_fmaf(v.y, w.x, im));
-            k += sr; if (k >= R) k -= R;
+    for (int wi = t; wi < 8 * kPS; wi += kPhaseThreads) {     // work item = (column n, 5 consecutive output rows)
+        const int g = wi / kPS, n = wi - g * kPS;
+        float2 in[kPR];
+#pragma unroll
+        for (int j = 0; j < kPR; ++j) in[j] = A[j * kPS + n];
+        for (int mm = 0; mm < 5; ++mm) {
+            const int m = g * 5 + mm;
+            float re = 0.0f, im = 0.0f;
+            int k = 0;
+#pragma unroll
+            for (int j = 0; j < kPR; ++j) {
+                const float2 w = twR[k];
+                re = __builtin_fmaf(in[j].x, w.x, __builtin_fmaf(-in[j].y, w.y, re));
+                im = __builtin_fmaf(in[j].x, w.y, __builtin_fmaf(in[j].y, w.x, im));
+                k += m; if (k >= kPR) k -= kPR;
+            }
+            re *= scale; im *= scale;
+            const float tot = sqrtf(re * re + im * im + 1e-15f);
+            // fftshift2d (even sizes): source (m, n) appears at ((m + R/2) % R, (n + S/2) % S) of the shifted map
+            const int flat = ((m + kPR / 2) % kPR) * kPS + (n + kPS / 2) % kPS;
+            if (tot > bestv || (tot == bestv && flat < bidx)) { bestv = tot; bidx = flat; }
         }
-        re *= scale; im *= scale;
-        const float tot = sqrtf(re * re + im * im + 1e-15f);
-        if (tot > bestv) { bestv = tot; bidx = m; }
     }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = t >> 6, lane = t & 63;
     for (int o = 32; o > 0; o >>= 1) {
         const float ov = __shfl_xor(bestv, o, 64);
         const int oi = __shfl_xor(bidx, o, 64);
@@ -119,8 +133,8 @@ __global__ __launch_bounds__(1024) void k_disco_phase_one(const float2* __restri
     }
     if (lane == 0) { bv[wave] = bestv; bi[wave] = bidx; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; ++w)
+    if (t == 0) {
+        for (int w = 1; w < kPhaseThreads / 64; ++w)
             if (bv[w] > bestv || (bv[w] == bestv && bi[w] < bidx)) { bestv = bv[w]; bidx = bi[w]; }
         *out_arg = bidx;
         *out_index = idx;
@@ -270,7 +284,7 @@ int mrs_loopdb_create(mrs_ctx* ctx, int32_t kind, int32_t channels, int32_t capa
     db->ctx = ctx; db->kind = kind; db->channels = channels;
     if (kind == MRS_LOOPDB_RING) { db->entry_floats = kTiledFloats; db->in_floats = (size_t)kA * kD * 2; }
     else if (kind == MRS_LOOPDB_RINGPP) { db->entry_floats = (size_t)channels * kTiledFloats; db->in_floats = (size_t)channels * kA * kD; }
-    else { db->sig_dim = 1024; db->R = 40; db->S = 120; db->entry_floats = (size_t)db->R * db->S * 2; db->in_floats = db->entry_floats; }
+    else { db->sig_dim = 1024; db->R = kPR; db->S = kPS; db->entry_floats = (size_t)db->R * db->S * 2; db->in_floats = db->entry_floats; }
     auto fail = [&](int st) { mrs_loopdb_destroy(db); return st; };
 #define LDB_TRY(expr) do { if ((expr) != hipSuccess) { mrs::set_error("%s failed (%s:%d)", #expr, __FILE__, __LINE__); return fail(MRS_ERR_HIP); } } while (0)
     LDB_TRY(hipStreamCreateWithFlags(&db->s, hipStreamNonBlocking));
@@ -468,8 +482,8 @@ int mrs_loopdb_query_disco(mrs_loopdb* db, const float* signature, const float* 
     hipLaunchKernelGGL(k_sig_nearest, dim3(blocks), dim3(256), 0, db->s, sig, db->d_sigs, n, db->sig_dim, db->d_best);
     const size_t lds = (size_t)(2 * db->R * db->S + db->S + db->R) * sizeof(float2);
     MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_disco_phase_one), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_disco_phase_one, dim3(1), dim3(1024), lds, db->s, reinterpret_cast<const float2*>(db->d_entries), db->d_best,
-                       reinterpret_cast<const float2*>(spec), db->R, db->S, reinterpret_cast<const float2*>(db->d_tw), db->d_small,
+    hipLaunchKernelGGL(k_disco_phase_one, dim3(1), dim3(kPhaseThreads), lds, db->s, reinterpret_cast<const float2*>(db->d_entries), db->d_best,
+                       reinterpret_cast<const float2*>(spec), reinterpret_cast<const float2*>(db->d_tw), db->d_small,
                        reinterpret_cast<float*>(db->d_small + 1), db->d_small + 2);
     MRS_HIP_TRY(hipGetLastError());
     MRS_HIP_TRY(hipMemcpyAsync(db->h_small, db->d_small, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, db->s));

@@ -78,6 +78,24 @@ class GicpBatch:
     def set_targets(self, clouds):
         self._set(1, clouds)
 
+    def set_sources_from(self, store, ids, store_which=1):
+        """Pair i's source := cloud ids[i] of `store` (a GicpBatch used as a submap store: set_targets(unique clouds) +
+        compute_covariances(1)).  Sorted points, covariances and boxes are copied on the device, nothing is rebuilt."""
+        self._set_from(0, store, ids, store_which)
+
+    def set_targets_from(self, store, ids, store_which=1):
+        self._set_from(1, store, ids, store_which)
+
+    def _set_from(self, which, store, ids, store_which):
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        assert ids.size == self.n_pairs
+        _lib.check(_lib.load().mrs_gicp_batch_set_clouds_from(self._h, which, store._h, int(store_which), _lib.ptr(ids),
+                                                              _lib.current_stream(self.device)))
+        so = store._n[store_which]
+        offs = np.zeros(self.n_pairs + 1, np.int64)
+        offs[1:] = np.cumsum([so[i + 1] - so[i] for i in ids])
+        self._n[which] = offs
+
     def compute_covariances(self, which, want_knn=False):
         knn = None
         if want_knn:

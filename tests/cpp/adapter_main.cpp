@@ -112,6 +112,16 @@ int main()
             g->setDevice(0);
             if (std::fabs(g->getFitnessScore(1.0) - gpu_fit) > 0.0) all_ok = false;
         }
+        // the SAME cloud objects handed over again (the node re-checks a pair it already holds): the adapter keeps what is on the device,
+        // like upstream's `if (input_ == cloud) return;`, and the alignment repeats bit for bit
+        icp->setInputSource(queryKeyframe);
+        icp->setInputTarget(databaseKeyframe);
+        PointCloudIPtr again(new PointCloudI);
+        icp->align(*again, transformMatrixf);
+        auto repeated = icp->getFinalTransformation();
+        for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < 4; ++c)
+                if (repeated(r, c) != finalResult(r, c)) all_ok = false;
         const double host_fit = icp->getFitnessScore(1.0);
         std::printf("%s converged=%d tx=%.4f ty=%.4f yaw=%.5f fitness(pcl host)=%.6f fitness(gpu)=%.6f aligned=%zu\n", method,
                     (int)icp->hasConverged(), finalResult(0, 3), finalResult(1, 3), std::atan2(finalResult(1, 0), finalResult(0, 0)),

@@ -458,3 +458,42 @@ def test_certified_passes_are_exact(dev, oracle):
                     assert np.array_equal(oracle.pair_d2(src, pose, target, c_new), oracle.pair_d2(src, pose, target, c_old))
         assert np.array_equal(res[1][0], res[2][0]) and np.array_equal(res[1][1], res[2][1])
         assert res[2][2] == 1.0 and res[1][2] < 0.5, res[1][2:]   # most (point, pass) pairs of 14 forced iterations were certified
+
+
+def test_submap_store_pairs_equal_per_pair_clouds_bit_for_bit(dev):
+    """A new scan against several stored candidates (main_RING.py:81-104; global_manager.cpp:2016-2021): clouds kept once in a store batch
+    (Morton order, boxes, hierarchy, covariances) and COPIED into the pairs give the transforms, iteration counts and fitness of handing every
+    pair its own copies of the points."""
+    from mr_slam_amd import gicp, synth
+    rng = np.random.default_rng(11)
+    scans = [synth.lidar_scan(700 + i, 9000 + 500 * i, metric=True) for i in range(4)]          # 4 stored submaps of different sizes
+    new = (scans[1] @ np.array([[np.cos(0.03), -np.sin(0.03), 0], [np.sin(0.03), np.cos(0.03), 0], [0, 0, 1]]).T + np.array([0.2, -0.1, 0.02])
+           + rng.normal(0, 0.01, scans[1].shape)).astype(np.float32)
+    pairs_src = [4, 4, 4, 4, 2]                                                                   # the new scan against all four + one stored pair
+    pairs_tgt = [0, 1, 2, 3, 3]
+    store = gicp.GicpBatch(5)
+    store.set_params(k_correspondences=15, max_correspondence_distance=5.0)
+    store.set_targets(scans + [new])
+    store.compute_covariances(1)
+    a = gicp.GicpBatch(5)
+    a.set_params(k_correspondences=15, max_correspondence_distance=5.0)
+    a.set_sources_from(store, pairs_src)
+    a.set_targets_from(store, pairs_tgt)
+    Ta, ca, ia = a.align()
+    fa = a.fitness(Ta, 1.0)
+    b = gicp.GicpBatch(5)
+    b.set_params(k_correspondences=15, max_correspondence_distance=5.0)
+    allc = scans + [new]
+    b.set_sources([allc[i] for i in pairs_src])
+    b.set_targets([allc[i] for i in pairs_tgt])
+    Tb, cb, ib = b.align()
+    fb = b.fitness(Tb, 1.0)
+    assert np.array_equal(Ta, Tb) and np.array_equal(ca, cb) and np.array_equal(ia, ib) and np.array_equal(fa, fb)
+    assert np.array_equal(a.covariances(0), b.covariances(0)) and np.array_equal(a.covariances(1), b.covariances(1))
+    assert ca[1] and np.abs(Ta[1][:3, 3] - np.array([-0.2, 0.1, -0.02])).max() < 0.08           # pair 1 is the true match
+    # the pairs change, the store stays: a second round against other candidates re-uses everything
+    a.set_targets_from(store, [3, 2, 1, 0, 0])
+    T2, _, _ = a.align()
+    b.set_targets([allc[i] for i in [3, 2, 1, 0, 0]])
+    T3, _, _ = b.align()
+    assert np.array_equal(T2, T3)

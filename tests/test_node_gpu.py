@@ -208,6 +208,9 @@ def test_detect_loop_icp_ring_twin_equals_the_reference_function_on_1000_candida
         cfg = sys.modules["config"]
         desc = [u.generate_RING(u.load_pc_infer(pc)) for pc in clouds]                 # util.py:174-200 on the drop-in modules
         PC, RING, TIRING = clouds[:N], [d[1] for d in desc[:N]], [d[2] for d in desc[:N]]
+        ref_d = np.array([float(u.fast_corr(desc[N][2].to(u.device), t.to(u.device))[0]) for t in TIRING[:200]], np.float32)   # the loop as the node runs it
+        ref_a = np.array([int(u.fast_corr(desc[N][2].to(u.device), t.to(u.device))[1]) for t in TIRING[:200]])
+        u.device = torch.device("cpu")      # util's own global too: solve_overdetermined_linear_system builds s_new on it (util.py:500)
         results = {}
         for which in ("reference", "twin"):
             f, pub = io.StringIO(), _Pub()
@@ -226,10 +229,8 @@ def test_detect_loop_icp_ring_twin_equals_the_reference_function_on_1000_candida
             finally:
                 sys.stdout = old
             results[which] = (f.getvalue(), [(m.Loops[0].id0, m.Loops[0].id1) for m in pub.msgs], log.getvalue())
-        # the candidate lists themselves: the reference's loop (util.fast_corr per entry) against one query of the device twin
+        # the candidate lists themselves: the reference's loop (util.fast_corr per entry, above) against one query of the device twin
         q = desc[N][2]
-        ref_d = np.array([float(u.fast_corr(q.to(u.device), t.to(u.device))[0]) for t in TIRING[:200]], np.float32)
-        ref_a = np.array([int(u.fast_corr(q.to(u.device), t.to(u.device))[1]) for t in TIRING[:200]])
     _, _, _, alld, alla = node.twin_of(TIRING, "ring").query(q, cfg.dist_threshold, want_all=True)
     assert np.array_equal(alla[:200], ref_a) and np.abs(alld[:200] - ref_d).max() < 1e-5
     rf, tf = results["reference"], results["twin"]
@@ -289,3 +290,42 @@ def test_detect_loop_icp_disco_twin_equals_the_reference_function():
                               [ln for ln in log.getvalue().splitlines() if not ln.startswith("robotid:")])
     assert results["reference"][0] == results["twin"][0] and results["reference"][1] == results["twin"][1]
     assert results["reference"][2] == results["twin"][2]
+
+
+@pytest.mark.skipif(not ref_import.available(), reason="reference Python files not present")
+def test_detect_loop_icp_ringpp_twin_equals_the_reference_function():
+    import torch
+    from mr_slam_amd import node, ring
+    path = os.path.join(ref_import.RING_ROS, "main_RINGplusplus.py")
+    if not os.path.exists(path):
+        pytest.skip("main_RINGplusplus.py not staged")
+    N = 60
+    base, clouds = _scene_variants(4, N + 1, 4000, 3)
+    with ref_import.reference_modules("dropin") as ref:
+        u = ref.util
+        cfg = sys.modules["config"]
+        cfg.dist_threshold = 0.41                                                       # main_RINGplusplus.py:397 (the node's argument default)
+        desc = [ring.generate_RINGplusplus(u.load_pc_infer(pc)) for pc in clouds]      # (bev [6,R,S] device, RING cpu, TIRING cpu): util.py:204-250's outputs
+        PC, BEV, TIRING = clouds[:N], [d[0] for d in desc[:N]], [d[2] for d in desc[:N]]
+        results = {}
+        for which in ("reference", "twin"):
+            f, pub = io.StringIO(), _Pub()
+            # rotate_bev is torchvision's rotate (util.py:67-70), absent from this image: both sides get the product's restatement
+            ns = _node_namespace(u, cfg, dict(f=f, pub=pub, device=torch.device("cuda:0"), rotate_bev=ring.rotate_bev))
+            ns = ref_import.reference_modules.functions_of(path, ["get_pose_msg_from_homo_matrix", "fast_gicp", "detect_loop_icp"], ns)
+            fn = ns["detect_loop_icp"] if which == "reference" else node.bind_detect_loop_icp(ns, "ringpp")
+            log = io.StringIO()
+            old = sys.stdout
+            sys.stdout = log
+            try:
+                if which == "reference":
+                    fn(0, 5, clouds[N], desc[N][0], desc[N][2].to(u.device), 1, PC, BEV, [t.to(u.device) for t in TIRING])
+                else:
+                    fn(0, 5, clouds[N], desc[N][0], desc[N][2], 1, PC, BEV, TIRING)
+            finally:
+                sys.stdout = old
+            results[which] = (f.getvalue(), [(m.Loops[0].id0, m.Loops[0].id1) for m in pub.msgs],
+                              [ln for ln in log.getvalue().splitlines() if not ln.startswith(("ICP processed time", "Top 1 TIRING distance", "robotid:"))])
+    assert results["reference"][0] == results["twin"][0] and results["reference"][1] == results["twin"][1]
+    assert results["reference"][2] == results["twin"][2]
+    assert any(ln.startswith(("Loop detected", "No loop detected")) for ln in results["twin"][2])
