@@ -513,6 +513,33 @@ int mrs_crop_scale_batch(mrs_ctx* ctx, const void* d_points, int32_t is_double, 
                          float* d_xyz_soa, int64_t* d_out_offsets, mrs_stream stream);
 
 /* ------------------------------------------------------------------------------------
+ * Multi-GPU exchange of the descriptor database over RCCL / xGMI
+ * ---------------------------------------------------------------------------------- */
+
+/* The reference has no collective at all (its three robots share one process and one GPU).  One process per GPU here; every rank builds the
+ * descriptors of its share of the scans, then either every rank receives everybody's (mrs_exchange_allgather: ONE ncclAllGather per launch;
+ * the per-robot lists of main_RING.py:284-288, replicated) or only the candidate rows a rank asks for travel (mrs_exchange_fetch_rows).
+ * A C++ host (the Mapping node) calls these directly; mr_slam_amd/shard.py calls the same entry points.  RCCL is looked up at run time
+ * (symbols already in the process first, then librccl.so.1); mrs_exchange_available() says whether it was found. */
+typedef struct mrs_exchange mrs_exchange;
+int mrs_exchange_available(void);
+/* ncclGetUniqueId: 128 bytes made by ONE rank and handed to the others by the host (file, socket, torch.distributed broadcast ...) */
+int mrs_exchange_unique_id(uint8_t* out128);
+/* ncclCommInitRank on the context's device; collective over all n_ranks */
+int mrs_exchange_create(mrs_ctx* ctx, int32_t n_ranks, int32_t rank, const uint8_t* id128, mrs_exchange** out);
+/* borrow a communicator the host already has (ncclComm_t as void*); it is not destroyed with the handle */
+int mrs_exchange_create_from_comm(mrs_ctx* ctx, void* nccl_comm, int32_t n_ranks, int32_t rank, mrs_exchange** out);
+int mrs_exchange_destroy(mrs_exchange* x);
+int mrs_exchange_world(const mrs_exchange* x, int32_t* n_ranks, int32_t* rank);
+/* d_all [n_ranks][n_local] entries of entry_bytes <- every rank's d_local [n_local], in rank order.  Enqueued on `stream`. */
+int mrs_exchange_allgather(mrs_exchange* x, const void* d_local, int64_t n_local, int64_t entry_bytes, void* d_all, mrs_stream stream);
+/* Rank r owns global rows [r * rows_per_rank, (r + 1) * rows_per_rank) (d_local_db).  d_out [n_rows] <- the entries of d_global_rows (device
+ * int64 [n_rows], any owner, repeats allowed; the same n_rows on every rank), in request order: the requests are all-gathered, every owner
+ * packs what it was asked for, one grouped send / receive per peer pair moves exactly those rows.  entry_bytes % 16 == 0.  Collective; blocking. */
+int mrs_exchange_fetch_rows(mrs_exchange* x, const void* d_local_db, int64_t rows_per_rank, int64_t entry_bytes, const int64_t* d_global_rows,
+                            int32_t n_rows, void* d_out, mrs_stream stream);
+
+/* ------------------------------------------------------------------------------------
  * Loop database: the per-robot descriptor lists of the LoopDetection nodes, resident on the device
  * ---------------------------------------------------------------------------------- */
 

@@ -161,6 +161,12 @@ int mrs_ctx_create(int device, mrs_ctx** out_ctx)
     MRS_HIP_TRY(hipSetDevice(device));
     hipDeviceProp_t prop;
     MRS_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    // the code objects in this library are gfx950 only (no other target is built): refuse every other device here instead of failing at the
+    // first launch.  MRS_ALLOW_ANY_ARCH=1 skips the test (a gfx950 part that reports a name this check does not know).
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !(getenv("MRS_ALLOW_ANY_ARCH") && atoi(getenv("MRS_ALLOW_ANY_ARCH")) == 1)) {
+        mrs::set_error("device %d is %s: this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+        return MRS_ERR_NO_DEVICE;
+    }
     mrs_ctx* c = new mrs_ctx();
     c->device = device;
     c->num_cu = prop.multiProcessorCount;

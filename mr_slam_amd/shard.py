@@ -309,3 +309,62 @@ class OwnerRescorer:
             if int(left.item()) == 0:
                 break
         return out_d, out_a
+
+
+class Exchange:
+    """The exchange step behind the C ABI (include/mrslam_hip.h: mrs_exchange_*, RCCL looked up at run time): what a C++ host would call,
+    usable from here as well.  The communicator is created by the library from a unique id that rank 0 makes and torch.distributed (any
+    backend) hands to the others; without an initialised process group the world is this one process.
+      allgather(local)              -> [world * n, ...]: every rank's `local` ([n, ...], the same n everywhere), in rank order
+      fetch_rows(local_db, rows)    -> local_db-shaped rows by GLOBAL index (rank r owns rows [r * n, (r + 1) * n)), in request order"""
+
+    def __init__(self, device=0, group=None):
+        import ctypes as C
+        from . import _lib
+        self._C, self._lib_mod = C, _lib
+        lib = _lib.load()
+        if not lib.mrs_exchange_available():
+            raise _lib.MrsError("RCCL entry points not found (librccl.so.1): the C-ABI exchange is unavailable")
+        self.device = int(device)
+        self.world, self.rank = _world(group), _rank(group)
+        ident = (C.c_uint8 * 128)()
+        if self.rank == 0:
+            _lib.check(lib.mrs_exchange_unique_id(ident))
+        if self.world > 1:
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        self._h = C.c_void_p()
+        _lib.check(lib.mrs_exchange_create(_lib.ctx(self.device), self.world, self.rank, ident, C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib_mod.load().mrs_exchange_destroy(self._h)
+        except Exception:
+            pass
+
+    @staticmethod
+    def _bytes(t):
+        return torch.view_as_real(t) if t.is_complex() else t
+
+    def allgather(self, local):
+        _lib = self._lib_mod
+        x = local.contiguous()
+        assert x.is_cuda and x.shape[0] > 0
+        out = torch.empty((self.world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        entry = x[0].numel() * x.element_size()
+        _lib.check(_lib.load().mrs_exchange_allgather(self._h, _lib.ptr(self._bytes(x)), self._C.c_int64(x.shape[0]), self._C.c_int64(entry),
+                                                      _lib.ptr(self._bytes(out)), _lib.current_stream(self.device)))
+        return out
+
+    def fetch_rows(self, local_db, global_rows):
+        _lib = self._lib_mod
+        db = local_db.contiguous()
+        rows = global_rows.to(torch.int64).reshape(-1).contiguous()
+        assert db.is_cuda and rows.is_cuda and rows.numel() > 0
+        entry = db[0].numel() * db.element_size()
+        out = torch.empty((rows.numel(),) + tuple(db.shape[1:]), dtype=db.dtype, device=db.device)
+        _lib.check(_lib.load().mrs_exchange_fetch_rows(self._h, _lib.ptr(self._bytes(db)), self._C.c_int64(db.shape[0]), self._C.c_int64(entry),
+                                                       _lib.ptr(rows), int(rows.numel()), _lib.ptr(self._bytes(out)), _lib.current_stream(self.device)))
+        return out

@@ -329,3 +329,21 @@ def test_detect_loop_icp_ringpp_twin_equals_the_reference_function():
     assert results["reference"][0] == results["twin"][0] and results["reference"][1] == results["twin"][1]
     assert results["reference"][2] == results["twin"][2]
     assert any(ln.startswith(("Loop detected", "No loop detected")) for ln in results["twin"][2])
+
+
+def test_exchange_through_the_c_abi_on_one_rank():
+    """mrs_exchange_* (RCCL behind the C ABI; include/mrslam_hip.h) at world size 1: the all-gather of a descriptor shard and the request-based
+    row fetch return what a local copy / gather returns.  (Several ranks need several GPUs: the driver's SCALE run.)"""
+    import torch
+    from mr_slam_amd import ring, shard
+    x = shard.Exchange(device=0)
+    assert (x.world, x.rank) == (1, 0)
+    spec = ring.half_spectrum(_norm_sinograms(48, 21))                         # [48,61,120] complex64 = 58 560 B entries
+    assert torch.equal(torch.view_as_real(x.allgather(spec)), torch.view_as_real(spec))
+    spec16 = ring.half_spectrum_f16(_norm_sinograms(48, 21), want_f32=False)[1]   # the fp16 replica format
+    assert torch.equal(x.allgather(spec16), spec16)
+    rows = torch.tensor([5, 0, 47, 5, 13, 46], device="cuda:0")
+    got = x.fetch_rows(spec, rows)
+    assert torch.equal(torch.view_as_real(got), torch.view_as_real(spec[rows]))
+    with pytest.raises(Exception):
+        x.fetch_rows(spec, torch.tensor([48], device="cuda:0"))                # outside the database
