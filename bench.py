@@ -136,7 +136,7 @@ def _cpu_workers(mode, inputs, threads, extra=()):
     """nproc / threads worker processes of oracle/cpu_worker.py, pinned to disjoint core ranges, released together; -> list of their JSON lines.
     inputs: one .npz path per worker."""
     import subprocess
-    t_start = time.time() + 12.0 + 0.05 * len(inputs)          # imports + warm-up of every worker happen before this instant
+    t_start = time.time() + 8.0 + 0.03 * len(inputs)           # imports + warm-up of every worker happen before this instant (late_s says if not)
     procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", mode, path, str(w), str(threads), repr(t_start), *map(str, extra)],
                               cwd=os.path.dirname(os.path.abspath(__file__)), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
              for w, path in enumerate(inputs)]
@@ -464,15 +464,16 @@ def gicp_leg(device_index, rank, n_pairs, iters):
     # every kernel of an outer iteration alone between HIP events, at the converged poses (numeric rooflines)
     kms, kcnt = b.profile(T_nat, reps=3)
     n_src, n_corr = kcnt["source_points"], kcnt["correspondences"]
-    lin_bytes = 20 * n_src + 112 * n_corr         # every source point: 16 B point + 4 B index; every correspondence: + 48 B covariance + gathered 16 + 48 B
+    lin_bytes = 20 * n_src + 64 * n_corr          # every source point: 16 B point + 4 B index; every correspondence: + 24 B normal (the PLANE covariance is
+                                                  # I - 0.999 n n^T, rebuilt in the kernel: round 5) + gathered 16 B point + 24 B normal
     knn_bytes = n_src * (16 + 4 * 15)             # the selection's compulsory traffic (point in, 15 indices out): it is VALU-bound, not HBM-bound
-    cov_bytes = n_src * (4 * 15 + 16 + 48)        # indices + own point in, 48 B covariance out (the 15 gathered points are L2 hits)
+    cov_bytes = n_src * (4 * 15 + 16 + 24)        # indices + own point in, 24 B normal out (the 15 gathered points are L2 hits)
 
     def hbm(bytes_, ms):
         gbs = bytes_ / (ms * 1e-3) / 1e9
         return {"bytes": bytes_, "ms": ms, "achieved": gbs, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS}
     roof = {
-        "k_linearize": dict(hbm(lin_bytes, kms["linearize"]), bound="hbm", note="132 B per correspondence + 20 B per unmatched source point, gathered covariances; "
+        "k_linearize": dict(hbm(lin_bytes, kms["linearize"]), bound="hbm", note="84 B per correspondence + 20 B per unmatched source point, gathered normals; "
                             "launched alone at the converged poses, 256 pairs"),
         "k_linearize_error_only": dict(hbm(lin_bytes, kms["linearize_error_only"]), bound="hbm", note="an LM trial: the same bytes, one sum instead of 28"),
         "k_nn_scan (round-3 search, every point, warm)": {"bound": "valu", "ms": kms["search_round3_all"], "queries_per_s": n_src / kms["search_round3_all"] * 1e3,
@@ -502,7 +503,8 @@ def gicp_leg(device_index, rank, n_pairs, iters):
                          "the uncertified queries on octree-cell leaves with per-query culling (k_nn_scan_g); one NN pass per outer iteration, LM trials "
                          "score the cached correspondences (upstream compute_error)",
             "pairs_per_s_incl_covariances": n_pairs / (t_nat + t_cov), "shared_submaps": shared,
-            "covariance_s": t_cov, "covariance_first_call_s": t_cov_first, "covariance_clouds_per_s": 2 * n_pairs / t_cov, "k": 15,
+            "covariance_s": t_cov, "covariance_steady_s": t_cov, "covariance_first_call_s": t_cov_first,
+            "pairs_per_s_incl_covariances_first_call": n_pairs / (t_nat + t_cov_first), "covariance_clouds_per_s": 2 * n_pairs / t_cov, "k": 15,
             "max_correspondence_distance": 5.0, "kernel_ms": kms, "kernel_counts": kcnt, "roofline": roof}
 
 
@@ -561,7 +563,7 @@ def sweep_legs(device, spec_pool, n_db=10_000):
             i, _ = disco.signature_search(qs, sig_db)
             return disco.phase_corr(spec_db[:nq], spec_db[i.long()])
         ms = ev_ms(disco_query)
-        out[f"disco_q{nq}_multi_kernel"] = {"queries_per_s": nq / ms * 1e3, "pairs_per_s": nq * n_db / ms * 1e3, "ms": ms, "db_entries": n_db,
+        out["disco_q1_multi_kernel" if nq == 1 else "disco_q4"] = {"queries_per_s": nq / ms * 1e3, "pairs_per_s": nq * n_db / ms * 1e3, "ms": ms, "db_entries": n_db,
                                             "bytes_per_entry": 4096, "db_gbs": n_db * 4096 / ms / 1e6,
                                             "note": "signature search over the whole database + rocFFT phase_corr with the best entry (batched form)"}
     return out
@@ -572,11 +574,12 @@ def node_shape_leg(device, spec_pool, n_db=10_000, n_loop=1000):
     every stored entry.  (i) the reference's loop as written, through the drop-in (`fast_corr` per entry on host tensors), (ii) its twin:
     mrs_loopdb append + ONE query, host wall time of the Python call included.  `spec_pool`: half spectra [>= 256,61,120] (device)."""
     from mr_slam_amd import node
-    half = spec_pool[:256]
-    pool = torch.cat([half, half[:, 1:60].flip(1).conj()], 1).contiguous()   # TIRING as generate_RING returns it (util.py:198): complex64 [256,120,120], rows 61.. Hermitian
-    host = [pool[i:i + 1].cpu() for i in range(256)]
-    TIRING = [host[i % 256] for i in range(n_db)]
-    cur = host[3]
+    n_pool = min(256, spec_pool.shape[0])
+    half = spec_pool[:n_pool]
+    pool = torch.cat([half, half[:, 1:60].flip(1).conj()], 1).contiguous()   # TIRING as generate_RING returns it (util.py:198): complex64 [.,120,120], rows 61.. Hermitian
+    host = [pool[i:i + 1].cpu() for i in range(n_pool)]
+    TIRING = [host[i % n_pool] for i in range(n_db)]
+    cur = host[3 % n_pool]
     out = {"db_entries": n_db}
     # (i) the unchanged loop
     t0 = time.perf_counter()
@@ -596,7 +599,7 @@ def node_shape_leg(device, spec_pool, n_db=10_000, n_loop=1000):
     torch.cuda.synchronize()
     t_app = time.perf_counter() - t0
     out["append"] = {"entries_per_s": n_db / t_app, "us_per_entry": 1e6 * t_app / n_db, "what": "TIRING<k>.append(pc_TIRING) from the host tensor, growth included"}
-    cur_dev = pool[3:4].contiguous()
+    cur_dev = pool[3 % n_pool:3 % n_pool + 1].contiguous()
     cur_spec = cur_dev[:, :61].contiguous()
     for name, qarg in (("query_host_tiring", cur), ("query_device_tiring", cur_dev), ("query_device_half_spectrum", cur_spec)):
         db.query(qarg, 0.48)
@@ -1355,13 +1358,15 @@ def main():
                 # within the margin of the acceptance threshold carries the owner's exact value (rescore.requested of them, in rescore.rounds
                 # fixed-size rounds that only end when every rank reports none left); the rest differ from exact by < 2e-3 < margin
                 undecided = {"replica_margin": rescorer.margin, "threshold": rescorer.threshold, "requested": rescorer.stats["requested"],
-                             "rounds": rescorer.stats["rounds"], "left_undecided": 0,
-                             "note": "the rescoring loop ends only when an all-reduce(MAX) of the per-rank remaining counts is 0"}
+                             "rounds": rescorer.stats["rounds"], "left_undecided": rescorer.stats["still_ambiguous"],
+                             "left_after_last_round_allreduce_max": rescorer.stats["left_after_last_round"],
+                             "note": "measured on the last call: left_undecided = ambiguous entries of its output that were not replaced by an owner's exact "
+                                     "score; the loop ends only when an all-reduce(MAX) of the per-rank remaining counts is 0"}
             line["exchange"] = {"design": EXCH,
                                 "process_group": {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "gpus_flag": args.gpus,
                                                   "devices_visible": torch.cuda.device_count()},
                                 "replica": (args.replica if EXCH == "allgather" else None),
-                                "decisions_on_replica_scores": (None if EXCH != "allgather" else 0),
+                                "decisions_on_replica_scores": (None if EXCH != "allgather" or rescorer is None else rescorer.stats["still_ambiguous"]),
                                 "rescore_proof": undecided,
                                 "allgather": {"format": ("exact fp32 half spectra, 58 560 B per descriptor" if REP32 else
                                                          "fp16 half spectra, 29 280 B per descriptor") + ", every descriptor to every rank",
@@ -1446,6 +1451,16 @@ def main():
                                                                  out_norm=norm_group[:ng * B]), reps=3, warm=1) / ng
             set_fused_grid(fused_grid)
             line["roofline"]["fused_grid_ms_per_launch"] = {fused_grid: kern_ms["bev_radon"], other: ms_other}
+            # the kernel's two phase floors in the same run (measurement option of the plan: the same kernel without its ray march / without its
+            # rasteriser) and how far the kernel is from a compute unit that overlapped them perfectly
+            fl = {}
+            for name, skip in (("full", 0), ("hbm_only_no_march", 2), ("march_only_no_rasteriser", 1)):
+                plan.set_option(plan.OPT_FUSED_SKIP, skip)
+                fl[name] = ev_ms(lambda: ring.ring_descriptors_fused(make_shard.whole[:ng].view(-1), group_offs[:ng * B + 1], raw=False, normalized=True,
+                                                                     out_norm=norm_group[:ng * B]), reps=3, warm=1) / ng
+            plan.set_option(plan.OPT_FUSED_SKIP, 0)
+            line["roofline"]["fused_phase_floors_ms_per_launch"] = fl
+            line["roofline"]["frac_of_max_hbm_only_march_only"] = max(fl["hbm_only_no_march"], fl["march_only_no_rasteriser"]) / fl["full"]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(host_scans(chunks[0][0], min(args.cpu_sample, B)))
     else:

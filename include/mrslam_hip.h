@@ -173,6 +173,7 @@ enum mrs_radon_option {
     MRS_RADON_OPT_FUSED_STAGGER_US = 1, /* odd workgroups start this many microseconds late (default 70, 0 = off) */
     MRS_RADON_OPT_FUSED_PREFETCH = 2,   /* 16-byte load triplets in flight per lane while rasterising: 2, 4 or 6 */
     MRS_RADON_OPT_FUSED_GRID = 3,       /* persistent workgroups (0 = one per compute unit)                      */
+    MRS_RADON_OPT_FUSED_SKIP = 5,       /* measurement aid, outputs meaningless: 1 = leave out the rasteriser, 2 = the ray march (phase floors) */
     MRS_RADON_OPT_FUSED_VARIANT = 4     /* 2 (default): rays dealt to lanes by length (slot tables), raw sums in registers, the sinogram written
                                            once; 1: the same with the raw sums parked in the output buffer; 0: (angle, detector) order */
 };

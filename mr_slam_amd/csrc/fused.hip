@@ -394,6 +394,10 @@ int mrs_radon_plan_set_option(mrs_radon_plan* plan, int32_t option, int32_t valu
             MRS_REQUIRE(value == 0 || plan->d_slot, "this plan has no slot tables");
             plan->fused_variant = value;
             return MRS_OK;
+        case MRS_RADON_OPT_FUSED_SKIP:
+            MRS_REQUIRE(value >= 0 && value <= 2, "skip must be 0 (run everything), 1 (no rasterising) or 2 (no ray march)");
+            plan->fused_skip = value;
+            return MRS_OK;
         default:
             mrs::set_error("unknown plan option %d", (int)option);
             return MRS_ERR_ARG;
@@ -457,7 +461,7 @@ int mrs_ring_descriptors_batch(mrs_radon_plan* plan, const float* d_xyz, const i
         static const bool want_prof = mrs::dev_env("MRS_FUSED_PROF") != nullptr;     // development aid: phase times on stderr (synchronises)
         static const char* const dev_skip_s = mrs::dev_env("MRS_FUSED_SKIP");
         static const int dev_skip_env = dev_skip_s ? atoi(dev_skip_s) : 0;
-        int dev_skip = dev_skip_env;
+        int dev_skip = dev_skip_env | plan->fused_skip;
         unsigned long long* d_prof = nullptr;
         if (want_prof) {
             MRS_HIP_TRY(hipMalloc(&d_prof, 4 * sizeof(unsigned long long)));

@@ -105,6 +105,21 @@ __device__ __forceinline__ float dist2(float qx, float qy, float qz, const float
     return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
 }
 
+// PLANE regularisation (the only one implemented, fast_gicp's default): C = U diag(1, 1, 1e-3) V^T = I - 0.999 n n^T with n the unit normal.
+// The library keeps n (3 doubles, 24 B per point) instead of the 6 doubles of C: every reader rebuilds C with THESE expressions (fp64,
+// no contraction: -ffp-contract=off), i.e. the very doubles the covariance kernels used to store -- half the bytes k_linearize streams and gathers.
+constexpr int kCovDoubles = 3;
+__host__ __device__ __forceinline__ void cov6_from_normal(const double* __restrict__ n, double (&c)[6])
+{
+    const double n0 = n[0], n1 = n[1], n2 = n[2];
+    c[0] = 1.0 - 0.999 * n0 * n0;
+    c[1] = -0.999 * n0 * n1;
+    c[2] = -0.999 * n0 * n2;
+    c[3] = 1.0 - 0.999 * n1 * n1;
+    c[4] = -0.999 * n1 * n2;
+    c[5] = 1.0 - 0.999 * n2 * n2;
+}
+
 // Bounding boxes of the Morton-ordered cloud at two granularities, in global memory (built once per set_clouds by k_boxes):
 //   tile t  = points [1024 t, 1024 t + 1024),  mini 64 t + m = points [1024 t + 16 m, + 16)   (slots past the cloud: empty boxes, lo = +inf, hi = -inf)
 struct Hier {
@@ -767,13 +782,8 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(KMAX
         for (int a = 0; a < 9; ++a) cv[a] /= cnt;
         double nrm[3];
         smallest_eigvec(cv, nrm);
-        double* out = cov_all + 6 * (size_t)(o + i);
-        out[0] = 1.0 - 0.999 * nrm[0] * nrm[0];
-        out[1] = -0.999 * nrm[0] * nrm[1];
-        out[2] = -0.999 * nrm[0] * nrm[2];
-        out[3] = 1.0 - 0.999 * nrm[1] * nrm[1];
-        out[4] = -0.999 * nrm[1] * nrm[2];
-        out[5] = 1.0 - 0.999 * nrm[2] * nrm[2];
+        double* out = cov_all + kCovDoubles * (size_t)(o + i);      // the unit normal: C = I - 0.999 n n^T is rebuilt by the readers (cov6_from_normal)
+        out[0] = nrm[0]; out[1] = nrm[1]; out[2] = nrm[2];
         if (knn_out) {
             const int oi = __float_as_int(q.w);
 #pragma unroll
@@ -1070,8 +1080,9 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(4, 4
             j_nx = idx_of(p + 2);
             if (j_cur >= 0) { a_nx = src[i + kNNThreads]; b_nx = tgt[j_cur]; }
             if (j < 0) continue;
-            const double* ca = src_cov + 6 * (size_t)(so + i);
-            const double* cb = tgt_cov + 6 * (size_t)(to + j);
+            double ca[6], cb[6];
+            cov6_from_normal(src_cov + kCovDoubles * (size_t)(so + i), ca);
+            cov6_from_normal(tgt_cov + kCovDoubles * (size_t)(to + j), cb);
             const double CA[9] = {ca[0], ca[1], ca[2], ca[1], ca[3], ca[4], ca[2], ca[4], ca[5]};
             double RC[9], RCR[9], M[9];
 #pragma unroll
@@ -1157,8 +1168,8 @@ __device__ __forceinline__ nnc::LeafHier cloud_hier(const HierArrays& A, int c)
 // away; if the old neighbour's new distance is below that, it is still THE nearest neighbour -- exactly, by the triangle inequality --
 // and no search is needed (k_nn_certify).  Queries that cannot be certified go to a per-pair work list and are searched as before.
 // Late iterations of an alignment move the cloud by less than the gap between a point's nearest and second nearest neighbour, so most of
-// their passes reduce to one streaming kernel.  Float evaluation error is covered by a relative 1e-5 + absolute 1e-6 m slack on both
-// sides; an exact tie (two points at one distance) leaves no gap and is always searched, so ties still resolve to the smaller index.
+// their passes reduce to one streaming kernel.  Float evaluation error is covered by a relative 1e-5 + absolute (1e-6 m + 4 ulps of the
+// largest coordinate) slack on both sides -- certificates are exact up to that evaluation error; an exact tie (two points at one distance) leaves no gap and is always searched, so ties still resolve to the smaller index.
 struct CertArrays {
     float* lb;             // [source points] lower bound described above (0: none)
     float* t_prev;         // [pairs][12] pose of the pair's last nearest-neighbour pass (float, like the searches use it)
@@ -1232,9 +1243,13 @@ __global__ __launch_bounds__(256) void k_nn_certify(const float4* __restrict__ s
             const float dy = qy - (Tp[4] * a[j].x + Tp[5] * a[j].y + Tp[6] * a[j].z + Tp[7]);
             const float dz = qz - (Tp[8] * a[j].x + Tp[9] * a[j].y + Tp[10] * a[j].z + Tp[11]);
             const float delta = sqrtf(dx * dx + dy * dy + dz * dz);
-            const float lbn = lb[j] - delta * 1.00001f - 1e-6f;
+            // slack for the float evaluation of T a on both sides of the comparison: 1e-5 relative + 1e-6 m + 4 ulps of the largest
+            // coordinate (an ulp at lidar range is 4e-6 m at 60 m: an absolute micrometre alone would rest on this kernel and the search
+            // rounding T a identically).  A certificate is exact up to that evaluation error; what fails the test is searched.
+            const float slack = 1e-6f + 4.0f * FLT_EPSILON * fmaxf(fmaxf(fabsf(qx), fabsf(qy)), fabsf(qz));
+            const float lbn = lb[j] - delta * 1.00001f - slack;
             const float d1sq = dist2(qx, qy, qz, nb[j]);
-            if (sqrtf(d1sq) * 1.00001f + 1e-6f < lbn) {       // (false for NaN)
+            if (sqrtf(d1sq) * 1.00001f + slack < lbn) {       // (false for NaN)
                 certified = true;
                 corr[so + i] = (double)d1sq < prm.max_corr2 ? seed[j] : -1;
                 C.lb[so + i] = lbn;
@@ -1487,13 +1502,8 @@ __global__ __launch_bounds__(256) void k_cov_from_knn(const float4* __restrict__
         for (int a = 0; a < 9; ++a) cv[a] /= cnt;
         double nrm[3];
         smallest_eigvec(cv, nrm);
-        double* out = cov_all + 6 * (size_t)(o + i);
-        out[0] = 1.0 - 0.999 * nrm[0] * nrm[0];
-        out[1] = -0.999 * nrm[0] * nrm[1];
-        out[2] = -0.999 * nrm[0] * nrm[2];
-        out[3] = 1.0 - 0.999 * nrm[1] * nrm[1];
-        out[4] = -0.999 * nrm[1] * nrm[2];
-        out[5] = 1.0 - 0.999 * nrm[2] * nrm[2];
+        double* out = cov_all + kCovDoubles * (size_t)(o + i);      // the unit normal: C = I - 0.999 n n^T is rebuilt by the readers (cov6_from_normal)
+        out[0] = nrm[0]; out[1] = nrm[1]; out[2] = nrm[2];
         if (knn_out) {
             const int oi = __float_as_int(pts[i].w);
             for (int s = 0; s < k; ++s) knn_out[(size_t)(o + oi) * k + s] = nb[s] >= 0 ? __float_as_int(pts[nb[s]].w) : -1;
@@ -1610,7 +1620,9 @@ __global__ void k_vox_build(const float4* __restrict__ pts, const double* __rest
         for (size_t j = i; j < n && keys[j] == k; ++j) {
             const float4 p = pts[perm[j]];
             m[0] += (double)p.x; m[1] += (double)p.y; m[2] += (double)p.z;
-            for (int a = 0; a < 6; ++a) c[a] += cov[6 * (size_t)perm[j] + a];
+            double cp[6];
+            cov6_from_normal(cov + kCovDoubles * (size_t)perm[j], cp);
+            for (int a = 0; a < 6; ++a) c[a] += cp[a];
             ++cnt;
         }
         const int v = slot[i];
@@ -1659,7 +1671,8 @@ __global__ __launch_bounds__(kNNThreads) void k_linearize_voxel(
             const int cx = voxel_coord_f(Tf[0] * a.x + Tf[1] * a.y + Tf[2] * a.z + Tf[3], resf) + 32768,
                       cy = voxel_coord_f(Tf[4] * a.x + Tf[5] * a.y + Tf[6] * a.z + Tf[7], resf) + 32768,
                       cz = voxel_coord_f(Tf[8] * a.x + Tf[9] * a.y + Tf[10] * a.z + Tf[11], resf) + 32768;
-            const double* ca = src_cov + 6 * (size_t)(so + i);
+            double ca[6];
+            cov6_from_normal(src_cov + kCovDoubles * (size_t)(so + i), ca);
             const double CA[9] = {ca[0], ca[1], ca[2], ca[1], ca[3], ca[4], ca[2], ca[4], ca[5]};
             double RC[9], RCRa[9];
 #pragma unroll
@@ -1994,7 +2007,7 @@ struct mrs_gicp_batch {
     std::vector<int64_t> offs[2];   // host copies: [0] source, [1] target
     int64_t* d_offs[2] = {nullptr, nullptr};
     float4* d_pts[2] = {nullptr, nullptr};
-    double* d_cov[2] = {nullptr, nullptr};   // sorted space
+    double* d_cov[2] = {nullptr, nullptr};   // sorted space: the unit normal of every point (kCovDoubles = 3 doubles; cov6_from_normal)
     int* d_tile_base[2] = {nullptr, nullptr};  // [n_pairs] first tile of each cloud
     float4* d_tlo[2] = {nullptr, nullptr};     // tile bounding boxes
     float4* d_thi[2] = {nullptr, nullptr};
@@ -2017,7 +2030,8 @@ struct mrs_gicp_batch {
     double* d_vcov = nullptr;
     int n_voxels = 0;
     double vox_res_built = 0.0;
-    int max_blocks = 0;
+    int max_blocks = 0;             // workgroups per pair of the reduction kernels for the CURRENT clouds (ensure_state)
+    int cap_blocks = 0;             // ... d_partial was allocated for
     int longest_src = 0;            // points in the largest source cloud (grid of the NN scan)
     double last_nn_passes = 0;
     // round-4 search structure (nn_core.hpp): octree-cell leaves of <= 16 points, tiles of 64 leaves, supers of 64 tiles, per cloud
@@ -2084,6 +2098,7 @@ void free_cloud(mrs_gicp_batch* h, int w)
 }
 
 int blocks_for_points(int n) { return (n + kNNThreads * kPts - 1) / (kNNThreads * kPts); }
+constexpr int kLinChunks = 4;     // blocks of 1024 points per workgroup of the reduction kernels (ensure_state)
 
 // Source points per lane in the NN scan.  Fewer points per wave = a more compact query set = sharper sub-tile
 // culling; more = every LDS candidate read serves more distance evaluations.  Measured (120k x 120k, MI355X):
@@ -2293,7 +2308,7 @@ static int prepare_side(mrs_gicp_batch* h, int32_t which, const int64_t* h_offse
         const int capt = tiles + tiles / 8 + 1;
         MRS_HIP_TRY(hipMalloc(&h->d_offs[which], (h->n_pairs + 1) * sizeof(int64_t)));
         MRS_HIP_TRY(hipMalloc(&h->d_pts[which], (size_t)cap * sizeof(float4)));
-        if (!h->no_cov) MRS_HIP_TRY(hipMalloc(&h->d_cov[which], (size_t)cap * 6 * sizeof(double)));
+        if (!h->no_cov) MRS_HIP_TRY(hipMalloc(&h->d_cov[which], (size_t)cap * kCovDoubles * sizeof(double)));
         MRS_HIP_TRY(hipMalloc(&h->d_tile_base[which], h->n_pairs * sizeof(int)));
         MRS_HIP_TRY(hipMalloc(&h->d_tlo[which], (size_t)capt * sizeof(float4)));
         MRS_HIP_TRY(hipMalloc(&h->d_thi[which], (size_t)capt * sizeof(float4)));
@@ -2543,7 +2558,11 @@ int mrs_gicp_batch_set_clouds_from(mrs_gicp_batch* h, int32_t which, mrs_gicp_ba
         hipLaunchKernelGGL(k_copy_segments<float4>, dim3(bx, P), dim3(256), 0, s, src, dst, (const int64_t*)table(a), scale);
     };
     copy4(store->d_pts[sw], h->d_pts[which], 0, 1);
-    copy4(reinterpret_cast<const float4*>(store->d_cov[sw]), reinterpret_cast<float4*>(h->d_cov[which]), 0, 3);      // 6 doubles = 3 x 16 bytes
+    {   // the normals: 3 doubles per point
+        const unsigned bx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((most[0] * kCovDoubles + 1023) / 1024, 256));
+        hipLaunchKernelGGL(k_copy_segments<double>, dim3(bx, P), dim3(256), 0, s, (const double*)store->d_cov[sw], h->d_cov[which], (const int64_t*)table(0),
+                           (int64_t)kCovDoubles);
+    }
     copy4(store->d_tlo[sw], h->d_tlo[which], 1, 1);
     copy4(store->d_thi[sw], h->d_thi[which], 1, 1);
     copy4(store->d_mlo[sw], h->d_mlo[which], 1, 64);
@@ -2653,20 +2672,32 @@ int mrs_gicp_batch_compute_covariances(mrs_gicp_batch* h, int32_t which, int32_t
     }
     static const char* const split_s = mrs::dev_env("MRS_KNN_SPLIT");      // development aid: 0 = selection and covariances in one kernel
     if (!(split_s && atoi(split_s) == 0)) {
+        // the neighbour indices pass from the selection to the covariance tail through scratch memory: clouds are processed in chunks so that
+        // it stays below ~512 MB (256 clouds x 120 k points x k = 15 would be 1.8 GB held by the scratch cache for the life of the process)
+        const int64_t per_cloud = std::max<int64_t>(1, longest * k * (int64_t)sizeof(int));
+        const int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(h->n_pairs, (512ll << 20) / per_cloud));
         mrs::Scratch knn;
-        int st = knn.alloc((size_t)h->offs[which][h->n_pairs] * k * sizeof(int), s);
+        int st = knn.alloc((size_t)chunk * per_cloud, s);
         if (st != MRS_OK) return st;
-        if (k <= 16)
-            hipLaunchKernelGGL((k_knn_cov<16, true>), grid, dim3(kNNThreads), 0, s, h->d_pts[which], h->d_offs[which], h->d_tile_base[which],
-                               h->d_tlo[which], h->d_thi[which], h->d_mlo[which], h->d_mhi[which], k, (double*)nullptr, knn.as<int>());
-        else if (k <= 20)
-            hipLaunchKernelGGL((k_knn_cov<20, true>), grid, dim3(kNNThreads), 0, s, h->d_pts[which], h->d_offs[which], h->d_tile_base[which],
-                               h->d_tlo[which], h->d_thi[which], h->d_mlo[which], h->d_mhi[which], k, (double*)nullptr, knn.as<int>());
-        else
-            hipLaunchKernelGGL((k_knn_cov<32, true>), grid, dim3(kNNThreads), 0, s, h->d_pts[which], h->d_offs[which], h->d_tile_base[which],
-                               h->d_tlo[which], h->d_thi[which], h->d_mlo[which], h->d_mhi[which], k, (double*)nullptr, knn.as<int>());
-        hipLaunchKernelGGL(k_cov_from_knn, dim3((unsigned)((longest + 255) / 256), h->n_pairs), dim3(256), 0, s, (const float4*)h->d_pts[which],
-                           (const int64_t*)h->d_offs[which], k, (const int*)knn.as<int>(), h->d_cov[which], d_knn_out);
+        for (int c0 = 0; c0 < h->n_pairs; c0 += chunk) {
+            const int nc = std::min(chunk, h->n_pairs - c0);
+            const dim3 g((unsigned)((longest + kNNThreads - 1) / kNNThreads), nc);
+            // the kernels index knn by GLOBAL point number: shift the chunk's buffer so that the chunk's first point lands on its start
+            int* const kn = knn.as<int>() - (size_t)h->offs[which][c0] * k;
+            const int64_t* const offs_c = h->d_offs[which] + c0;
+            const int* const tb_c = h->d_tile_base[which] + c0;
+            if (k <= 16)
+                hipLaunchKernelGGL((k_knn_cov<16, true>), g, dim3(kNNThreads), 0, s, h->d_pts[which], offs_c, tb_c,
+                                   h->d_tlo[which], h->d_thi[which], h->d_mlo[which], h->d_mhi[which], k, (double*)nullptr, kn);
+            else if (k <= 20)
+                hipLaunchKernelGGL((k_knn_cov<20, true>), g, dim3(kNNThreads), 0, s, h->d_pts[which], offs_c, tb_c,
+                                   h->d_tlo[which], h->d_thi[which], h->d_mlo[which], h->d_mhi[which], k, (double*)nullptr, kn);
+            else
+                hipLaunchKernelGGL((k_knn_cov<32, true>), g, dim3(kNNThreads), 0, s, h->d_pts[which], offs_c, tb_c,
+                                   h->d_tlo[which], h->d_thi[which], h->d_mlo[which], h->d_mhi[which], k, (double*)nullptr, kn);
+            hipLaunchKernelGGL(k_cov_from_knn, dim3((unsigned)((longest + 255) / 256), nc), dim3(256), 0, s, (const float4*)h->d_pts[which],
+                               offs_c, k, (const int*)kn, h->d_cov[which], d_knn_out);
+        }
         MRS_HIP_TRY(hipGetLastError());
         h->cov_valid[which] = true;
         if (which == 1) h->vox_res_built = 0.0;
@@ -2706,16 +2737,18 @@ int mrs_gicp_batch_get_covariances(mrs_gicp_batch* h, int32_t which, double* h_c
     MRS_HIP_TRY(hipSetDevice(h->ctx->device));
     MRS_HIP_TRY(hipDeviceSynchronize());
     const size_t total = (size_t)h->offs[which][h->n_pairs];
-    std::vector<double> sorted(total * 6);
+    std::vector<double> sorted(total * kCovDoubles);
     std::vector<float4> pts(total);
-    MRS_HIP_TRY(hipMemcpy(sorted.data(), h->d_cov[which], total * 6 * sizeof(double), hipMemcpyDeviceToHost));
+    MRS_HIP_TRY(hipMemcpy(sorted.data(), h->d_cov[which], total * kCovDoubles * sizeof(double), hipMemcpyDeviceToHost));
     MRS_HIP_TRY(hipMemcpy(pts.data(), h->d_pts[which], total * sizeof(float4), hipMemcpyDeviceToHost));
     for (int c = 0; c < h->n_pairs; ++c) {  // the library stores clouds in Morton order; .w = original index
         const int64_t o = h->offs[which][c];
         for (int64_t i = o; i < h->offs[which][c + 1]; ++i) {
             int orig;
             memcpy(&orig, &pts[i].w, sizeof(int));
-            memcpy(h_cov6 + (size_t)(o + orig) * 6, &sorted[(size_t)i * 6], 6 * sizeof(double));
+            double c6[6];
+            cov6_from_normal(&sorted[(size_t)i * kCovDoubles], c6);      // the doubles the device kernels work with
+            memcpy(h_cov6 + (size_t)(o + orig) * 6, c6, 6 * sizeof(double));
         }
     }
     return MRS_OK;
@@ -2725,18 +2758,26 @@ static int ensure_state(mrs_gicp_batch* h)
 {
     int64_t longest = 0;
     for (int i = 0; i < h->n_pairs; ++i) longest = std::max(longest, h->offs[0][i + 1] - h->offs[0][i]);
-    const int mb = blocks_for_points((int)longest);
+    // workgroups of the reduction kernels (k_linearize, k_linearize_voxel, k_fitness) per pair: every workgroup walks kLinChunks blocks of 1024
+    // points before its 28 wave reductions + LDS round (one per 1024 points, the ds_bpermute butterflies were 38 % of the LDS pipe's time and
+    // a third of the kernel's instructions: profiles/r04_pmc.json).  The partial sums are added in workgroup order (k_lm_update): a fixed order
+    // for a given cloud size, the same for every search setting.
+    static const char* const ch_s = mrs::dev_env("MRS_LIN_CHUNKS");
+    const int chunks = ch_s ? std::max(1, atoi(ch_s)) : kLinChunks;
+    const int mb = (blocks_for_points((int)longest) + chunks - 1) / chunks;
     h->longest_src = (int)longest;
     if (!h->d_state) {
         MRS_HIP_TRY(hipMalloc(&h->d_state, h->n_pairs * sizeof(LmState)));
         MRS_HIP_TRY(hipMalloc(&h->d_nblocks, h->n_pairs * sizeof(int)));
         MRS_HIP_TRY(hipMalloc(&h->d_nactive, 4 * sizeof(int)));
     }
-    if (mb > h->max_blocks) {
+    if (mb > h->cap_blocks) {
         if (h->d_partial) (void)hipFree(h->d_partial);
         MRS_HIP_TRY(hipMalloc(&h->d_partial, (size_t)h->n_pairs * mb * kTerms * sizeof(double)));
-        h->max_blocks = mb;
+        h->cap_blocks = mb;
     }
+    h->max_blocks = mb;      // grid AND row stride of d_partial: a function of the clouds at hand only (the block -> points mapping, hence the order
+                             // of the sums, must not depend on what the object held before)
     const int cb = (int)((longest + kCertBlock - 1) / kCertBlock);
     if (cb > h->cert.nb || !h->cert.bcount) {
         if (h->cert.bcount) (void)hipFree(h->cert.bcount);
@@ -2745,7 +2786,7 @@ static int ensure_state(mrs_gicp_batch* h)
         h->cert.nb = cb;
     }
     std::vector<int> nb(h->n_pairs);
-    for (int i = 0; i < h->n_pairs; ++i) nb[i] = blocks_for_points((int)(h->offs[0][i + 1] - h->offs[0][i]));
+    for (int i = 0; i < h->n_pairs; ++i) nb[i] = std::min(blocks_for_points((int)(h->offs[0][i + 1] - h->offs[0][i])), h->max_blocks);
     MRS_HIP_TRY(hipMemcpy(h->d_nblocks, nb.data(), nb.size() * sizeof(int), hipMemcpyHostToDevice));
     return MRS_OK;
 }
@@ -2913,7 +2954,7 @@ int mrs_gicp_batch_linearize(mrs_gicp_batch* h, const double* h_poses, double* h
     MRS_HIP_TRY(hipStreamSynchronize(s));
     for (int p = 0; p < h->n_pairs; ++p) {
         double sum[kTerms] = {0};
-        const int nb = blocks_for_points((int)(h->offs[0][p + 1] - h->offs[0][p]));
+        const int nb = std::min(blocks_for_points((int)(h->offs[0][p + 1] - h->offs[0][p])), h->max_blocks);
         for (int b = 0; b < nb; ++b)
             for (int t = 0; t < kTerms; ++t) sum[t] += part[((size_t)p * h->max_blocks + b) * kTerms + t];
         int t = 0;

@@ -15,6 +15,7 @@ struct mrs_radon_plan {
     int fused_stagger_us = 70;  // odd workgroups start this many microseconds late (phase-shifts the HBM-bound and the VALU-bound halves)
     int fused_prefetch = 2;     // 16-byte load triplets in flight per lane while rasterising (2 or 4)
     int fused_grid = 0;         // persistent workgroups (0 = one per compute unit)
+    int fused_skip = 0;         // measurement aid (MRS_RADON_OPT_FUSED_SKIP): 1 = the slot-table kernel without its rasteriser, 2 = without its ray march
     int fused_variant = 2;      // 2 (default): slot tables (rays sorted by orientation and length) + rolled ray loop, raw sums in registers, sinogram written once;
                                 // 1: the same with the raw sums parked in the output buffer (re-read, rewritten); 0: the table in ray order, 15 rays unrolled
     // slot tables of the two-image kernels: lane slot s = k * 1024 + lane carries ray slot_ray[s] (-1: idle).  Rays are sorted by

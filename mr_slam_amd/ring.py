@@ -50,7 +50,7 @@ class RadonPlan:
         _lib.check(_lib.load().mrs_radon_plan_degenerate_count(self._h, int(bool(reset)), C.byref(n)))
         return n.value
 
-    OPT_FUSED_STAGGER_US, OPT_FUSED_PREFETCH, OPT_FUSED_GRID, OPT_FUSED_VARIANT = 1, 2, 3, 4
+    OPT_FUSED_STAGGER_US, OPT_FUSED_PREFETCH, OPT_FUSED_GRID, OPT_FUSED_VARIANT, OPT_FUSED_SKIP = 1, 2, 3, 4, 5
 
     def set_option(self, option, value):
         """Tuning knobs of the fused descriptor kernel (mrs_radon_plan_set_option); results do not depend on them."""

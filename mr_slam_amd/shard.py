@@ -249,7 +249,9 @@ class OwnerRescorer:
 
     def __init__(self, threshold, margin=2e-3, slots=64, group=None):
         self.threshold, self.margin, self.slots, self.group = float(threshold), float(margin), int(slots), group
-        self.stats = {"calls": 0, "requested": 0, "rounds": 0, "flipped": 0}
+        # left_after_last_round: the all-reduced (MAX over ranks) count of ambiguous candidates still waiting when the last call's loop ended;
+        # still_ambiguous: entries of the last call's OUTPUT whose replica score was ambiguous and that were NOT replaced by an exact one (measured)
+        self.stats = {"calls": 0, "requested": 0, "rounds": 0, "flipped": 0, "left_after_last_round": None, "still_ambiguous": None}
 
     def ambiguous(self, dist_replica):
         return torch.nonzero((dist_replica - self.threshold).abs() < self.margin).reshape(-1)
@@ -269,6 +271,8 @@ class OwnerRescorer:
         if amb.numel() > S:                                  # the closest to the threshold first
             amb = amb[torch.argsort((dist_replica[amb] - self.threshold).abs())]
         out_d, out_a = dist_replica.clone(), angle_replica.clone()
+        replaced = torch.zeros(dist_replica.shape[0], dtype=torch.bool, device=dev)
+        all_amb = amb.clone()
         # fixed-size rounds of `slots` requests per rank until NO rank has an ambiguous candidate left: every rank issues the
         # same sequence of collectives (the number of rounds is agreed on by an all-reduce of the remaining counts)
         while True:
@@ -305,9 +309,12 @@ class OwnerRescorer:
                 self.stats["flipped"] += int(((new_d < self.threshold) != (dist_replica[take] < self.threshold)).sum())
                 out_d[take] = new_d
                 out_a[take] = ans_a[rank * S: rank * S + m]
+                replaced[take] = True
             self.stats["rounds"] = self.stats.get("rounds", 0) + 1
             if int(left.item()) == 0:
+                self.stats["left_after_last_round"] = int(left.item())
                 break
+        self.stats["still_ambiguous"] = int((~replaced[all_amb]).sum()) if all_amb.numel() else 0
         return out_d, out_a
 
 

@@ -42,7 +42,7 @@ src = os.path.join(root, "gpurun_out", tag)
 KEYS = {"k_cart_lds": "k_cart_lds", "k_polar_lds": "k_polar_lds", "k_radon2": "k_radon2", "k_bev_radon2": "k_bev_radon2", "k_bev_radon3": "k_bev_radon3",
         "k_ring_spec_corr_pairs": "k_ring_spec_corr_pairs", "k_ring_corr_fft": "k_ring_corr_fft", "k_linearize": "k_linearize", "k_nn_scan": "k_nn_scan",
         "k_knn_cov": "k_knn_cov", "k_knn_features": "k_knn_features", "k_nn_scan_g": "k_nn_scan_g", "k_nn_certify": "k_nn_certify",
-        "k_cov_from_knn": "k_cov_from_knn", "k_knn_select": "k_knn_select", "k_feat_from_knn": "k_feat_from_knn"}
+        "k_cov_from_knn": "k_cov_from_knn", "k_knn_select": "k_knn_select", "k_feat_from_knn": "k_feat_from_knn", "k_ring_sweep_dma": "k_ring_sweep_dma"}
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 files = newest(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))) + sorted(glob.glob(os.path.join(src, "pmc_*.csv")))   # raw passes or slimmed ones
 for f in files:
@@ -53,6 +53,11 @@ for f in files:
         k = m.group(1)
         if k == "k_ring_corr_fft":
             k += "@grid%s" % r["Grid_Size"]
+        if k == "k_ring_sweep_dma":                # row layout / DMA-tiled / multi-channel are different instantiations: <WAVES, SPLIT, NT, RING, QDMA, TILED, PRIO, MC, PF>
+            t = re.search(r"k_ring_sweep_dma<([^>]*)>", r["Kernel_Name"])
+            a = [x.strip() for x in t.group(1).split(",")] if t else []
+            if len(a) >= 8:
+                k += "<%s%s>" % ("tiled" if a[5] in ("true", "1") else "rows", ", 6 channels" if a[7] in ("true", "1") else "")
         if k == "k_knn_cov":                       # k = 15 covariances (16 slots) and the k = 30 point-feature selection (32 slots) are different kernels
             t = re.search(r"k_knn_cov<\s*(\d+)", r["Kernel_Name"])
             if t:

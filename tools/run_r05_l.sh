@@ -1,0 +1,7 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/r05
+mkdir -p $OUT
+cd $R
+timeout 1200 python -m pytest tests -m gpu -q > $OUT/gpu_tests.txt 2>&1; echo "pytest rc $?" >> $OUT/gpu_tests.txt; tail -n 6 $OUT/gpu_tests.txt | cut -c1-200
+bash tools/run_profiles.sh r05 > $OUT/run_profiles.log 2>&1; tail -n 30 $OUT/run_profiles.log | cut -c1-300
