@@ -328,7 +328,8 @@ double mrs_gicp_batch_last_nn_passes(const mrs_gicp_batch* h);
  * `stream`, `reps` times, at the given poses (double[n_pairs][16]).  out_ms float[8]: 0 k_linearize (28 sums), 1 k_linearize (error only:
  * an LM trial), 2 round-3 search of every point (warm), 3 k_nn_certify at an unchanged pose, 4 round-4 search of every point (warm),
  * 5 k-NN selection of the sources, 6 k_cov_from_knn of the sources, 7 certify + work-list search after a 1 mm step.  out_counts int64[3]:
- * source points, correspondences at the poses, queries on the work lists of [7].  Leaves the batch's settings unchanged. */
+ * source points, correspondences at the poses, queries on the work lists of [7].  The batch's search settings are restored on every way out
+ * (errors included); its correspondences, warm-start seeds and certificates are OVERWRITTEN (they are those of the profiled poses afterwards). */
 int mrs_gicp_batch_profile(mrs_gicp_batch* h, const double* h_poses, int32_t reps, float* out_ms, int64_t* out_counts, mrs_stream stream);
 
 /* Which exact nearest-neighbour searches the batch uses for G2 / G3 (no reference counterpart: upstream fast_gicp searches a
@@ -422,7 +423,8 @@ int mrs_ring_corr_fft_pairs(mrs_ctx* ctx, const float* d_a_spec, const float* d_
                             float* d_dist, int32_t* d_angle, float* d_corr, mrs_stream stream);
 /* Several sweeps in one launch (the loop of main_RING.py:133-140 for a batch of new scans, each against ITS OWN slice of one descriptor
  * pool): query q is entry d_query_row[q] of d_spec ([entries][61][120] complex64) and sweeps the n_db entries that start at entry
- * d_db_first[q] (device int64 arrays, n_query <= 65535); d_dist / d_angle [n_query][n_db] as in mrs_ring_corr_fft_sweep. */
+ * d_db_first[q] (device int64 arrays, n_query <= 65535); d_dist / d_angle [n_query][n_db] as in mrs_ring_corr_fft_sweep.
+ * PRECONDITION (not checked: the indices live on the device): every d_query_row[q] and every d_db_first[q] + n_db - 1 is an entry of d_spec. */
 int mrs_ring_corr_fft_sweep_blocks(mrs_ctx* ctx, const float* d_spec, const int64_t* d_query_row, int32_t n_query, const int64_t* d_db_first,
                                    int32_t n_db, float* d_dist, int32_t* d_angle, mrs_stream stream);
 

@@ -2316,7 +2316,7 @@ static int prepare_side(mrs_gicp_batch* h, int32_t which, const int64_t* h_offse
         MRS_HIP_TRY(hipMalloc(&h->d_mhi[which], (size_t)capt * 64 * sizeof(float4)));
         MRS_HIP_TRY(hipMalloc(&h->d_bbox[which], (size_t)h->n_pairs * 6 * sizeof(int)));
         h->cap_points[which] = cap; h->cap_tiles[which] = capt;
-        if (which == 0) {
+        if (which == 0 && !h->no_cov) {       // correspondences, seeds and certificates belong to alignments: the RING++ front end's containers (no_cov) never read them
             if (h->d_corr) (void)hipFree(h->d_corr);
             if (h->d_seed) (void)hipFree(h->d_seed);
             h->d_corr = nullptr; h->d_seed = nullptr;
@@ -2999,8 +2999,17 @@ int mrs_gicp_batch_profile(mrs_gicp_batch* h, const double* h_poses, int32_t rep
         MRS_HIP_TRY(hipStreamSynchronize(s));
         return MRS_OK;
     };
-    hipEvent_t e0, e1;
-    MRS_HIP_TRY(hipEventCreate(&e0)); MRS_HIP_TRY(hipEventCreate(&e1));
+    // everything this function borrows goes back on EVERY way out (the MRS_HIP_TRY returns included): the two events and the search settings
+    struct Guard {
+        mrs_gicp_batch* h; int core, cold; bool cert; hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Guard() {
+            h->search_core = core; h->cold_core = cold; h->use_certificates = cert;
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } guard{h, h->search_core, h->cold_core, h->use_certificates};
+    MRS_HIP_TRY(hipEventCreate(&guard.e0)); MRS_HIP_TRY(hipEventCreate(&guard.e1));
+    const hipEvent_t e0 = guard.e0, e1 = guard.e1;
     auto timed = [&](float& ms, auto&& launch) -> int {
         launch();                                     // warm
         MRS_HIP_TRY(hipEventRecord(e0, s));
@@ -3013,10 +3022,7 @@ int mrs_gicp_batch_profile(mrs_gicp_batch* h, const double* h_poses, int32_t rep
         return MRS_OK;
     };
     const dim3 lin_grid(h->max_blocks, P), wg((unsigned)((h->longest_src + kCertBlock - 1) / kCertBlock), P);
-    const int saved_core = h->search_core, saved_cold = h->cold_core;
-    const bool saved_cert = h->use_certificates;
-    h->search_core = 1; h->cold_core = 0; h->use_certificates = true;
-    auto restore = [&]() { h->search_core = saved_core; h->cold_core = saved_cold; h->use_certificates = saved_cert; };
+    h->search_core = 1; h->cold_core = 0; h->use_certificates = true;      // restored by `guard`
     auto round3 = [&]() {
         launch_nn_scan(h->longest_src, P, h->ctx->num_cu, s, h->d_pts[0], h->d_offs[0], h->d_pts[1], h->d_offs[1], h->d_tile_base[1], h->d_tlo[1],
                        h->d_thi[1], h->d_mlo[1], h->d_mhi[1], h->d_state, h->prm, h->d_corr, h->d_seed, (const int*)h->d_bbox[1], (float*)nullptr, 0);
@@ -3039,7 +3045,7 @@ int mrs_gicp_batch_profile(mrs_gicp_batch* h, const double* h_poses, int32_t rep
         hipLaunchKernelGGL(k_nn_store_pose, dim3((P + 255) / 256), dim3(256), 0, s, (const LmState*)h->d_state, P, h->cert, 0, (const int64_t*)h->d_offs[0],
                            h->prm.motion_switch);
     };
-    auto fail = [&](int code) { restore(); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return code; };
+    auto fail = [&](int code) { return code; };      // `guard` cleans up
     if ((st = upload(0, 0.0)) != MRS_OK) return fail(st);
     round3();                                         // seeds + correspondences at the poses
     if ((st = timed(out_ms[2], round3)) != MRS_OK) return fail(st);
@@ -3115,9 +3121,7 @@ int mrs_gicp_batch_profile(mrs_gicp_batch* h, const double* h_poses, int32_t rep
              })) != MRS_OK) return fail(st);
         MRS_HIP_TRY(hipStreamSynchronize(s));
     }
-    restore();
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    return MRS_OK;
+    return MRS_OK;       // `guard` restores the search settings and destroys the events
 }
 
 int mrs_gicp_batch_fitness(mrs_gicp_batch* h, const double* h_poses, double max_range, double* h_scores,

@@ -164,6 +164,7 @@ struct mrs_loopdb {
     unsigned long long* d_best = nullptr;     // DiSCO: packed (distance bits, index)
     int32_t* d_small = nullptr;               // DiSCO: index, distance bits, argmax
     int32_t* h_small = nullptr;               // pinned
+    bool phase_attr_set = false;              // DiSCO: the phase kernel's LDS attribute has been set on this handle's device
     Pinned stage[kStageSlots];
     int stage_next = 0;
     size_t stage_bytes = 0;
@@ -481,7 +482,10 @@ int mrs_loopdb_query_disco(mrs_loopdb* db, const float* signature, const float* 
     const int blocks = std::max(1, std::min((n + 3) / 4, 4 * (db->ctx->num_cu > 0 ? db->ctx->num_cu : 256)));
     hipLaunchKernelGGL(k_sig_nearest, dim3(blocks), dim3(256), 0, db->s, sig, db->d_sigs, n, db->sig_dim, db->d_best);
     const size_t lds = (size_t)(2 * db->R * db->S + db->S + db->R) * sizeof(float2);
-    MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_disco_phase_one), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (!db->phase_attr_set) {
+        MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_disco_phase_one), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        db->phase_attr_set = true;
+    }
     hipLaunchKernelGGL(k_disco_phase_one, dim3(1), dim3(kPhaseThreads), lds, db->s, reinterpret_cast<const float2*>(db->d_entries), db->d_best,
                        reinterpret_cast<const float2*>(spec), reinterpret_cast<const float2*>(db->d_tw), db->d_small,
                        reinterpret_cast<float*>(db->d_small + 1), db->d_small + 2);

@@ -15,6 +15,7 @@
 // (L2 shares it between the query rows) and the in-register FFT (VALU) binds at 115-135 M pairs/s.  RING++ descriptors
 // ([C][61][120]) are swept channel-outer (k_ring_sweep_mc); fp16 replicas of the database are accepted as well.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
@@ -950,8 +951,15 @@ static hipError_t sweep_dma_launch_t(int num_cu, hipStream_t s, const float2* q,
     const size_t lds = (size_t)WAVES * kRing * kSlotBytes + (size_t)(kHalf * kD + 8) * sizeof(v2f) +
                        (SPLIT ? (size_t)(WAVES / 2) * 2 * 64 * sizeof(v2f) + (WAVES / 2) * 2 * sizeof(unsigned) : 0);
     auto kern = k_ring_sweep_dma<WAVES, SPLIT, NT, kRing, true, TILED, PRIO, MC>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static std::atomic<unsigned> attr_set{0};          // per instantiation, one bit per device: the attribute call costs microseconds of a 100-us query
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
+    if (!(attr_set.load(std::memory_order_relaxed) & (1u << (dev & 31)))) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set.fetch_or(1u << (dev & 31), std::memory_order_relaxed);
+    }
     const int per_wg = SPLIT ? WAVES / 2 : WAVES;
     int blocks = std::max(1, std::min(num_cu, (p.ndb + per_wg - 1) / per_wg));
     if (MC) blocks = std::max(p.channels, std::min(num_cu, p.channels * ((p.ndb + per_wg - 1) / per_wg)));   // every channel needs a workgroup

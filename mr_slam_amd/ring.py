@@ -482,10 +482,15 @@ def corr_sweep_fft_tiled(query_spec, tiled, n_db=None):
     return dist, ang
 
 
-def corr_sweep_fft_blocks(spec_pool, query_rows, db_first, n_db, out=None):
+def corr_sweep_fft_blocks(spec_pool, query_rows, db_first, n_db, out=None, check=False):
     """Several C1 sweeps in one launch: query q = entry query_rows[q] of spec_pool ([E,61,120] complex64) against the n_db entries that start
-    at entry db_first[q] (int64 device tensors).  Returns (dist [Q,n_db], angle [Q,n_db]); bit-identical to corr_sweep_fft per query."""
+    at entry db_first[q] (int64 device tensors).  Returns (dist [Q,n_db], angle [Q,n_db]); bit-identical to corr_sweep_fft per query.
+    The kernel trusts the indices (they live on the device): check=True verifies them against the pool first (one host synchronisation)."""
     d = _dev(spec_pool)
+    if check:
+        E = spec_pool.shape[0]
+        assert int(query_rows.min()) >= 0 and int(query_rows.max()) < E and int(db_first.min()) >= 0 and int(db_first.max()) + int(n_db) <= E, \
+            "query row or database block outside the pool"
     assert spec_pool.dtype == torch.complex64 and spec_pool.is_contiguous() and spec_pool.shape[1:] == (61, 120)
     qr, df = query_rows.contiguous(), db_first.contiguous()
     assert qr.dtype == torch.int64 and df.dtype == torch.int64 and qr.numel() == df.numel()

@@ -51,6 +51,14 @@ def test_bench_line_contract():
     for leg in ("roofline_polar", "roofline_radon", "sweeps", "pipeline_shard", "dropin_latency"):
         assert leg in d, leg
     assert d["roofline_polar"]["bound"] == "hbm" and d["sweeps"]["ring_q1"]["pairs_per_s"] > 0 and d["sweeps"]["disco_q4"]["queries_per_s"] > 0
+    # round 5: the one-query sweeps on the database's resident (DMA-tiled) format next to the row layout; the node's shape; GICP protocols
+    for k in ("ring_q1", "ring_q1_row_layout", "ringpp_q1", "ringpp_q1_row_layout", "disco_q1"):
+        assert d["sweeps"][k]["pairs_per_s"] > 0, k
+    ns = d["node_shape"]
+    assert ns["matches_pairwise"] is True and ns["twin_pairs_per_s"] > 20 * ns["reference_loop_through_dropin"]["pairs_per_s"] and ns["append"]["entries_per_s"] > 0
+    assert d["gicp"]["warm"]["iters_per_s"] > 0 and "cold start" in d["gicp"]["protocol"] and d["gicp"]["shared_submaps"]["pairs_per_s_incl_covariances"] > 0
+    assert r["gicp_iters_per_s_warm"] == d["gicp"]["warm"]["iters_per_s"] and r["gicp_pairs_per_s_incl_covariances_shared_submaps"] > 0
+    assert 0 < r["frac_of_max_hbm_only_march_only"] and set(r["fused_phase_floors_ms_per_launch"]) == {"full", "hbm_only_no_march", "march_only_no_rasteriser"}
     # default step: BEV + Radon + normalisation of a group of launches in one kernel; the rasteriser's own roofline rides along
     assert d["config"]["fused_launches"] == 3 and "k_bev_radon3" in r["kernel"] and d["kernel_ms"]["bev_radon"] > 0
     assert set(r["fused_grid_ms_per_launch"]) == {"persistent", "per_pair"} and r["valu_roofline"] is None or r["valu_roofline"]["floor_ms_bounds"][0] > 0

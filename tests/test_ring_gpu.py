@@ -508,7 +508,7 @@ def test_blocked_sweeps_equal_single_sweeps_bit_for_bit(dev):
     pool = ring.half_spectrum(ring.normalize(sino[:, None])[:, 0]).contiguous()
     qrow = torch.tensor([5, 2999, 100, 100, 1234, 0, 2300], dtype=torch.int64, device=dev)
     first = torch.tensor([0, 2300, 50, 0, 1234, 2300, 1600], dtype=torch.int64, device=dev)
-    d, a = ring.corr_sweep_fft_blocks(pool, qrow, first, n_db)
+    d, a = ring.corr_sweep_fft_blocks(pool, qrow, first, n_db, check=True)
     assert d.shape == (7, n_db)
     for i in range(qrow.numel()):
         wd, wa = ring.corr_sweep_fft(pool[int(qrow[i]):int(qrow[i]) + 1], pool[int(first[i]):int(first[i]) + n_db])
