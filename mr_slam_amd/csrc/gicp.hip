@@ -1041,7 +1041,10 @@ __global__ __launch_bounds__(kNNThreads) void k_nn_scan(
 // Two poses: the Mahalanobis matrices belong to the linearisation pose S.x (upstream caches them in
 // update_correspondences), the residuals to the evaluated pose S.xi.  Phase 0: xi == x, all 28 sums
 // (FastGICP::linearize); phase 1: only the error sum (FastGICP::compute_error of an LM trial).
-__global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_linearize(
+// WAVES: waves per SIMD the register budget is cut for; PREN: the normals of the lane's NEXT point (own 24 B streamed, neighbour's 24 B gathered)
+// travel one point ahead like the points themselves, instead of being requested where the algebra needs them
+template <int WAVES, bool PREN>
+__global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_linearize(
     const float4* __restrict__ src_all, const int64_t* __restrict__ src_offs, const double* __restrict__ src_cov,
     const float4* __restrict__ tgt_all, const int64_t* __restrict__ tgt_offs, const double* __restrict__ tgt_cov,
     const LmState* __restrict__ st, const int* __restrict__ corr, double* __restrict__ partial, int max_blocks)
@@ -1070,19 +1073,33 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(4, 4
         auto idx_of = [&](int p) { const int i = base + p * kNNThreads + (int)threadIdx.x; return (p < kPts && i < n) ? corr[so + i] : -1; };
         int j_cur = idx_of(0), j_nx = idx_of(1);
         float4 a_nx = make_float4(0.f, 0.f, 0.f, 0.f), b_nx = a_nx;
-        if (j_cur >= 0) { a_nx = src[base + threadIdx.x]; b_nx = tgt[j_cur]; }
+        double na_nx[3] = {0.0, 0.0, 0.0}, nb_nx[3] = {0.0, 0.0, 0.0};
+        auto fetch_normals = [&](int i_next, int j_next) {
+            const double* pa = src_cov + kCovDoubles * (size_t)(so + i_next);
+            const double* pb = tgt_cov + kCovDoubles * (size_t)(to + j_next);
+            na_nx[0] = pa[0]; na_nx[1] = pa[1]; na_nx[2] = pa[2];
+            nb_nx[0] = pb[0]; nb_nx[1] = pb[1]; nb_nx[2] = pb[2];
+        };
+        if (j_cur >= 0) {
+            a_nx = src[base + threadIdx.x]; b_nx = tgt[j_cur];
+            if (PREN) fetch_normals(base + (int)threadIdx.x, j_cur);
+        }
 #pragma unroll 1
         for (int p = 0; p < kPts; ++p) {
             const int i = base + p * kNNThreads + threadIdx.x;
             const int j = j_cur;
             const float4 a = a_nx, bb = b_nx;
+            const double na[3] = {na_nx[0], na_nx[1], na_nx[2]}, nbv[3] = {nb_nx[0], nb_nx[1], nb_nx[2]};
             j_cur = j_nx;
             j_nx = idx_of(p + 2);
-            if (j_cur >= 0) { a_nx = src[i + kNNThreads]; b_nx = tgt[j_cur]; }
+            if (j_cur >= 0) {
+                a_nx = src[i + kNNThreads]; b_nx = tgt[j_cur];
+                if (PREN) fetch_normals(i + kNNThreads, j_cur);
+            }
             if (j < 0) continue;
             double ca[6], cb[6];
-            cov6_from_normal(src_cov + kCovDoubles * (size_t)(so + i), ca);
-            cov6_from_normal(tgt_cov + kCovDoubles * (size_t)(to + j), cb);
+            cov6_from_normal(PREN ? na : src_cov + kCovDoubles * (size_t)(so + i), ca);
+            cov6_from_normal(PREN ? nbv : tgt_cov + kCovDoubles * (size_t)(to + j), cb);
             const double CA[9] = {ca[0], ca[1], ca[2], ca[1], ca[3], ca[4], ca[2], ca[4], ca[5]};
             double RC[9], RCR[9], M[9];
 #pragma unroll
@@ -2098,7 +2115,8 @@ void free_cloud(mrs_gicp_batch* h, int w)
 }
 
 int blocks_for_points(int n) { return (n + kNNThreads * kPts - 1) / (kNNThreads * kPts); }
-constexpr int kLinChunks = 4;     // blocks of 1024 points per workgroup of the reduction kernels (ensure_state)
+constexpr int kLinChunks = 4;
+constexpr int kLinVariant = 3;    // launch_linearize     // blocks of 1024 points per workgroup of the reduction kernels (ensure_state)
 
 // Source points per lane in the NN scan.  Fewer points per wave = a more compact query set = sharper sub-tile
 // culling; more = every LDS candidate read serves more distance evaluations.  Measured (120k x 120k, MI355X):
@@ -2115,6 +2133,20 @@ void launch_nn_scan(int longest_src, int n_pairs, int num_cu, hipStream_t s, Arg
         hipLaunchKernelGGL(k_nn_scan<2>, dim3((unsigned)(wgs(2) / n_pairs), n_pairs), dim3(kNNThreads), 0, s, args...);
     else
         hipLaunchKernelGGL(k_nn_scan<1>, dim3((unsigned)(wgs(1) / n_pairs), n_pairs), dim3(kNNThreads), 0, s, args...);
+}
+
+// k_linearize instantiation: 3 (default) = 3 waves per SIMD (142 registers, no spills), normals one point ahead: 0.55 ms per 256 pairs; 1 = 4 waves
+// (128 registers, 3 spilled), normals requested at use: 0.69 ms; 2 = 4 waves + look-ahead (26 spills): 0.95 ms; 4 = 3 waves, no look-ahead: 0.58 ms; 5 = 2 waves.  MRS_DEV=1 MRS_LIN_VARIANT=<n> switches for A/B runs (same sums, same bits).
+template <class... Args>
+void launch_linearize(dim3 grid, hipStream_t s, Args... args)
+{
+    static const char* const v_s = mrs::dev_env("MRS_LIN_VARIANT");
+    static const int v = v_s ? atoi(v_s) : kLinVariant;
+    if (v == 2) hipLaunchKernelGGL((k_linearize<4, true>), grid, dim3(kNNThreads), 0, s, args...);
+    else if (v == 3) hipLaunchKernelGGL((k_linearize<3, true>), grid, dim3(kNNThreads), 0, s, args...);
+    else if (v == 4) hipLaunchKernelGGL((k_linearize<3, false>), grid, dim3(kNNThreads), 0, s, args...);
+    else if (v == 5) hipLaunchKernelGGL((k_linearize<2, true>), grid, dim3(kNNThreads), 0, s, args...);
+    else hipLaunchKernelGGL((k_linearize<4, false>), grid, dim3(kNNThreads), 0, s, args...);
 }
 
 // Octree-cell leaves + tiles + supers of every cloud of side `w` from the sorted keys (set_clouds).  Synchronises (the leaf counts size the arrays).
@@ -2882,7 +2914,7 @@ int mrs_gicp_batch_align(mrs_gicp_batch* h, const double* h_guess, double* h_fin
                 h->big_movers = next[2];
                 if ((st = nn_pass(h, nn_ticks == 0 ? 0 : 1, s)) != MRS_OK) return st;
             }
-            hipLaunchKernelGGL(k_linearize, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_cov[0],
+            launch_linearize(grid, s, h->d_pts[0], h->d_offs[0], h->d_cov[0],
                                h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->d_corr, h->d_partial, h->max_blocks);
         }
         if (next[0] > 0) ++nn_ticks;
@@ -2941,7 +2973,7 @@ int mrs_gicp_batch_linearize(mrs_gicp_batch* h, const double* h_poses, double* h
                            h->max_blocks);
     } else {
         if ((st = nn_pass(h, 2, s)) != MRS_OK) return st;
-        hipLaunchKernelGGL(k_linearize, dim3(h->max_blocks, h->n_pairs), dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0],
+        launch_linearize(dim3(h->max_blocks, h->n_pairs), s, h->d_pts[0], h->d_offs[0],
                            h->d_cov[0], h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->d_corr, h->d_partial,
                            h->max_blocks);
     }
@@ -3050,7 +3082,7 @@ int mrs_gicp_batch_profile(mrs_gicp_batch* h, const double* h_poses, int32_t rep
     round3();                                         // seeds + correspondences at the poses
     if ((st = timed(out_ms[2], round3)) != MRS_OK) return fail(st);
     if ((st = timed(out_ms[0], [&]() {
-             hipLaunchKernelGGL(k_linearize, lin_grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_cov[0], h->d_pts[1], h->d_offs[1], h->d_cov[1],
+             launch_linearize(lin_grid, s, h->d_pts[0], h->d_offs[0], h->d_cov[0], h->d_pts[1], h->d_offs[1], h->d_cov[1],
                                 h->d_state, h->d_corr, h->d_partial, h->max_blocks);
          })) != MRS_OK) return fail(st);
     {   // correspondences at the poses
@@ -3065,7 +3097,7 @@ int mrs_gicp_batch_profile(mrs_gicp_batch* h, const double* h_poses, int32_t rep
     if ((st = timed(out_ms[3], certify)) != MRS_OK) return fail(st);
     if ((st = upload(1, 0.0)) != MRS_OK) return fail(st);
     if ((st = timed(out_ms[1], [&]() {
-             hipLaunchKernelGGL(k_linearize, lin_grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_cov[0], h->d_pts[1], h->d_offs[1], h->d_cov[1],
+             launch_linearize(lin_grid, s, h->d_pts[0], h->d_offs[0], h->d_cov[0], h->d_pts[1], h->d_offs[1], h->d_cov[1],
                                 h->d_state, h->d_corr, h->d_partial, h->max_blocks);
          })) != MRS_OK) return fail(st);
     // a pass after a 1 mm step: certify + search the work lists (the certificates are those of the unmoved poses: t_prev stays)

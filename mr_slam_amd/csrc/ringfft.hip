@@ -501,7 +501,7 @@ struct DmaUnit {            // one (candidate, half) as the DMA sees it; wave-un
     bool live;              // false: past the end of this wave's work (fillers only)
 };
 
-template <int WAVES, bool SPLIT, int NT, int RING = kRing, bool QDMA = true, bool TILED = false, bool PRIO = false, bool MC = false, int PF = 2>
+template <int WAVES, bool SPLIT, int NT, int RING = kRing, bool QDMA = true, bool TILED = false, bool PRIO = false, bool MC = false, int PF = 2>   // (!SPLIT: candidates are handed out by a per-workgroup LDS ticket)
 __global__ __launch_bounds__(WAVES * 64) void k_ring_sweep_dma(const float2* __restrict__ Q, const float2* __restrict__ DB, FftCorrP p,
                                                                float* __restrict__ dist, int* __restrict__ angle)
 {
@@ -532,6 +532,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_sweep_dma(const float2* __r
     const int c0 = SPLIT ? slice * (WAVES / 2) + (wave >> 1) : slice * WAVES + wave;
     const int cstride = nslices * (SPLIT ? WAVES / 2 : WAVES);
     const int my_half = SPLIT ? (wave & 1) : 0;
+    // !SPLIT: the workgroup's candidates are the sequence t = 0, 1, 2 ... -> slice * WAVES + t % WAVES + (t / WAVES) * cstride; wave w starts with
+    // t = w and draws every further one from a ticket in LDS (a wave that finishes early takes what is left: no wave idles through a last round
+    // that only some of them have a candidate for).  Which wave scores a candidate does not touch its result.
+    unsigned* const ticket = reinterpret_cast<unsigned*>(qs + kQueryVals);       // first word behind the query (the SPLIT form's partial sums live there)
+    auto cand_of = [&](unsigned t) { return slice * WAVES + (int)(t % WAVES) + (int)(t / WAVES) * cstride; };
 
     // per-lane pieces of a DMA: lanes 0-31 row J, lanes 32-63 row 60 - J; 16 B = 2 columns per lane.
     // Row layout ([61][120]): the two rows are 960 (60 - 2 J) bytes apart and a half-row starts on a 64-byte boundary.
@@ -581,6 +586,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_sweep_dma(const float2* __r
     if (QDMA) {
         wait_vmcnt<RING>();
         if (SPLIT && threadIdx.x < (WAVES / 2) * 2) counters[threadIdx.x] = 0;
+        if (!SPLIT && threadIdx.x == 0) *ticket = WAVES;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     } else {   // query -> LDS through registers (compact rows), zero tail; counters
         for (int i = threadIdx.x; i < kQueryVals; i += WAVES * 64) {
@@ -589,6 +595,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_sweep_dma(const float2* __r
             qs[i] = v;
         }
         if (SPLIT && threadIdx.x < (WAVES / 2) * 2) counters[threadIdx.x] = 0;
+        if (!SPLIT && threadIdx.x == 0) *ticket = WAVES;
         __syncthreads();
     }
 
@@ -598,8 +605,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_sweep_dma(const float2* __r
     float accA0 = 0.0f, accA1 = 0.0f;                    // !SPLIT: sums of half 0 while half 1 runs
     while (cur.live) {
         DmaUnit nxt;
-        if (SPLIT) nxt = unit_of(c + cstride, my_half);
-        else nxt = cur.half == 0 ? unit_of(c, 1) : unit_of(c + cstride, 0);
+        int c_next = c + cstride;
+        if (SPLIT) nxt = unit_of(c_next, my_half);
+        else if (cur.half == 0) nxt = unit_of(c, 1);
+        else {                                           // the candidate after this one: drawn now, its first elements are requested at the end of this unit
+            unsigned t = 0;
+            if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            c_next = cand_of(__builtin_amdgcn_readfirstlane(t));
+            nxt = unit_of(c_next, 0);
+        }
         const int h = cur.half;
         const v2f* const qcol = qs + h * 64 + lane;
         const float m = (h == 1 && piece >= 24) ? 0.0f : 1.0f;
@@ -647,14 +661,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_sweep_dma(const float2* __r
         if (MC) {
             static_assert(!MC || !SPLIT, "the multi-channel form keeps both halves of a candidate on one wave");
             p.mc_partial[((size_t)ch * p.ndb + c) * 128 + h * 64 + lane] = make_float2(w0, w1);
-            if (h == 1) c += cstride;
+            if (h == 1) c = c_next;
         } else if (!SPLIT) {
             if (h == 0) { accA0 = w0; accA1 = w1; }
             else {
                 const float s0 = (accA0 + w0) * kOrtho120, s1 = (accA1 + w1) * kOrtho120;
                 const size_t o = (size_t)blockIdx.y * p.ndb + c;
                 sweep_epilogue(s0, s1, lane, p.denom, dist + o, angle + o);
-                c += cstride;
+                c = c_next;
             }
         } else {
             const int pi = wave >> 1;
@@ -949,7 +963,7 @@ template <int WAVES, bool SPLIT, int NT, bool TILED, bool PRIO, bool MC = false>
 static hipError_t sweep_dma_launch_t(int num_cu, hipStream_t s, const float2* q, const float2* db, const FftCorrP& p, float* dist, int* angle)
 {
     const size_t lds = (size_t)WAVES * kRing * kSlotBytes + (size_t)(kHalf * kD + 8) * sizeof(v2f) +
-                       (SPLIT ? (size_t)(WAVES / 2) * 2 * 64 * sizeof(v2f) + (WAVES / 2) * 2 * sizeof(unsigned) : 0);
+                       (SPLIT ? (size_t)(WAVES / 2) * 2 * 64 * sizeof(v2f) + (WAVES / 2) * 2 * sizeof(unsigned) : 16 /* the ticket */);
     auto kern = k_ring_sweep_dma<WAVES, SPLIT, NT, kRing, true, TILED, PRIO, MC>;
     static std::atomic<unsigned> attr_set{0};          // per instantiation, one bit per device: the attribute call costs microseconds of a 100-us query
     int dev = 0;
