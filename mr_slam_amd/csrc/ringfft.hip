@@ -10,10 +10,12 @@
 // across lanes), forms the conjugate product, and runs a 120-point real inverse transform entirely in
 // registers (half-length trick + generated straight-line complex FFT-60, csrc/fft_codelets.hpp).
 // The 120 |corr| values per lane are summed across the 120 lanes with a wave reduce-scatter.
-// 58.56 KB and ~1 400 packed / scalar VALU instructions per 120-lane column pass: with one query the sweep runs at the
-// device's copy rate (81 M pairs/s = 4.8 TB/s, profiles/r02_*); with several queries per launch the database is fetched once
-// (L2 shares it between the query rows) and the in-register FFT (VALU) binds at 115-135 M pairs/s.  RING++ descriptors
-// ([C][61][120]) are swept channel-outer (k_ring_sweep_mc); fp16 replicas of the database are accepted as well.
+// 58.56 KB and ~1 400 packed / scalar VALU instructions per 120-lane column pass.  With several queries per launch the database is fetched
+// once (L2 shares it between the query rows) and the in-register FFT (VALU) binds at 115-135 M pairs/s (k_ring_corr_fft: the candidate's column
+// in registers).  With ONE query -- the node's loop, main_RING.py:133 -- the sweep is a stream of the database and runs as an LDS-DMA pipeline per
+// wave (k_ring_sweep_dma, round 5: `global_load_lds_dwordx4` into a private ring of LDS slots, DMA-tiled entries): 98-105 M pairs/s = 0.72-0.77
+// of the HBM peak (0.60 with the column in registers); RING++ descriptors ([C][61][120]) one channel per workgroup (16-17 M pairs/s = 0.72-0.74;
+// k_ring_sweep_mc, channel-outer, for several queries).  fp16 replicas of the database are accepted as well.
 #include <algorithm>
 #include <atomic>
 #include <cmath>
