@@ -132,6 +132,30 @@ def load_pmc():
 
 
 # --------------------------------------------------------------------------------------------------- CPU baseline
+def cpu_budget():
+    """(hardware threads the OS reports, cores' worth of CPU time the container may use, where that limit comes from).  On the GPU boxes `nproc`
+    says 256 while the cgroup grants 16 cores of time (cpu.max = "1600000 100000"): threads beyond the quota are throttled, not run."""
+    nproc = os.cpu_count() or 1
+    try:
+        nproc = min(nproc, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota, src = float(nproc), "no cgroup CPU quota found"
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota, src = float(q) / float(per), f"cgroup v2 cpu.max = {q} {per}"
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota, src = q / per, f"cgroup v1 cfs_quota_us / cfs_period_us = {q} / {per}"
+        except (OSError, ValueError):
+            pass
+    return nproc, max(1, int(min(nproc, quota))), src
+
+
 def _cpu_workers(mode, inputs, threads, extra=()):
     """nproc / threads worker processes of oracle/cpu_worker.py, pinned to disjoint core ranges, released together; -> list of their JSON lines.
     inputs: one .npz path per worker."""
@@ -151,12 +175,12 @@ def _cpu_workers(mode, inputs, threads, extra=()):
 
 def cpu_baseline(scans):
     """The same workload on the host cores with the oracle port (BEV restatement in C, Radon restatement in C + OpenMP,
-    fast_corr restatement on torch CPU) on a bounded sample, at 16 threads and at `nproc` threads; `value` / `cores` are
-    those of the faster setting, both are in `at_threads`."""
+    fast_corr restatement on torch CPU) on a bounded sample, on the cores the container may really use (cpu_budget: the cgroup quota, not `nproc`);
+    `value` / `cores` are those of the fastest setting, every setting tried is in `at_threads`."""
     from oracle import pyoracle as O
     from oracle import corr_oracle as K
     from concurrent.futures import ThreadPoolExecutor
-    nproc = os.cpu_count() or 1
+    nproc, usable, quota_src = cpu_budget()
     cpu_model = "unknown"
     try:
         for ln in open("/proc/cpuinfo"):
@@ -168,18 +192,24 @@ def cpu_baseline(scans):
     ang = np.linspace(0, 2 * np.pi, 120).astype(np.float32)
 
     def run(cores, soas):
-        torch.set_num_threads(cores)
+        # the correlation leg is thousands of 120-point FFTs: torch's intra-op threads buy nothing there (0.2 ms per pair on one thread) and have a
+        # pathological mode on some hosts (16 ms per pair at 2 threads); one torch thread, the other legs on `cores` threads
+        torch.set_num_threads(1)
         os.environ["OMP_NUM_THREADS"] = str(cores)
         O.set_omp_threads(cores)
         w = O.bev_cart(soas[0], 1, 1, 120, 120, 1).reshape(-1, 3)[:, 2].reshape(1, 120, 120)
-        wt = K.tiring_from_sinogram(O.radon_parallel(w, ang, 120, 1.0))
+        ws = O.radon_parallel(w, ang, 120, 1.0)
+        O.set_omp_threads(1)
+        wt = K.tiring_from_sinogram(ws)
         K.fast_corr(wt, wt)
         t0 = time.perf_counter()
         with ThreadPoolExecutor(cores) as ex:      # the reference rasteriser is single-threaded per scan; ctypes drops the GIL
             imgs = np.stack(list(ex.map(lambda s: O.bev_cart(s, 1, 1, 120, 120, 1).reshape(-1, 3)[:, 2].reshape(120, 120), soas)))
         t1 = time.perf_counter()
+        O.set_omp_threads(cores)        # torch re-applies ITS thread count to the calling thread's OpenMP state inside every op
         sino = O.radon_parallel(imgs, ang, 120, 1.0)
         t2 = time.perf_counter()
+        O.set_omp_threads(1)            # ... and torch's own parallel regions must not inherit the C legs' count (one OpenMP runtime serves both)
         tir = [K.tiring_from_sinogram(s[None]) for s in sino]
         for i in range(len(tir)):
             K.fast_corr(tir[i], tir[(i + 1) % len(tir)])
@@ -187,22 +217,20 @@ def cpu_baseline(scans):
         n = len(soas)
         return {"value": n / (t3 - t0), "cores": cores, "sample_scans": n,
                 "ms_per_pair": {"bev": 1e3 * (t1 - t0) / n, "radon": 1e3 * (t2 - t1) / n, "fft_corr": 1e3 * (t3 - t2) / n}}
-    # SURVEY.md 8(d) asks for `nproc` threads.  On a 256-thread host the port is SLOWER with all of them (the correlation leg is thousands of tiny
-    # FFTs: 2.7 pairs/s at 256 threads against 1377 at 16 on an EPYC 9575F), so both settings are timed -- the all-threads one on a 32-scan
-    # slice so that the leg stays bounded -- and `value` / `cores` are those of the faster one; both are in the block.
+    # SURVEY.md 8(d) asks for the box's cores.  What a process may USE is the container's CPU quota, not what `nproc` prints: the GPU boxes report 256
+    # hardware threads and grant 16 cores of CPU time -- a 256-thread run is throttled to 2.7 pairs/s, 32 pinned 8-thread workers together do no
+    # better than one 16-thread process (measured, round 5).  The baseline therefore runs at the usable core count: one process up to 16 threads,
+    # and, where more cores are really available, usable / 8 pinned worker processes x 8 threads released together (oracle/cpu_worker.py).
     all_soas = [synth.to_soa(s) for s in scans]
-    few = run(min(nproc, 16), all_soas)
-    out = {"value": few["value"], "unit": "pairs/s", "cores": few["cores"], "nproc": nproc, "cpu_model": cpu_model, "kind": "port",
+    few = run(min(usable, 16), all_soas)
+    out = {"value": few["value"], "unit": "pairs/s", "cores": few["cores"], "nproc": nproc, "usable_cores": usable, "cpu_quota": quota_src,
+           "cpu_model": cpu_model, "kind": "port",
            "sample": f"{len(scans)} scans x 120k pts: C BEV restatement (1 thread per scan, scans over {few['cores']} threads), "
                      f"C Radon restatement (OpenMP over images), torch-CPU fast_corr ({few['cores']} threads)",
            "ms_per_pair": few["ms_per_pair"], "at_threads": {str(few["cores"]): few}}
-    if nproc > 16:
-        allt = run(nproc, all_soas[:32])                                      # ONE process with every hardware thread: oversubscribed (kept for the record)
-        out["at_threads"][str(nproc) + "_one_process"] = allt
-        # the box used the way a deployment would: nproc / 8 worker processes x 8 threads (the reference's own setting is 4-8 threads per
-        # registration / descriptor process), pinned to disjoint cores, the sample dealt to them, released at the same instant
+    if usable > 16:
         import tempfile
-        nw, per = max(1, nproc // 8), 16
+        nw, per = max(1, usable // 8), 16
         with tempfile.TemporaryDirectory() as td:
             paths = []
             for w in range(nw):
@@ -212,16 +240,15 @@ def cpu_baseline(scans):
             res = _cpu_workers("ring", paths, 8)
         if res:
             rate = sum(r["units"] for r in res) / max(r["seconds"] for r in res)
-            out["at_threads"][str(nproc)] = {"value": rate, "cores": nproc, "workers": len(res), "threads_per_worker": 8, "sample_scans": sum(r["units"] for r in res),
-                                             "slowest_worker_s": max(r["seconds"] for r in res), "fastest_worker_s": min(r["seconds"] for r in res)}
-            out["value_at_nproc_threads"] = rate
+            out["at_threads"][str(usable)] = {"value": rate, "cores": usable, "workers": len(res), "threads_per_worker": 8, "sample_scans": sum(r["units"] for r in res),
+                                              "slowest_worker_s": max(r["seconds"] for r in res), "fastest_worker_s": min(r["seconds"] for r in res)}
+            out["value_at_usable_cores"] = rate
             if rate > out["value"]:
-                out["at_threads"]["16"] = few
-                out.update({"value": rate, "cores": nproc,
+                out.update({"value": rate, "cores": usable,
                             "sample": f"{len(res)} worker processes x 8 threads on disjoint cores, {per} scans x 120k pts each (C BEV / Radon restatements, "
                                       "torch-CPU fast_corr), released together; rate = all scans / slowest worker"})
     soas = all_soas
-    out["gicp"] = cpu_gicp_baseline(nproc)
+    out["gicp"] = cpu_gicp_baseline(usable)
     # the reference's own CPU rasterisers, compiled from its sources (kind "reference"): one thread, and one scan per thread on every core
     def ref_rate(fn, label):
         sample = soas[:128]
@@ -229,8 +256,8 @@ def cpu_baseline(scans):
         for s in sample:
             fn(s)
         out[f"reference_{label}_bev_scans_per_s"] = len(sample) / (time.perf_counter() - t0)
-        many = (soas * ((4 * nproc + len(soas) - 1) // len(soas)))[:max(4 * nproc, len(sample))]
-        with ThreadPoolExecutor(nproc) as ex:
+        many = (soas * ((4 * usable + len(soas) - 1) // len(soas)))[:max(4 * usable, len(sample))]
+        with ThreadPoolExecutor(usable) as ex:
             t0 = time.perf_counter()
             list(ex.map(fn, many))
             out[f"reference_{label}_bev_scans_per_s_all_cores"] = len(many) / (time.perf_counter() - t0)
@@ -244,7 +271,7 @@ def cpu_baseline(scans):
         for s in sample:
             O.ref_bev_cart(s, 1, 1, 120, 120, 1)
         out["reference_cart_bev_scans_per_s"] = len(sample) / (time.perf_counter() - t0)
-    out["reference_bev_threads"] = nproc
+    out["reference_bev_threads"] = usable
     return out
 
 
@@ -344,7 +371,8 @@ def cpu_gicp_baseline(nproc, iters=20):
                                       "covariance_clouds_per_s": 2 / (t2 - t1), "kdtree_build_s": t1 - t0, "cores": th,
                                       "pairs_per_s_incl_covariances_and_trees": 1.0 / (t3 - t0)}
     if nproc > 8:
-        # every core: nproc / 8 independent pairs, one 8-thread registration each (the Mapping node's own setting, global_manager.cpp:2438)
+        # every usable core: nproc / 8 independent pairs, one 8-thread registration each (the Mapping node's own setting, global_manager.cpp:2438);
+        # `nproc` here is the usable core count (cpu_budget)
         import tempfile
         nw = max(1, nproc // 8)
         with tempfile.TemporaryDirectory() as td:
