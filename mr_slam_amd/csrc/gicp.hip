@@ -164,79 +164,191 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
-// The traversal every nearest-neighbour query of this file runs on.  No LDS tile, no workgroup barrier: a WAVE (its queries are 64
-// consecutive Morton-ordered points, i.e. spatially compact) walks the hierarchy on its own.  The earlier design staged 1024-point tiles
-// through the LDS for the whole workgroup; counters showed a wave staging 9 tiles (9 216 candidates, box reductions and barriers
-// included) to evaluate ~670 of them, so that staging cost more than scanning.  Here:
-//   * tiles: lane l tests tile (64 r + l) against the wave's query box widened by `reach` (the largest bound of any lane, fixed at
-//     entry: bounds only shrink) -> one ballot per 64 tiles;
-//   * minis of a hit tile: lane l tests mini l the same way -> one ballot per tile;
-//   * a hit mini is then tested exactly (`need`: any lane whose own ball touches the box, current bounds) and its 16 candidates are
-//     read with wave-uniform addresses (scalar / broadcast loads out of L2) as two groups of 8 squared distances handed to `visit`.
+// ---- the traversal of the k-NN selection ------------------------------------------------------------------------------------------
+// No LDS tile, no workgroup barrier: a WAVE (its queries are 64 consecutive Morton-ordered points, i.e. spatially compact) walks the
+// two-level box hierarchy on its own.  What bounds this kernel is not arithmetic but the LENGTH OF ITS DEPENDENCY CHAINS: a wave of
+// k_knn_cov<30> lived 0.9 ms for ~30 k VALU instructions (a SIMD with five such waves was busy a third of the time), because every mini
+// cost two dependent round trips to the L2 (its box -> test -> its 16 candidates -> distances), taken one after the other.  And a
+// wave whose 64 queries straddle a jump of the Morton curve has a bounding box the size of the scene: tested against THAT box, every mini
+// of the cloud passed the coarse test and was then rejected one round trip at a time -- 3 ms for one wave, the tail of the whole launch.
+//   * coarse tests against QUAD boxes: the queries of 4 consecutive lanes share a box and a bound (16 per wave; a jump of the curve
+//     spoils one of them, not the wave).  Lane l tests tile / mini l against the 16 quads (v_readlane broadcasts, ~20 VALU instructions
+//     per quad): one ballot per 64 boxes and NO per-mini test afterwards -- whatever passes is evaluated;
+//   * tiles nearest first (smallest box distance to any quad) inside a chunk of 64 tiles, the chunk of the wave's own tile first; the
+//     bounds are asked again before every tile (`bound()`), so a lane whose seed was poor holds the walk only until its neighbours' tile
+//     has been seen;
+//   * the 16 candidates of a mini arrive by scalar loads in two halves, the next half REQUESTED BEFORE the current one is evaluated
+//     (scalar loads return out of order, so only lgkmcnt(0) exists: an empty asm that reads one register of the current half makes the
+//     compiler wait for it before the next requests are issued -- everything outstanding during the arithmetic belongs to the next half).
 // Conservative at every level (0.9999 slack on the box distances), so the neighbours found are the exact ones.
-struct NoRec { __device__ __forceinline__ void operator()(int) const {} };
-template <class Need, class Visit, class Rec = NoRec>
-__device__ __forceinline__ void hier_visit(const float4* __restrict__ pts, int n, const Hier& H, const float (&wlo)[3], const float (&whi)[3],
-                                           float reach, float qx, float qy, float qz, Need need, Visit visit, Rec rec = Rec())
+__device__ __forceinline__ float lane_f(float v, int l) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l)); }
+__device__ __forceinline__ float first_f(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
+
+// box of the live queries of this lane's group of 4 consecutive lanes (empty: +inf / -inf)
+__device__ __forceinline__ void quad_box(bool live, const float4& q, float (&lo)[3], float (&hi)[3])
 {
-    const int lane = threadIdx.x & 63;
-    for (int tb = 0; tb < H.ntiles; tb += 64) {
-        const int t = tb + lane;
-        bool hit = false;
-        if (t < H.ntiles) hit = box_box_d2(H.tlo[t], H.thi[t], wlo, whi) * 0.9999f <= reach;
-        unsigned long long tmask = __ballot(hit);
-        while (tmask) {
-            const int tt = tb + (int)__builtin_ctzll(tmask);
-            tmask &= tmask - 1;
-            const bool mhit = box_box_d2(H.mlo[tt * 64 + lane], H.mhi[tt * 64 + lane], wlo, whi) * 0.9999f <= reach;
-            unsigned long long mmask = __ballot(mhit);
-            while (mmask) {
-                const int m = (int)__builtin_ctzll(mmask);
-                mmask &= mmask - 1;
-                const float4 lo = H.mlo[tt * 64 + m], hi = H.mhi[tt * 64 + m];
-                if (!__any(need(lo, hi))) continue;
-                rec(tt * 64 + m);
-                const int j0 = tt * kTile + m * 16;
-                float4 c[16];          // all 16 candidates requested before the first use (wave-uniform addresses: scalar loads)
+    lo[0] = live ? q.x : INFINITY; lo[1] = live ? q.y : INFINITY; lo[2] = live ? q.z : INFINITY;
+    hi[0] = live ? q.x : -INFINITY; hi[1] = live ? q.y : -INFINITY; hi[2] = live ? q.z : -INFINITY;
 #pragma unroll
-                for (int u = 0; u < 16; ++u) c[u] = j0 + u < n ? pts[j0 + u] : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
+    for (int a = 0; a < 3; ++a)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    float dd[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const float dx = qx - c[8 * h + u].x, dy = qy - c[8 * h + u].y, dz = qz - c[8 * h + u].z;
-                        dd[u] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                    }
-                    visit(j0 + 8 * h, dd);
-                }
-            }
+        for (int o = 1; o < 4; o <<= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64));
         }
+}
+__device__ __forceinline__ float quad_max(float v)
+{
+    v = fmaxf(v, __shfl_xor(v, 1, 64));
+    return fmaxf(v, __shfl_xor(v, 2, 64));
+}
+
+// does THIS lane's box (blo, bhi) come within the bound of any query of the wave?  16 quad tests (box against the quad's box and largest
+// bound); a quad in `wide` (its box is larger than its bound: the 4 points straddle a jump of the Morton curve, and everything between the
+// two ends of the jump would "touch" the box) is tested query by query instead.  dmin: the smallest distance seen.
+__device__ __forceinline__ bool quads_hit(const float4& blo, const float4& bhi, const float (&qlo)[3], const float (&qhi)[3], float qT,
+                                          unsigned wide, const float4& q, float T, float& dmin)
+{
+    bool hit = false;
+    dmin = INFINITY;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        if (wide >> g & 1) {        // wave-uniform
+#pragma unroll
+            for (int l = 4 * g; l < 4 * g + 4; ++l) {
+                const float d = box_point_d2(blo, bhi, lane_f(q.x, l), lane_f(q.y, l), lane_f(q.z, l));
+                hit |= d * 0.9999f <= lane_f(T, l);         // a dead lane's T is -1
+                dmin = fminf(dmin, lane_f(T, l) >= 0.0f ? d : INFINITY);
+            }
+        } else {
+            const float l[3] = {lane_f(qlo[0], 4 * g), lane_f(qlo[1], 4 * g), lane_f(qlo[2], 4 * g)};
+            const float h[3] = {lane_f(qhi[0], 4 * g), lane_f(qhi[1], 4 * g), lane_f(qhi[2], 4 * g)};
+            const float d = box_box_d2(blo, bhi, l, h);
+            hit |= d * 0.9999f <= lane_f(qT, 4 * g);
+            dmin = fminf(dmin, d);
+        }
+    }
+    return hit;
+}
+
+// quads whose box is larger than their bound (bit g: lanes 4g .. 4g + 3)
+__device__ __forceinline__ unsigned wide_quads(const float (&qlo)[3], const float (&qhi)[3], float qT)
+{
+    const float ex = qhi[0] - qlo[0], ey = qhi[1] - qlo[1], ez = qhi[2] - qlo[2];
+    const bool w = ex * ex + ey * ey + ez * ez > qT;           // (an empty quad: -inf extents, inf > -1: tested lane by lane, every lane dead)
+    const unsigned long long m = __ballot(w);
+    unsigned out = 0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) out |= (unsigned)(m >> (4 * g) & 1ull) << g;
+    return out;
+}
+
+struct Cand8 { float4 c[8]; };
+__device__ __forceinline__ void cand_request(Cand8& o, const float4* __restrict__ pts, int j0)       // wave-uniform j0: scalar loads
+{
+#pragma unroll
+    for (int u = 0; u < 8; ++u) o.c[u] = pts[j0 + u];       // 128 contiguous bytes; past the cloud's end: the next cloud's points or the 16 points of
+                                                            // slack behind the last one (prepare_side), masked in cand_dist
+    asm volatile("" ::: "memory");        // the requests stay where they are written
+}
+__device__ __forceinline__ void cand_arrived(const Cand8& a)
+{
+    // a use of the half: the compiler's s_waitcnt lgkmcnt(0) lands HERE, before the next requests.  The .w lanes (never read by the arithmetic)
+    // are named too: left dead, the register allocator hands them out as scratch while the loads are in flight, and every such write
+    // costs a wait for everything outstanding
+    asm volatile("" ::"s"(a.c[0].x), "s"(a.c[0].w), "s"(a.c[1].w), "s"(a.c[2].w), "s"(a.c[3].w), "s"(a.c[4].w), "s"(a.c[5].w), "s"(a.c[6].w), "s"(a.c[7].w) : "memory");
+}
+__device__ __forceinline__ void cand_dist(const Cand8& a, int j0, int n, float qx, float qy, float qz, float (&dd)[8])
+{
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const float dx = qx - a.c[u].x, dy = qy - a.c[u].y, dz = qz - a.c[u].z;
+        dd[u] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    }
+    if (j0 + 8 > n) {           // the cloud's last points (wave-uniform): what was read beyond them does not exist
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dd[u] = j0 + u < n ? dd[u] : INFINITY;
     }
 }
 
-// The minis a previous walk of the same wave visited (ids 64 tile + mini, ascending), without the tile / mini box tests of a second walk
-template <class Need, class Visit>
-__device__ __forceinline__ void mini_list_visit(const float4* __restrict__ pts, int n, const Hier& H, const int* __restrict__ ids, int n_ids,
-                                                float qx, float qy, float qz, Need need, Visit visit)
+// the candidates of the minis `ids(r)`, r = 0 .. count - 1 (wave-uniform), 8 at a time: visit(first index, 8 squared distances)
+template <class Ids, class Visit>
+__device__ __forceinline__ void stream_minis(const float4* __restrict__ pts, int n, int count, Ids ids, float qx, float qy, float qz, Visit visit)
 {
-    for (int r = 0; r < n_ids; ++r) {
-        const int id = __builtin_amdgcn_readfirstlane(ids[r]);
-        const float4 lo = H.mlo[id], hi = H.mhi[id];
-        if (!__any(need(lo, hi))) continue;
-        const int j0 = id * 16;
-        float4 c[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) c[u] = j0 + u < n ? pts[j0 + u] : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float dd[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float dx = qx - c[8 * h + u].x, dy = qy - c[8 * h + u].y, dz = qz - c[8 * h + u].z;
-                dd[u] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    if (count <= 0) return;
+    Cand8 A, B;
+    int j0 = ids(0) * 16;
+    cand_request(A, pts, j0);
+    for (int r = 0; r < count; ++r) {
+        cand_arrived(A);
+        cand_request(B, pts, j0 + 8);
+        asm volatile("" : "+v"(qx));          // (the arithmetic on A reads qx: it stays behind the requests for B)
+        float dd[8];
+        cand_dist(A, j0, n, qx, qy, qz, dd);
+        visit(j0, dd);
+        cand_arrived(B);
+        const int jn = r + 1 < count ? ids(r + 1) * 16 : j0;
+        if (r + 1 < count) cand_request(A, pts, jn);
+        asm volatile("" : "+v"(qx));
+        cand_dist(B, j0 + 8, n, qx, qy, qz, dd);
+        visit(j0 + 8, dd);
+        j0 = jn;
+    }
+}
+
+// Walk of the hierarchy for the 64 queries of a wave.  bound(): the lane's current bound (called by the whole wave before every tile; it may
+// do wave-wide bookkeeping first); a dead lane's bound is ignored.  NEAREST: tiles nearest first (pass 1: bounds shrink); otherwise tiles
+// and minis in index order (pass 2 without the list of pass 1: candidates must arrive in ascending index order).  rec(id): every mini visited.
+template <bool NEAREST, class Bound, class Visit, class Rec>
+__device__ __forceinline__ void knn_walk(const float4* __restrict__ pts, int n, const Hier& H, bool live, const float4& q, int home_tile,
+                                         Bound bound, Visit visit, Rec rec)
+{
+    const int lane = threadIdx.x & 63;
+    float qlo[3], qhi[3];
+    quad_box(live, q, qlo, qhi);
+    const int nchunks = (H.ntiles + 63) >> 6;
+    const int hc = min(home_tile, H.ntiles - 1) >> 6;
+    for (int ci = 0; ci < nchunks; ++ci) {
+        const int ch = !NEAREST ? ci : (ci == 0 ? hc : (ci <= hc ? ci - 1 : ci));       // NEAREST: the chunk of the wave's own tile first
+        const int t = ch * 64 + lane;
+        float T = bound();
+        T = live ? T : -1.0f;
+        float qT = quad_max(T);
+        unsigned wide = wide_quads(qlo, qhi, qT);
+        float key = INFINITY;           // box distance of a tile still to be visited; +inf: not (or no longer) a candidate
+        {
+            const int tc = min(t, H.ntiles - 1);
+            float dmin;
+            const bool hit = quads_hit(H.tlo[tc], H.thi[tc], qlo, qhi, qT, wide, q, T, dmin);
+            if (hit && t < H.ntiles) key = dmin;
+        }
+        unsigned long long tmask = __ballot(key < INFINITY);
+        while (tmask) {
+            int tl;
+            if (NEAREST) {
+                float best = key;
+                for (int o = 32; o > 0; o >>= 1) best = fminf(best, __shfl_xor(best, o, 64));
+                best = first_f(best);
+                tl = (int)__builtin_ctzll(__ballot(key == best));
+                T = bound();
+                T = live ? T : -1.0f;
+                qT = quad_max(T);
+                wide = wide_quads(qlo, qhi, qT);
+                if (!(best * 0.9999f <= first_f(wave_max(T)))) break;        // every tile left is at least as far from every query
+            } else {
+                tl = (int)__builtin_ctzll(tmask);
             }
-            visit(j0 + 8 * h, dd);
+            tmask &= ~(1ull << tl);
+            if (lane == tl) key = INFINITY;
+            const int tt = ch * 64 + tl;
+            float dmin;
+            const bool mh = quads_hit(H.mlo[tt * 64 + lane], H.mhi[tt * 64 + lane], qlo, qhi, qT, wide, q, T, dmin);
+            const unsigned long long mmask = __ballot(mh);
+            const int cnt = __builtin_popcountll(mmask);
+            unsigned long long left = mmask;         // ids(r) is asked for r = 0, 1, 2, ... in turn
+            stream_minis(pts, n, cnt,
+                         [&](int) { const int m = (int)__builtin_ctzll(left); left &= left - 1; rec(tt * 64 + m); return tt * 64 + m; },
+                         q.x, q.y, q.z, visit);
         }
     }
 }
@@ -538,54 +650,33 @@ __device__ void smallest_eigvec(const double* c, double* n_out)
     n_out[0] = v[s]; n_out[1] = v[3 + s]; n_out[2] = v[6 + s];
 }
 
-// sorted insertion into the KMAX nearest so far (static register indices)
-template <int KMAX>
-__device__ __forceinline__ void knn_insert(float (&dk)[KMAX], int (&ik)[KMAX], float d, int j)
-{
-#pragma unroll
-    for (int s = KMAX - 1; s > 0; --s) {
-        const bool up = dk[s - 1] > d;
-        const bool here = !up && dk[s] > d;
-        dk[s] = up ? dk[s - 1] : (here ? d : dk[s]);
-        ik[s] = up ? ik[s - 1] : (here ? j : ik[s]);
-    }
-    if (dk[0] > d) { dk[0] = d; ik[0] = j; }
-}
-
-// Seeds the list with the query's 64 neighbours along the Morton curve [home, home + 64): the k-th distance is
-// close to final before the first tile is scanned, which spares most of the insertions of a cold start.  The
-// tile scan then skips exactly that index range (no duplicates).
-constexpr int kHome = 64;
-constexpr int kKnnSpare = 8;      // (7 for 32 slots, so that list + kKnnRec ints per wave stay within 40 KB: four workgroups per compute unit) list slots beyond KMAX: room for candidates tied with the k-th distance before the tie-safe pass is needed
-template <int KMAX>
-__device__ __forceinline__ int knn_seed_home(const float4* __restrict__ pts, int n, int i, bool live, const float4& q,
-                                             float (&dk)[KMAX], int (&ik)[KMAX])
-{
-    const int home = max(0, min(i - kHome / 2, n - kHome));
-    for (int u = 0; u < kHome; ++u) {
-        const int j = home + u;
-        if (j >= n) break;             // n < kHome: wave-uniform
-        const float d = dist2(q.x, q.y, q.z, pts[live ? j : 0]);
-        if (live && d < dk[KMAX - 1]) knn_insert<KMAX>(dk, ik, d, j);
-    }
-    return home;
-}
-
 // ---- exact k nearest neighbours in two passes ----------------------------------------------------------------------------------
-// A sorted insertion that carries the index costs ~20 VALU cycles per slot (compares + selects) and, in SIMT, every lane of a wave pays
-// for every lane's insertions: with 16 (32) slots the insertions were most of k_knn_cov (k_knn_features).  Here the scan keeps only the
-// KMAX smallest DISTANCES, sorted, by a chain of v_med3_f32 (dk[s] = med3(dk[s-1], d, dk[s]): one 4-cycle instruction per slot, no
-// predicate: a distance beyond the list leaves it unchanged).  That yields the exact k-th distance tau; a second scan with the fixed
-// bound tau (it revisits only the few minis within tau) appends the index of every candidate with d <= tau to a per-lane list in
-// the LDS, and the <= KMAX + 8 collected candidates are then put in (distance, index) order by the old insertion -- a couple of dozen
-// insertions per query instead of one per candidate that beat any lane's bound.  Exactly equal distances resolve to the smaller
-// (Morton-space) index.  The whole workgroup must call it together.
+// A sorted insertion that carries the index costs ~8 VALU instructions per slot and, in SIMT, every lane of a wave pays for every
+// lane's insertions.  Here the scan keeps only the KMAX smallest DISTANCES, sorted, by a chain of v_med3_f32
+// (dk[s] = med3(dk[s-1], d, dk[s]): one instruction per slot, no predicate: a distance beyond the list leaves it unchanged).
+//   pass 1 (the k-th distance tau): seed = the 64 neighbours along the Morton curve; then the hierarchy walk.  A candidate closer than
+//     the lane's bound T = dk[KMAX - 1] is only NOTED in a lane-private LDS buffer (one predicated ds_write); the chain runs when some
+//     lane's buffer is more than half full: once per candidate a LANE accepted, not once per candidate ANY lane of the wave accepted
+//     (rounds 3-4: ~480 chain passes per wave, 15 k of its 44 k VALU instructions; now ~50).  T is refreshed at every flush; a stale T
+//     is a valid bound (bounds only shrink), it merely lets a few more candidates through;
+//   pass 2 (the indices): tau is exact, and so is the number of candidates strictly inside it (nless = #{dk[s] < tau}); the walk over
+//     the minis pass 1 noted appends every candidate with d < tau and the first kk - nless exact ties with tau (they arrive in
+//     ascending index order): never more than kk entries, whatever the number of duplicates (no overflow path);
+//   order: the rank of a collected candidate is the number of dk[s] below its distance (+ the equal ones already placed: a bit mask),
+//     2 VALU instructions per slot in place of the 8 of a (distance, index) insertion, and no index registers.
+// Exactly equal distances resolve to the smaller (Morton-space) index.  The whole workgroup must call it together.
 
-// development counters (MRS_KNN_DBG=1 prints them): per wave and round -- tiles staged / candidate groups of 8 visited in pass 1 and 2, groups
-// where some lane's list changed, selection steps, query waves
+// development counters (MRS_KNN_DBG=1 prints them): per wave -- candidate groups of 8 visited in pass 1, groups in which some lane noted
+// a candidate, chain passes (seed excluded), pass 2 groups, entries ranked, query waves
 __device__ unsigned long long g_knn_dbg[8];
 __device__ int g_knn_dbg_on;       // set by the host when MRS_KNN_DBG is in the environment
+__device__ unsigned long long g_knn_trace[2 * 65536];       // MRS_KNN_DBG=1: (start, end) of every workgroup of the last launch on the 100 MHz wall clock
 __device__ int g_knn_norec;        // development aid (MRS_KNN_REC=0): pass 2 walks the hierarchy again instead of revisiting pass 1's minis
+
+constexpr int kHome = 64;         // Morton-curve neighbours that seed the bound (the walk skips exactly that index range)
+constexpr int kKnnBuf = 16;       // LDS slots per lane for noted candidates (in the first slots of the index list: pass 1 is over before pass 2 writes)
+constexpr int kKnnRec = 64;       // minis a wave can note in pass 1 for pass 2 (more: pass 2 walks the hierarchy again)
+constexpr int kKnnBlk = 64;       // neighbour lists leave the selection in blocks of 64 points, slot-major (knn_at)
 
 template <int KMAX>
 __device__ __forceinline__ void dist_insert(float (&dk)[KMAX], float d)
@@ -595,7 +686,7 @@ __device__ __forceinline__ void dist_insert(float (&dk)[KMAX], float d)
     dk[0] = fminf(dk[0], d);
 }
 
-// (distance, index) ordered insertion of the final selection
+// (distance, index) ordered insertion (k_knn_select, the round-4 search core)
 template <int KMAX>
 __device__ __forceinline__ void knn_insert_tie(float (&dk)[KMAX], int (&ik)[KMAX], float d, int j)
 {
@@ -609,133 +700,165 @@ __device__ __forceinline__ void knn_insert_tie(float (&dk)[KMAX], int (&ik)[KMAX
     if (dk[0] > d || (dk[0] == d && ik[0] > j)) { dk[0] = d; ik[0] = j; }
 }
 
-// dk / ik: the k nearest of point i (itself included), ascending in (distance, index); slots >= the number found hold +inf / -1.
-// list: kNNThreads x (KMAX + kKnnSpare) ints of LDS, slot-major.
-__host__ __device__ constexpr int knn_spare(int kmax) { return kmax > 20 ? kKnnSpare - 1 : kKnnSpare; }
-constexpr int kKnnRec = 64;       // minis a wave can note in pass 1 for pass 2 (more: pass 2 walks the hierarchy again)
-template <int KMAX>
-__device__ __forceinline__ void knn_two_pass(int* __restrict__ list, const float4* __restrict__ pts, int n, const Hier& H,
-                                             int i, bool live, const float4& q, int k, float (&dk)[KMAX], int (&ik)[KMAX],
-                                             int* __restrict__ rec_ids = nullptr /* wave-private, kKnnRec ints of LDS */)
+// Neighbour lists between the selection and its consumers (k_cov_from_knn, k_feat_from_knn): cloud-local sorted-space indices, per cloud
+// in blocks of 64 points, slot-major inside a block -- entry (point i, slot s) of cloud c (first point o) lies at
+//   knn[(o + 64 c) k + (i / 64) 64 k + 64 s + i % 64]
+// so that a wave's loads of one slot are ONE 256-byte row (as [point][k] every lane walked its own 4 k bytes: 64 lines per load
+// instruction, re-fetched from HBM whenever the L1 / L2 lost them: k_feat_from_knn read 1.1 KB per point).  Room: knn_ints().
+__host__ __device__ inline size_t knn_ints(int64_t points, int64_t clouds, int k) { return (size_t)(points + kKnnBlk * clouds) * (size_t)k; }
+__device__ __forceinline__ size_t knn_at(int64_t o, int c, int i, int k, int s)
 {
+    return (size_t)(o + (int64_t)kKnnBlk * c) * k + (size_t)(i >> 6) * (kKnnBlk * k) + (size_t)(s << 6) + (size_t)(i & 63);
+}
+
+// The k nearest of point i (itself included) in (distance, index) order: emit(rank, index) once per neighbour, ranks 0 .. found - 1;
+// returns the number found (< k only in a cloud with fewer than k points).  list: KMAX x kNNThreads ints of LDS, slot-major.
+template <int KMAX, class Emit>
+__device__ __forceinline__ int knn_two_pass(int* __restrict__ list, const float4* __restrict__ pts, int n, const Hier& H,
+                                            int i, bool live, const float4& q, int k, int* __restrict__ rec_ids /* wave-private, kKnnRec ints of LDS, or null */,
+                                            Emit emit)
+{
+    static_assert(KMAX <= 32 && KMAX >= kKnnBuf, "rank mask is 32 bits; the note buffer lives in the list");
+    const int tid = (int)threadIdx.x;
+    float dk[KMAX];
 #pragma unroll
     for (int s = 0; s < KMAX; ++s) dk[s] = INFINITY;
-    // pass 1: the KMAX smallest distances.  Seed: the 64 neighbours along the Morton curve (the bound is close to final before the
-    // hierarchy is walked); the walk skips exactly that index range.
+    // pass 1: the KMAX smallest distances.  Seed: the 64 neighbours along the Morton curve, 8 loads in flight at a time
     const int home = max(0, min(i - kHome / 2, n - kHome));
-    for (int u = 0; u < kHome; ++u) {
-        const int j = home + u;
-        if (j >= n) break;             // n < kHome: wave-uniform
-        const float d = dist2(q.x, q.y, q.z, pts[live ? j : 0]);
-        dist_insert<KMAX>(dk, (live && d == d) ? d : INFINITY);
+    for (int u0 = 0; u0 < kHome; u0 += 8) {
+        if (home + u0 >= n) break;             // n < kHome: wave-uniform
+        float4 hp[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) hp[u] = pts[(live && home + u0 + u < n) ? home + u0 + u : 0];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float d = dist2(q.x, q.y, q.z, hp[u]);
+            dist_insert<KMAX>(dk, (live && home + u0 + u < n && d == d) ? d : INFINITY);
+        }
     }
-    float lo[3] = {live ? q.x : INFINITY, live ? q.y : INFINITY, live ? q.z : INFINITY};
-    float hi[3] = {live ? q.x : -INFINITY, live ? q.y : -INFINITY, live ? q.z : -INFINITY};
-    wave_bbox(lo, hi);
-    int c_g1 = 0, c_ins = 0, c_g2 = 0;
+    const int home_tile = __builtin_amdgcn_readfirstlane(i) >> 10;      // kTile = 1024
+    float* const buf = reinterpret_cast<float*>(list);
+    int nb = 0;                     // candidates noted since the last flush
+    int c_g1 = 0, c_ins = 0, c_chain = 0, c_g2 = 0;
+    auto flush = [&]() {
+#pragma unroll 1
+        for (int s = 0; s < kKnnBuf; ++s) {
+            if (!__any(s < nb)) break;
+            const float v = s < nb ? buf[s * kNNThreads + tid] : INFINITY;
+            dist_insert<KMAX>(dk, v);
+            ++c_chain;
+        }
+        nb = 0;
+    };
     int nrec = 0;       // wave-uniform
-    hier_visit(pts, n, H, lo, hi, wave_max(live ? dk[KMAX - 1] : 0.0f), q.x, q.y, q.z,
-               [&](const float4& blo, const float4& bhi) { return live && box_point_d2(blo, bhi, q.x, q.y, q.z) * 0.9999f <= dk[KMAX - 1]; },
+    knn_walk<true>(pts, n, H, live, q, home_tile,
+               [&]() { if (__any(nb > 0)) flush(); return dk[KMAX - 1]; },       // before every tile: bounds up to date
                [&](int j0, const float (&dd)[8]) {
                    ++c_g1;
+                   const float T = dk[KMAX - 1];
                    const float mn = fminf(fminf(fminf(dd[0], dd[1]), fminf(dd[2], dd[3])), fminf(fminf(dd[4], dd[5]), fminf(dd[6], dd[7])));
-                   if (!__any(live && mn < dk[KMAX - 1])) return;
+                   if (!__any(live && mn < T)) return;
                    ++c_ins;
 #pragma unroll
                    for (int u = 0; u < 8; ++u) {
-                       const bool use = live && (unsigned)(j0 + u - home) >= (unsigned)kHome && dd[u] == dd[u];
-                       dist_insert<KMAX>(dk, use ? dd[u] : INFINITY);
+                       const bool use = live && (unsigned)(j0 + u - home) >= (unsigned)kHome && dd[u] < T;       // NaN: false
+                       if (use) { buf[nb * kNNThreads + tid] = dd[u]; ++nb; }
                    }
+                   if (__any(nb > kKnnBuf - 8)) flush();
                },
-               [&](int id) {       // every mini within some lane's bound of the moment (a superset of the minis within the final bounds)
+               [&](int id) {       // every mini within some quad's bound of the moment (a superset of the minis within the final bounds)
                    if (rec_ids && nrec < kKnnRec && (threadIdx.x & 63) == 0) rec_ids[nrec] = id;
                    ++nrec;
                });
-    // pass 2: every candidate within the k-th distance, home range included, appended to the lane's list (KMAX + 8 slots: room for 8 exact
-    // ties with the k-th distance beyond the k - 1 strictly closer candidates).  A lane that would need more (a cluster of duplicates:
-    // round-3 review -- closer neighbours were dropped when more than 8 ties preceded them in Morton order) makes its WAVE repeat the pass
-    // with the tie-safe bookkeeping: strictly closer candidates from the bottom of the list, ties from slot k - 1 downwards (they arrive in
-    // ascending index order; one is only kept while the list still has room for it, at most k - #closer can be needed).
-    constexpr int CAP = KMAX + knn_spare(KMAX);
+    if (__any(nb > 0)) flush();
+    // pass 2: the candidates within the k-th distance, home range included, in ascending index order
     const int kk = k < KMAX ? k : KMAX;
-    const float tau = live ? dk[kk - 1] : -1.0f;
-    int cnt = 0;
-    bool spilled = false;
-    auto need2 = [&](const float4& blo, const float4& bhi) { return live && box_point_d2(blo, bhi, q.x, q.y, q.z) * 0.9999f <= tau; };
+    float tau = dk[KMAX - 1];
+    int nless = 0;
+#pragma unroll
+    for (int s = 0; s < KMAX - 1; ++s) tau = (s == kk - 1) ? dk[s] : tau;
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) {
+        dk[s] = s < kk ? dk[s] : INFINITY;        // the ranks below count dk[s] < d over every slot
+        nless += dk[s] < tau ? 1 : 0;
+    }
+    if (!live) tau = -1.0f;
+    const int room = kk - nless;                  // exact ties with tau that belong to the k nearest
+    int cnt = 0, nt = 0;
     auto visit2 = [&](int j0, const float (&dd)[8]) {
         ++c_g2;
+        const float mn = fminf(fminf(fminf(dd[0], dd[1]), fminf(dd[2], dd[3])), fminf(fminf(dd[4], dd[5]), fminf(dd[6], dd[7])));
+        if (!__any(mn <= tau)) return;
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             if (dd[u] <= tau && dd[u] < INFINITY) {     // tau is +inf for a cloud with fewer than k points: padding stays out
-                if (cnt < CAP) list[cnt * kNNThreads + (int)threadIdx.x] = j0 + u;
-                else spilled = true;
-                ++cnt;
+                const bool tie = dd[u] == tau;
+                if (!tie || nt < room) {
+                    list[cnt * kNNThreads + tid] = j0 + u;
+                    ++cnt;
+                    nt += tie ? 1 : 0;
+                }
             }
     };
-    if (rec_ids && nrec <= kKnnRec) {       // the minis pass 1 visited, in the same order, without walking the hierarchy again
+    if (rec_ids && nrec <= kKnnRec) {       // the minis pass 1 visited, without walking the hierarchy again -- in INDEX order (ties resolve by arrival)
         nnc::wave_lds_sync();
-        mini_list_visit(pts, n, H, rec_ids, nrec, q.x, q.y, q.z, need2, visit2);
+        const int lane = threadIdx.x & 63;
+        const int id = lane < nrec ? rec_ids[lane] : 0x7fffffff;
+        int rank = 0;
+        for (int m = 0; m < nrec; ++m) rank += __builtin_amdgcn_readlane(id, m) < id ? 1 : 0;
+        nnc::wave_lds_sync();
+        if (lane < nrec) rec_ids[rank] = id;
+        nnc::wave_lds_sync();
+        // (no box test: nearly every one of them holds a candidate of some lane, and the test would be a round trip per mini)
+        stream_minis(pts, n, nrec, [&](int r) { return __builtin_amdgcn_readfirstlane(rec_ids[r]); }, q.x, q.y, q.z, visit2);
     } else {
-        hier_visit(pts, n, H, lo, hi, wave_max(tau), q.x, q.y, q.z, need2, visit2);
+        knn_walk<false>(pts, n, H, live, q, 0, [&]() { return tau; }, visit2, [](int) {});
     }
-    int nlt = min(cnt, CAP), ntie = 0;       // fast path: every collected candidate goes through the (distance, index) insertion below
-    const bool safe = __any(spilled);
-    if (safe) {
-        nlt = 0;
-        hier_visit(pts, n, H, lo, hi, wave_max(tau), q.x, q.y, q.z,
-                   [&](const float4& blo, const float4& bhi) { return live && box_point_d2(blo, bhi, q.x, q.y, q.z) * 0.9999f <= tau; },
-                   [&](int j0, const float (&dd)[8]) {
-#pragma unroll
-                       for (int u = 0; u < 8; ++u) {
-                           if (dd[u] < tau) {                 // at most k - 1 of these; a tie in the way was not needed
-                               list[min(nlt, KMAX - 1) * kNNThreads + (int)threadIdx.x] = j0 + u;
-                               ++nlt;
-                               ntie = min(ntie, kk - nlt);
-                           } else if (dd[u] == tau && dd[u] < INFINITY && nlt + ntie < kk) {
-                               list[(kk - 1 - ntie) * kNNThreads + (int)threadIdx.x] = j0 + u;
-                               ++ntie;
-                           }
-                       }
-                   });
-    }
-    // selection: (distance, index) order
-#pragma unroll
-    for (int s = 0; s < KMAX; ++s) { dk[s] = INFINITY; ik[s] = -1; }
-    int most = max(nlt, ntie);
+    cnt = min(cnt, kk);       // (cannot exceed it: nless candidates are closer than tau, at most room ties were taken)
+    // order: rank = #{dk < d} + the equal ones placed before (entries arrive in ascending index order)
+    int most = cnt;
     for (int o = 32; o > 0; o >>= 1) most = max(most, __shfl_xor(most, o, 64));
     if (g_knn_dbg_on && (threadIdx.x & 63) == 0) {
         atomicAdd(&g_knn_dbg[1], (unsigned long long)c_g1); atomicAdd(&g_knn_dbg[2], (unsigned long long)c_ins);
+        atomicAdd(&g_knn_dbg[3], (unsigned long long)c_chain);
         atomicAdd(&g_knn_dbg[4], (unsigned long long)c_g2); atomicAdd(&g_knn_dbg[5], (unsigned long long)most);
         atomicAdd(&g_knn_dbg[6], 1ull);
+        atomicMax(&g_knn_dbg[7], (unsigned long long)c_g1); atomicMax(&g_knn_dbg[0], (unsigned long long)c_chain);
     }
+    unsigned used = 0;
+    int j = cnt > 0 ? list[tid] : 0;
+    float4 pj = pts[j];
+#pragma unroll 1
     for (int c = 0; c < most; ++c) {
-        const bool ha = c < nlt, hb = safe && c < ntie;
-        const int ja = ha ? list[c * kNNThreads + (int)threadIdx.x] : 0;
-        const int jb = hb ? list[(kk - 1 - c) * kNNThreads + (int)threadIdx.x] : 0;
-        const float da = dist2(q.x, q.y, q.z, pts[ja]);
-        if (ha) knn_insert_tie<KMAX>(dk, ik, da, ja);
-        if (safe) {
-            const float db = dist2(q.x, q.y, q.z, pts[jb]);
-            if (hb) knn_insert_tie<KMAX>(dk, ik, db, jb);
+        const bool h = c < cnt;
+        const int jn = c + 1 < cnt ? list[(c + 1) * kNNThreads + tid] : 0;
+        const float4 pn = pts[jn];          // the next entry's point is on its way while this one is ranked
+        const float d = dist2(q.x, q.y, q.z, pj);
+        int r = 0;
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) r += dk[s] < d ? 1 : 0;
+        r = min(r, 31);
+        r += __builtin_ctz(~(used >> r));
+        if (h && r < kk) {
+            used |= 1u << r;
+            emit(r, j);
         }
+        j = jn; pj = pn;
     }
+    return cnt;
 }
 
-// G2: exact kNN (KMAX slots, the first k are used) + covariance + PLANE regularisation, on the
-// Morton-ordered cloud with tile culling (bound = the lane's current KMAX-th distance).
-// grid = (blocks, clouds); cloud c spans pts[offs[c] .. offs[c+1]).
-// cov out (sorted space): 6 doubles per point (xx, xy, xz, yy, yz, zz).
-// knn_out optional, ORIGINAL indexing: knn_out[(offs[c] + orig_i) * k + s] = original neighbour index.
-// SPLIT: only the selection -- the neighbours go to knn_out as cloud-local SORTED-space indices [point][k] and k_cov_from_knn does the
-// fp64 tail: without the covariance / eigenvector state the selection keeps fewer registers alive (more waves per SIMD).
-template <int KMAX, bool SPLIT = false>
-__global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(KMAX <= 16 ? (SPLIT ? 6 : 5) : (SPLIT ? 4 : 1)))) void k_knn_cov(const float4* __restrict__ pts_all,
+// G2 / N1 selection: exact kNN (KMAX slots, the first k are used) on the Morton-ordered cloud with tile / mini culling (bound = the lane's
+// current KMAX-th distance).  grid = (blocks, clouds); cloud c spans pts[offs[c] .. offs[c+1]).  The neighbours go to knn (layout: knn_at)
+// as cloud-local SORTED-space indices, -1 in the slots a cloud with fewer than k points cannot fill; k_cov_from_knn / k_feat_from_knn do
+// the fp64 tails (without their state the selection keeps fewer registers alive: more waves per SIMD).
+template <int KMAX, int WAVES = (KMAX <= 20 ? 6 : (KMAX <= 30 ? 5 : 4))>
+__global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_knn_cov(const float4* __restrict__ pts_all,
                                                         const int64_t* __restrict__ offs, const int* __restrict__ tile_base,
                                                         const float4* __restrict__ tlo, const float4* __restrict__ thi,
-        const float4* __restrict__ mlo, const float4* __restrict__ mhi,
-                                                        int k, double* __restrict__ cov_all, int* __restrict__ knn_out)
+        const float4* __restrict__ mlo, const float4* __restrict__ mhi, int k, int* __restrict__ knn)
 {
-    __shared__ int knn_list[(KMAX + knn_spare(KMAX)) * kNNThreads];
+    __shared__ int knn_list[KMAX * kNNThreads];
     __shared__ int knn_rec[kNNThreads / 64][kKnnRec];
     const int c = blockIdx.y;
     const int64_t o = offs[c];
@@ -745,51 +868,21 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(KMAX
     H.tlo = tlo + tile_base[c]; H.thi = thi + tile_base[c];
     H.mlo = mlo + (size_t)64 * tile_base[c]; H.mhi = mhi + (size_t)64 * tile_base[c];
     H.ntiles = (n + kTile - 1) / kTile;
+    const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if (g_knn_dbg_on && threadIdx.x == 0 && wg < 65536) g_knn_trace[2 * wg] = wall_clock64();
     for (int base = blockIdx.x * kNNThreads; base < n; base += gridDim.x * kNNThreads) {
         const int i = base + threadIdx.x;
         const bool live = i < n;
         const float4 q = pts[live ? i : 0];
-        float dk[KMAX];
-        int ik[KMAX];
-        knn_two_pass<KMAX>(knn_list, pts, n, H, i, live, q, k, dk, ik, (SPLIT && !g_knn_norec) ? knn_rec[threadIdx.x >> 6] : nullptr);
-        if (!live) continue;
-        if (SPLIT) {
-#pragma unroll
-            for (int s = 0; s < KMAX; ++s)
-                if (s < k) knn_out[(size_t)(o + i) * k + s] = ik[s];
-            continue;
-        }
-        double mean[3] = {0, 0, 0};
-        int cnt = 0;
-#pragma unroll
-        for (int s = 0; s < KMAX; ++s)
-            if (s < k && ik[s] >= 0) {
-                const float4 p = pts[ik[s]];
-                mean[0] += (double)p.x; mean[1] += (double)p.y; mean[2] += (double)p.z;
-                ++cnt;
-            }
-        mean[0] /= cnt; mean[1] /= cnt; mean[2] /= cnt;
-        double cv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int s = 0; s < KMAX; ++s)
-            if (s < k && ik[s] >= 0) {
-                const float4 p = pts[ik[s]];
-                const double dx = (double)p.x - mean[0], dy = (double)p.y - mean[1], dz = (double)p.z - mean[2];
-                cv[0] += dx * dx; cv[1] += dx * dy; cv[2] += dx * dz;
-                cv[4] += dy * dy; cv[5] += dy * dz; cv[8] += dz * dz;
-            }
-        cv[3] = cv[1]; cv[6] = cv[2]; cv[7] = cv[5];
-        for (int a = 0; a < 9; ++a) cv[a] /= cnt;
-        double nrm[3];
-        smallest_eigvec(cv, nrm);
-        double* out = cov_all + kCovDoubles * (size_t)(o + i);      // the unit normal: C = I - 0.999 n n^T is rebuilt by the readers (cov6_from_normal)
-        out[0] = nrm[0]; out[1] = nrm[1]; out[2] = nrm[2];
-        if (knn_out) {
-            const int oi = __float_as_int(q.w);
-#pragma unroll
-            for (int s = 0; s < KMAX; ++s)
-                if (s < k) knn_out[(size_t)(o + oi) * k + s] = ik[s] >= 0 ? __float_as_int(pts[ik[s]].w) : -1;
-        }
+        int* const out = knn + knn_at(o, c, live ? i : 0, k, 0);
+        const int found = knn_two_pass<KMAX>(knn_list, pts, n, H, i, live, q, k, g_knn_norec ? nullptr : knn_rec[threadIdx.x >> 6],
+                                             [&](int r, int j) { out[r << 6] = j; });
+        if (live && found < k)
+            for (int s = found; s < k; ++s) out[s << 6] = -1;
+    }
+    if (g_knn_dbg_on && wg < 65536) {
+        __syncthreads();
+        if (threadIdx.x == 0) g_knn_trace[2 * wg + 1] = wall_clock64();
     }
 }
 
@@ -879,87 +972,6 @@ __device__ void sym3_eigvals(const double* c, double* w)
     if (y < z) { t = y; y = z; z = t; }
     if (x < y) { t = x; x = y; y = t; }
     w[0] = x; w[1] = y; w[2] = z;
-}
-
-// N1 fused: exact kNN (k <= 32, the point itself included, like sklearn's kneighbors on the fitted
-// set: util.py:163-170) -> covariance P^T P / (k-1) (util.py:123-131) -> eigenvalues of the 3x3 and
-// of its xy 2x2 block, both descending (util.py:134-158) -> the 13 hand-crafted features.
-// Outputs are in the caller's ORIGINAL point order; feat_planes (optional) receives the channel-major
-// [9][n] planes x,y,z,C,O,E,L2,dZ,vZ that generate_RINGplusplus feeds to the feature BEV
-// (util.py:220-228: features [0,1,3,10,11,12]).
-template <int KMAX>
-__global__ __launch_bounds__(kNNThreads) void k_knn_features(const float4* __restrict__ pts_all,
-                                                             const int64_t* __restrict__ offs, const int* __restrict__ tile_base,
-                                                             const float4* __restrict__ tlo, const float4* __restrict__ thi,
-        const float4* __restrict__ mlo, const float4* __restrict__ mhi,
-                                                             int k, int* __restrict__ knn_out, float* __restrict__ eig_out,
-                                                             float* __restrict__ feat_out, float* __restrict__ feat_planes)
-{
-    __shared__ int knn_list[(KMAX + knn_spare(KMAX)) * kNNThreads];
-    const int c = blockIdx.y;
-    const int64_t o = offs[c];
-    const int n = (int)(offs[c + 1] - o);
-    const float4* pts = pts_all + o;
-    Hier H;
-    H.tlo = tlo + tile_base[c]; H.thi = thi + tile_base[c];
-    H.mlo = mlo + (size_t)64 * tile_base[c]; H.mhi = mhi + (size_t)64 * tile_base[c];
-    H.ntiles = (n + kTile - 1) / kTile;
-    for (int base = blockIdx.x * kNNThreads; base < n; base += gridDim.x * kNNThreads) {
-        const int i = base + threadIdx.x;
-        const bool live = i < n;
-        const float4 q = pts[live ? i : 0];
-        float dk[KMAX];
-        int ik[KMAX];
-        knn_two_pass<KMAX>(knn_list, pts, n, H, i, live, q, k, dk, ik);
-        if (!live) continue;
-        const int oi = __float_as_int(q.w);
-        double mean[3] = {0, 0, 0};
-        float nz[KMAX];
-        int cnt = 0;
-#pragma unroll
-        for (int s = 0; s < KMAX; ++s) {
-            nz[s] = 0.0f;
-            if (s < k && ik[s] >= 0) {
-                const float4 p = pts[ik[s]];
-                mean[0] += (double)p.x; mean[1] += (double)p.y; mean[2] += (double)p.z;
-                nz[s] = p.z;
-                ++cnt;
-            }
-        }
-        mean[0] /= cnt; mean[1] /= cnt; mean[2] /= cnt;
-        double cv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int s = 0; s < KMAX; ++s)
-            if (s < k && ik[s] >= 0) {
-                const float4 p = pts[ik[s]];
-                const double dx = (double)p.x - mean[0], dy = (double)p.y - mean[1], dz = (double)p.z - mean[2];
-                cv[0] += dx * dx; cv[1] += dx * dy; cv[2] += dx * dz;
-                cv[4] += dy * dy; cv[5] += dy * dz; cv[8] += dz * dz;
-            }
-        cv[3] = cv[1]; cv[6] = cv[2]; cv[7] = cv[5];
-        for (int a = 0; a < 9; ++a) cv[a] /= (double)(cnt - 1);
-        double w[3];
-        sym3_eigvals(cv, w);
-        const double hm = 0.5 * (cv[0] + cv[4]), hd = 0.5 * (cv[0] - cv[4]);
-        const double rad = sqrt(hd * hd + cv[1] * cv[1]);
-        float e[5] = {(float)w[0], (float)w[1], (float)w[2], (float)(hm + rad), (float)(hm - rad)};
-        float f[13];
-        point_features(e, nz, k, f);
-        const size_t gi = (size_t)(o + oi);
-        if (knn_out) {
-#pragma unroll
-            for (int s = 0; s < KMAX; ++s)
-                if (s < k) knn_out[gi * k + s] = ik[s] >= 0 ? __float_as_int(pts[ik[s]].w) : -1;
-        }
-        if (eig_out) for (int j = 0; j < 5; ++j) eig_out[gi * 5 + j] = e[j];
-        if (feat_out) for (int j = 0; j < 13; ++j) feat_out[gi * 13 + j] = f[j];
-        if (feat_planes) {
-            float* pl = feat_planes + (size_t)9 * o;  // scan-local channel-major planes
-            pl[0 * (size_t)n + oi] = q.x; pl[1 * (size_t)n + oi] = q.y; pl[2 * (size_t)n + oi] = q.z;
-            pl[3 * (size_t)n + oi] = f[0]; pl[4 * (size_t)n + oi] = f[1]; pl[5 * (size_t)n + oi] = f[3];
-            pl[6 * (size_t)n + oi] = f[10]; pl[7 * (size_t)n + oi] = f[11]; pl[8 * (size_t)n + oi] = f[12];
-        }
-    }
 }
 
 __device__ __forceinline__ bool inv3_sym(const double* a, double* r)
@@ -1160,8 +1172,8 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(WAVE
 
 
 // ================================================================================================================================
-// Round 4 search core (nn_core.hpp): octree-cell leaves + query groups.  The kernels below replace k_nn_scan / k_knn_cov /
-// k_knn_features; the round-3 kernels stay selectable (mrs_gicp_batch_set_search(h, 0)) for A/B runs and as a cross-check in the tests.
+// Round 4 search core (nn_core.hpp): octree-cell leaves + query groups.  The kernels below replace k_nn_scan / k_knn_cov;
+// the round-3 kernels stay selectable (mrs_gicp_batch_set_search(h, 0)) for A/B runs and as a cross-check in the tests.
 struct HierArrays {
     const float4* llo; const float4* lhi; const float4* tlo; const float4* thi; const float4* slo; const float4* shi;
     const int* leaf_first; const int* tile_first; const int* super_first;   // [clouds + 1]
@@ -1409,7 +1421,7 @@ __device__ __forceinline__ float kth_of(const float (&dk)[KMAX], int k)
 }
 
 // G2 / N1, round 4: exact k nearest neighbours (the point itself included) of every point of every cloud, as cloud-local sorted-space
-// indices in (distance, index) order: knn[(offs[c] + i) * k + s]; -1 in the slots a cloud with fewer than k points cannot fill.
+// indices in (distance, index) order, layout knn_at(); -1 in the slots a cloud with fewer than k points cannot fill.
 // Seed: the group's 32 (64 for k > 16) neighbours along the Morton curve give a bound close to the final one; pass 1: the KMAX smallest
 // DISTANCES (v_med3 chain, no indices) over the leaves within the shrinking bound -> tau = the exact k-th distance; pass 2: every candidate
 // within tau, strictly closer ones from the bottom of a k-slot LDS list, exact ties from its top (they arrive in ascending index order, and a
@@ -1477,10 +1489,10 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_select(const float4* __restr
             if (hb) knn_insert_tie<KMAX>(dk, ik, db, jb);
         }
         if (live) {
-            int* out = knn + (size_t)(o + i) * k;
+            int* out = knn + knn_at(o, c, i, k, 0);
 #pragma unroll
             for (int s = 0; s < KMAX; ++s)
-                if (s < k) out[s] = ik[s];
+                if (s < k) out[s << 6] = ik[s];
         }
     }
 }
@@ -1495,11 +1507,11 @@ __global__ __launch_bounds__(256) void k_cov_from_knn(const float4* __restrict__
     const int n = (int)(offs[c + 1] - o);
     const float4* pts = pts_all + o;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int* nb = knn + (size_t)(o + i) * k;
+        const int* nb = knn + knn_at(o, c, i, k, 0);       // slot s at nb[64 s]: one row per wave and slot
         double mean[3] = {0, 0, 0};
         int cnt = 0;
         for (int s = 0; s < k; ++s) {
-            const int j = nb[s];
+            const int j = nb[s << 6];
             if (j < 0) continue;
             const float4 p = pts[j];
             mean[0] += (double)p.x; mean[1] += (double)p.y; mean[2] += (double)p.z;
@@ -1508,7 +1520,7 @@ __global__ __launch_bounds__(256) void k_cov_from_knn(const float4* __restrict__
         mean[0] /= cnt; mean[1] /= cnt; mean[2] /= cnt;
         double cv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int s = 0; s < k; ++s) {
-            const int j = nb[s];
+            const int j = nb[s << 6];
             if (j < 0) continue;
             const float4 p = pts[j];
             const double dx = (double)p.x - mean[0], dy = (double)p.y - mean[1], dz = (double)p.z - mean[2];
@@ -1523,12 +1535,12 @@ __global__ __launch_bounds__(256) void k_cov_from_knn(const float4* __restrict__
         out[0] = nrm[0]; out[1] = nrm[1]; out[2] = nrm[2];
         if (knn_out) {
             const int oi = __float_as_int(pts[i].w);
-            for (int s = 0; s < k; ++s) knn_out[(size_t)(o + oi) * k + s] = nb[s] >= 0 ? __float_as_int(pts[nb[s]].w) : -1;
+            for (int s = 0; s < k; ++s) knn_out[(size_t)(o + oi) * k + s] = nb[s << 6] >= 0 ? __float_as_int(pts[nb[s << 6]].w) : -1;
         }
     }
 }
 
-// N1 tail: covariance / eigenvalues / the 13 features of every point from its k neighbours (k_knn_features' arithmetic, same order)
+// N1 tail: covariance / eigenvalues / the 13 features of every point from its k neighbours (neighbours summed in (distance, index) order)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_feat_from_knn(const float4* __restrict__ pts_all, const int64_t* __restrict__ offs, int k,
                                                       const int* __restrict__ knn, int* __restrict__ knn_out, float* __restrict__ eig_out,
                                                       float* __restrict__ feat_out, float* __restrict__ feat_planes)
@@ -1538,7 +1550,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     const int n = (int)(offs[c + 1] - o);
     const float4* pts = pts_all + o;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int* nb = knn + (size_t)(o + i) * k;
+        const int* nb = knn + knn_at(o, c, i, k, 0);       // slot s at nb[64 s]
         const float4 q = pts[i];
         const int oi = __float_as_int(q.w);
         double mean[3] = {0, 0, 0};
@@ -1547,8 +1559,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
             nz[s] = 0.0f;
-            if (s < k && nb[s] >= 0) {
-                const float4 p = pts[nb[s]];
+            if (s < k && nb[s << 6] >= 0) {
+                const float4 p = pts[nb[s << 6]];
                 mean[0] += (double)p.x; mean[1] += (double)p.y; mean[2] += (double)p.z;
                 nz[s] = p.z;
                 ++cnt;
@@ -1557,8 +1569,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         mean[0] /= cnt; mean[1] /= cnt; mean[2] /= cnt;
         double cv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int s = 0; s < k; ++s) {
-            if (nb[s] < 0) continue;
-            const float4 p = pts[nb[s]];
+            if (nb[s << 6] < 0) continue;
+            const float4 p = pts[nb[s << 6]];
             const double dx = (double)p.x - mean[0], dy = (double)p.y - mean[1], dz = (double)p.z - mean[2];
             cv[0] += dx * dx; cv[1] += dx * dy; cv[2] += dx * dz;
             cv[4] += dy * dy; cv[5] += dy * dz; cv[8] += dz * dz;
@@ -1574,7 +1586,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         point_features(e, nz, k, f);
         const size_t gi = (size_t)(o + oi);
         if (knn_out)
-            for (int s = 0; s < k; ++s) knn_out[gi * k + s] = nb[s] >= 0 ? __float_as_int(pts[nb[s]].w) : -1;
+            for (int s = 0; s < k; ++s) knn_out[gi * k + s] = nb[s << 6] >= 0 ? __float_as_int(pts[nb[s << 6]].w) : -1;
         if (eig_out) for (int j = 0; j < 5; ++j) eig_out[gi * 5 + j] = e[j];
         if (feat_out) for (int j = 0; j < 13; ++j) feat_out[gi * 13 + j] = f[j];
         if (feat_planes) {
@@ -2283,7 +2295,7 @@ int nn_pass(mrs_gicp_batch* h, int mode, hipStream_t s)
     return MRS_OK;
 }
 
-// k nearest neighbours of every point of side `w` (k_knn_select) into knn [total][k]
+// k nearest neighbours of every point of side `w` (k_knn_select) into knn (layout: knn_at)
 int launch_knn_select(mrs_gicp_batch* h, int w, int k, int* d_knn, hipStream_t s)
 {
     int64_t longest = 0;
@@ -2297,6 +2309,68 @@ int launch_knn_select(mrs_gicp_batch* h, int w, int k, int* d_knn, hipStream_t s
     else
         hipLaunchKernelGGL((k_knn_select<32>), grid, dim3(kNNThreads), 0, s, (const float4*)h->d_pts[w], (const int64_t*)h->d_offs[w], HA, k, d_knn);
     MRS_HIP_TRY(hipGetLastError());
+    return MRS_OK;
+}
+
+// the selection kernel of the default search setting over clouds [c0, c0 + nc) of side w; knn: see knn_at (cloud numbers count from c0)
+void launch_knn_cov(mrs_gicp_batch* h, int w, int c0, int nc, int64_t longest, int k, int* d_knn, hipStream_t s)
+{
+    const dim3 g((unsigned)((longest + kNNThreads - 1) / kNNThreads), nc);
+    const int64_t* const offs_c = h->d_offs[w] + c0;
+    const int* const tb_c = h->d_tile_base[w] + c0;
+    static const char* const wv_s = mrs::dev_env("MRS_KNN_WAVES");      // development aid: waves per SIMD of the selection kernel
+    const int wv = wv_s ? atoi(wv_s) : 0;
+    if (k <= 16 && wv == 5)
+        hipLaunchKernelGGL((k_knn_cov<16, 5>), g, dim3(kNNThreads), 0, s, h->d_pts[w], offs_c, tb_c, h->d_tlo[w], h->d_thi[w], h->d_mlo[w], h->d_mhi[w], k, d_knn);
+    else if (k <= 16)
+        hipLaunchKernelGGL(k_knn_cov<16>, g, dim3(kNNThreads), 0, s, h->d_pts[w], offs_c, tb_c, h->d_tlo[w], h->d_thi[w], h->d_mlo[w], h->d_mhi[w], k, d_knn);
+    else if (k <= 20)
+        hipLaunchKernelGGL(k_knn_cov<20>, g, dim3(kNNThreads), 0, s, h->d_pts[w], offs_c, tb_c, h->d_tlo[w], h->d_thi[w], h->d_mlo[w], h->d_mhi[w], k, d_knn);
+    else if (k <= 30 && wv == 4)
+        hipLaunchKernelGGL((k_knn_cov<30, 4>), g, dim3(kNNThreads), 0, s, h->d_pts[w], offs_c, tb_c, h->d_tlo[w], h->d_thi[w], h->d_mlo[w], h->d_mhi[w], k, d_knn);
+    else if (k <= 30)       // RING++'s k: 30 list slots = 30 KB of LDS = five workgroups per compute unit (32: four)
+        hipLaunchKernelGGL(k_knn_cov<30>, g, dim3(kNNThreads), 0, s, h->d_pts[w], offs_c, tb_c, h->d_tlo[w], h->d_thi[w], h->d_mlo[w], h->d_mhi[w], k, d_knn);
+    else
+        hipLaunchKernelGGL(k_knn_cov<32>, g, dim3(kNNThreads), 0, s, h->d_pts[w], offs_c, tb_c, h->d_tlo[w], h->d_thi[w], h->d_mlo[w], h->d_mhi[w], k, d_knn);
+}
+
+// development aids of the selection kernel (MRS_DEV=1): MRS_KNN_DBG=1 counters, MRS_KNN_REC=0 = pass 2 walks the hierarchy again
+int knn_dev_switches(hipStream_t s)
+{
+    if (mrs::dev_env("MRS_KNN_DBG")) {
+        const int on = 1;
+        MRS_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_knn_dbg_on), &on, sizeof(on)));
+    }
+    const char* const e = mrs::dev_env("MRS_KNN_REC");      // read per call (the tests flip it)
+    const int off = (e && atoi(e) == 0) ? 1 : 0;
+    static int cur = 0;
+    if (off != cur) {
+        MRS_HIP_TRY(hipStreamSynchronize(s));
+        MRS_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_knn_norec), &off, sizeof(off)));
+        cur = off;
+    }
+    return MRS_OK;
+}
+
+int knn_dbg_report(hipStream_t s)
+{
+    static const bool knn_dbg = mrs::dev_env("MRS_KNN_DBG") != nullptr;
+    if (!knn_dbg) return MRS_OK;
+    unsigned long long c[8];
+    MRS_HIP_TRY(hipStreamSynchronize(s));
+    MRS_HIP_TRY(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_knn_dbg), sizeof(c)));
+    const double w = (double)(c[6] ? c[6] : 1);
+    fprintf(stderr, "[knn dbg] per query wave: pass 1 groups of 8 candidates %.1f (some lane noted one in %.1f), chain passes after the seed %.1f, pass 2 groups %.1f, "
+                    "entries ranked %.1f; %llu waves; the busiest wave: %llu groups in pass 1, %llu chain passes\n", c[1] / w, c[2] / w, c[3] / w, c[4] / w, c[5] / w, c[6], c[7], c[0]);
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    MRS_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_knn_dbg), z, sizeof(z)));
+    if (const char* path = getenv("MRS_KNN_TRACE_FILE")) {       // (start, end) of every workgroup of the launch just finished, raw uint64 pairs
+        std::vector<unsigned long long> tr(2 * 65536);
+        MRS_HIP_TRY(hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(g_knn_trace), tr.size() * sizeof(unsigned long long)));
+        if (FILE* f = fopen(path, "wb")) { fwrite(tr.data(), sizeof(unsigned long long), tr.size(), f); fclose(f); }
+        std::fill(tr.begin(), tr.end(), 0ull);
+        MRS_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_knn_trace), tr.data(), tr.size() * sizeof(unsigned long long)));
+    }
     return MRS_OK;
 }
 
@@ -2339,7 +2413,7 @@ static int prepare_side(mrs_gicp_batch* h, int32_t which, const int64_t* h_offse
         const int64_t cap = total + total / 8;
         const int capt = tiles + tiles / 8 + 1;
         MRS_HIP_TRY(hipMalloc(&h->d_offs[which], (h->n_pairs + 1) * sizeof(int64_t)));
-        MRS_HIP_TRY(hipMalloc(&h->d_pts[which], (size_t)cap * sizeof(float4)));
+        MRS_HIP_TRY(hipMalloc(&h->d_pts[which], ((size_t)cap + 16) * sizeof(float4)));      // + 16: a mini's 16 candidates are read whole (cand_request)
         if (!h->no_cov) MRS_HIP_TRY(hipMalloc(&h->d_cov[which], (size_t)cap * kCovDoubles * sizeof(double)));
         MRS_HIP_TRY(hipMalloc(&h->d_tile_base[which], h->n_pairs * sizeof(int)));
         MRS_HIP_TRY(hipMalloc(&h->d_tlo[which], (size_t)capt * sizeof(float4)));
@@ -2678,7 +2752,7 @@ int mrs_gicp_batch_compute_covariances(mrs_gicp_batch* h, int32_t which, int32_t
     if (h->search_core == 1 && h->cold_core == 1) {     // setting 3: the round-4 k-NN kernel (slower than the round-3 one on the bench's scans)
         MRS_REQUIRE(h->hier_valid[which], "search setting 3 was selected after set_clouds: set the clouds again");
         mrs::Scratch knn;
-        int st = knn.alloc((size_t)h->offs[which][h->n_pairs] * k * sizeof(int), s);
+        int st = knn.alloc(knn_ints(h->offs[which][h->n_pairs], h->n_pairs, k) * sizeof(int), s);
         if (st != MRS_OK) return st;
         if ((st = launch_knn_select(h, which, k, knn.as<int>(), s)) != MRS_OK) return st;
         hipLaunchKernelGGL(k_cov_from_knn, dim3((unsigned)((longest + 255) / 256), h->n_pairs), dim3(256), 0, s, (const float4*)h->d_pts[which],
@@ -2688,74 +2762,26 @@ int mrs_gicp_batch_compute_covariances(mrs_gicp_batch* h, int32_t which, int32_t
         if (which == 1) h->vox_res_built = 0.0;
         return MRS_OK;
     }
-    if (mrs::dev_env("MRS_KNN_DBG")) {
-        const int on = 1;
-        MRS_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_knn_dbg_on), &on, sizeof(on)));
+    int st = knn_dev_switches(s);
+    if (st != MRS_OK) return st;
+    // the neighbour indices pass from the selection to the covariance tail through scratch memory: clouds are processed in chunks so that
+    // it stays below ~512 MB (256 clouds x 120 k points x k = 15 would be 1.8 GB held by the scratch cache for the life of the process)
+    const int64_t per_cloud = (int64_t)(knn_ints(longest, 1, k) * sizeof(int));
+    const int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(h->n_pairs, (512ll << 20) / per_cloud));
+    mrs::Scratch knn;
+    if ((st = knn.alloc((size_t)chunk * per_cloud, s)) != MRS_OK) return st;
+    for (int c0 = 0; c0 < h->n_pairs; c0 += chunk) {
+        const int nc = std::min(chunk, h->n_pairs - c0);
+        // the kernels index knn by GLOBAL point number (knn_at: (offs[c] + 64 c) k with c counted from the chunk's first cloud): shift the
+        // chunk's buffer so that the chunk's first point lands on its start
+        int* const kn = knn.as<int>() - (size_t)h->offs[which][c0] * k;
+        const int64_t* const offs_c = h->d_offs[which] + c0;
+        launch_knn_cov(h, which, c0, nc, longest, k, kn, s);
+        hipLaunchKernelGGL(k_cov_from_knn, dim3((unsigned)((longest + 255) / 256), nc), dim3(256), 0, s, (const float4*)h->d_pts[which],
+                           offs_c, k, (const int*)kn, h->d_cov[which], d_knn_out);
     }
-    {
-        const char* const e = mrs::dev_env("MRS_KNN_REC");      // development aid, read per call (the tests flip it): 0 = no mini list
-        const int off = (e && atoi(e) == 0) ? 1 : 0;
-        static int cur = 0;
-        if (off != cur) {
-            MRS_HIP_TRY(hipStreamSynchronize(s));
-            MRS_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_knn_norec), &off, sizeof(off)));
-            cur = off;
-        }
-    }
-    static const char* const split_s = mrs::dev_env("MRS_KNN_SPLIT");      // development aid: 0 = selection and covariances in one kernel
-    if (!(split_s && atoi(split_s) == 0)) {
-        // the neighbour indices pass from the selection to the covariance tail through scratch memory: clouds are processed in chunks so that
-        // it stays below ~512 MB (256 clouds x 120 k points x k = 15 would be 1.8 GB held by the scratch cache for the life of the process)
-        const int64_t per_cloud = std::max<int64_t>(1, longest * k * (int64_t)sizeof(int));
-        const int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(h->n_pairs, (512ll << 20) / per_cloud));
-        mrs::Scratch knn;
-        int st = knn.alloc((size_t)chunk * per_cloud, s);
-        if (st != MRS_OK) return st;
-        for (int c0 = 0; c0 < h->n_pairs; c0 += chunk) {
-            const int nc = std::min(chunk, h->n_pairs - c0);
-            const dim3 g((unsigned)((longest + kNNThreads - 1) / kNNThreads), nc);
-            // the kernels index knn by GLOBAL point number: shift the chunk's buffer so that the chunk's first point lands on its start
-            int* const kn = knn.as<int>() - (size_t)h->offs[which][c0] * k;
-            const int64_t* const offs_c = h->d_offs[which] + c0;
-            const int* const tb_c = h->d_tile_base[which] + c0;
-            if (k <= 16)
-                hipLaunchKernelGGL((k_knn_cov<16, true>), g, dim3(kNNThreads), 0, s, h->d_pts[which], offs_c, tb_c,
-                                   h->d_tlo[which], h->d_thi[which], h->d_mlo[which], h->d_mhi[which], k, (double*)nullptr, kn);
-            else if (k <= 20)
-                hipLaunchKernelGGL((k_knn_cov<20, true>), g, dim3(kNNThreads), 0, s, h->d_pts[which], offs_c, tb_c,
-                                   h->d_tlo[which], h->d_thi[which], h->d_mlo[which], h->d_mhi[which], k, (double*)nullptr, kn);
-            else
-                hipLaunchKernelGGL((k_knn_cov<32, true>), g, dim3(kNNThreads), 0, s, h->d_pts[which], offs_c, tb_c,
-                                   h->d_tlo[which], h->d_thi[which], h->d_mlo[which], h->d_mhi[which], k, (double*)nullptr, kn);
-            hipLaunchKernelGGL(k_cov_from_knn, dim3((unsigned)((longest + 255) / 256), nc), dim3(256), 0, s, (const float4*)h->d_pts[which],
-                               offs_c, k, (const int*)kn, h->d_cov[which], d_knn_out);
-        }
-        MRS_HIP_TRY(hipGetLastError());
-        h->cov_valid[which] = true;
-        if (which == 1) h->vox_res_built = 0.0;
-        return MRS_OK;
-    }
-    if (k <= 16)
-        hipLaunchKernelGGL(k_knn_cov<16>, grid, dim3(kNNThreads), 0, s, h->d_pts[which], h->d_offs[which], h->d_tile_base[which],
-                           h->d_tlo[which], h->d_thi[which], h->d_mlo[which], h->d_mhi[which], k, h->d_cov[which], d_knn_out);
-    else if (k <= 20)
-        hipLaunchKernelGGL(k_knn_cov<20>, grid, dim3(kNNThreads), 0, s, h->d_pts[which], h->d_offs[which], h->d_tile_base[which],
-                           h->d_tlo[which], h->d_thi[which], h->d_mlo[which], h->d_mhi[which], k, h->d_cov[which], d_knn_out);
-    else
-        hipLaunchKernelGGL(k_knn_cov<32>, grid, dim3(kNNThreads), 0, s, h->d_pts[which], h->d_offs[which], h->d_tile_base[which],
-                           h->d_tlo[which], h->d_thi[which], h->d_mlo[which], h->d_mhi[which], k, h->d_cov[which], d_knn_out);
     MRS_HIP_TRY(hipGetLastError());
-    static const bool knn_dbg = mrs::dev_env("MRS_KNN_DBG") != nullptr;
-    if (knn_dbg) {
-        unsigned long long c[8];
-        MRS_HIP_TRY(hipStreamSynchronize(s));
-        MRS_HIP_TRY(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_knn_dbg), sizeof(c)));
-        const double w = (double)(c[6] ? c[6] : 1);
-        fprintf(stderr, "[knn dbg] per query wave: pass 1 groups of 8 candidates %.1f (list changed in %.1f), pass 2 groups %.1f, selection steps %.1f; %llu waves\n",
-                c[1] / w, c[2] / w, c[4] / w, c[5] / w, c[6]);
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        MRS_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_knn_dbg), z, sizeof(z)));
-    }
+    if ((st = knn_dbg_report(s)) != MRS_OK) return st;
     h->cov_valid[which] = true;
     if (which == 1) h->vox_res_built = 0.0;
     return MRS_OK;
@@ -3002,7 +3028,7 @@ int mrs_gicp_batch_linearize(mrs_gicp_batch* h, const double* h_poses, double* h
  * the given poses and with the batch's clouds / covariances, `reps` times each (the average goes to out_ms):
  *   [0] k_linearize, all 28 sums (phase 0)            [1] k_linearize, error only (an LM trial)
  *   [2] round-3 search of every point, warm           [3] k_nn_certify at an unchanged pose (everything certified)
- *   [4] round-4 search of every point, warm           [5] k-NN selection of the sources (k_knn_cov<.., SPLIT>)
+ *   [4] round-4 search of every point, warm           [5] k-NN selection of the sources (k_knn_cov)
  *   [6] k_cov_from_knn of the sources                 [7] k_nn_certify + work-list search at a pose moved by 1 mm along x
  * out_counts: [0] source points, [1] correspondences (d^2 < max_corr^2) at the poses, [2] queries on the work lists of [7]. */
 int mrs_gicp_batch_profile(mrs_gicp_batch* h, const double* h_poses, int32_t reps, float* out_ms, int64_t* out_counts, mrs_stream stream)
@@ -3133,19 +3159,8 @@ int mrs_gicp_batch_profile(mrs_gicp_batch* h, const double* h_poses, int32_t rep
     {   // k-NN selection + covariances of the sources
         const int k = h->prm.k;
         mrs::Scratch knn;
-        if ((st = knn.alloc(h->n_seed * k * sizeof(int), s)) != MRS_OK) return fail(st);
-        const dim3 grid((unsigned)((h->longest_src + kNNThreads - 1) / kNNThreads), P);
-        auto select = [&]() {
-            if (k <= 16)
-                hipLaunchKernelGGL((k_knn_cov<16, true>), grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_tile_base[0], h->d_tlo[0], h->d_thi[0],
-                                   h->d_mlo[0], h->d_mhi[0], k, (double*)nullptr, knn.as<int>());
-            else if (k <= 20)
-                hipLaunchKernelGGL((k_knn_cov<20, true>), grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_tile_base[0], h->d_tlo[0], h->d_thi[0],
-                                   h->d_mlo[0], h->d_mhi[0], k, (double*)nullptr, knn.as<int>());
-            else
-                hipLaunchKernelGGL((k_knn_cov<32, true>), grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_tile_base[0], h->d_tlo[0], h->d_thi[0],
-                                   h->d_mlo[0], h->d_mhi[0], k, (double*)nullptr, knn.as<int>());
-        };
+        if ((st = knn.alloc(knn_ints(h->n_seed, P, k) * sizeof(int), s)) != MRS_OK) return fail(st);
+        auto select = [&]() { launch_knn_cov(h, 0, 0, P, h->longest_src, k, knn.as<int>(), s); };
         if ((st = timed(out_ms[5], select)) != MRS_OK) return fail(st);
         if ((st = timed(out_ms[6], [&]() {
                  hipLaunchKernelGGL(k_cov_from_knn, dim3((unsigned)((h->longest_src + 255) / 256), P), dim3(256), 0, s, (const float4*)h->d_pts[0],
@@ -3274,43 +3289,26 @@ int mrs_pointfeat_batch(mrs_ctx* ctx, const float* d_points, int32_t stride_floa
         hipStream_t s = (hipStream_t)stream;
         int64_t longest = 0;
         for (int i = 0; i < batch; ++i) longest = std::max(longest, h_offsets[i + 1] - h_offsets[i]);
-        const dim3 grid((unsigned)((longest + kNNThreads - 1) / kNNThreads), batch);
         static const char* const core_s = mrs::dev_env("MRS_NN_CORE");      // development aid: 1 = the round-4 k-NN kernel (slower here)
-        if (core_s && atoi(core_s) == 1) {
-            mrs::Scratch knn;
-            st = knn.alloc((size_t)h_offsets[batch] * k * sizeof(int), s);
-            if (st == MRS_OK) st = launch_knn_select(h, 0, k, knn.as<int>(), s);
-            if (st == MRS_OK) {
-                hipLaunchKernelGGL(k_feat_from_knn, dim3((unsigned)((longest + 255) / 256), batch), dim3(256), 0, s, (const float4*)h->d_pts[0],
-                                   (const int64_t*)h->d_offs[0], k, (const int*)knn.as<int>(), d_knn, d_eigens, d_features, d_feat_planes);
-                if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-                    mrs::set_error("k_feat_from_knn launch failed");
-                    st = MRS_ERR_HIP;
-                }
-            }
-        } else if (core_s && atoi(core_s) == 2) {     // development aid: one kernel (selection + eigenvalues + features), the round-3 form
-            hipLaunchKernelGGL(k_knn_features<32>, grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_tile_base[0],
-                               h->d_tlo[0], h->d_thi[0], h->d_mlo[0], h->d_mhi[0], k, d_knn, d_eigens, d_features, d_feat_planes);
-        } else {
-            // default: the selection without the fp64 eigenvalue / feature state (k_knn_cov<32, SPLIT>: capped at 128 VGPRs = 4 waves per SIMD, the
-            // traversal is latency-bound), neighbour indices through a scratch buffer to k_feat_from_knn (same arithmetic, same order as the fused
-            // kernel).  64 scans: 20.1 ms against 26.6 for the one-kernel form (236 VGPRs, 2 waves per SIMD); split at 2 / 3 waves per SIMD: 27.5 / 22.5
-            mrs::Scratch knn;
-            st = knn.alloc((size_t)h_offsets[batch] * k * sizeof(int), s);
-            if (st == MRS_OK) {
-                hipLaunchKernelGGL((k_knn_cov<32, true>), grid, dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0], h->d_tile_base[0], h->d_tlo[0], h->d_thi[0],
-                                   h->d_mlo[0], h->d_mhi[0], k, (double*)nullptr, knn.as<int>());
-                hipLaunchKernelGGL(k_feat_from_knn, dim3((unsigned)((longest + 255) / 256), batch), dim3(256), 0, s, (const float4*)h->d_pts[0],
-                                   (const int64_t*)h->d_offs[0], k, (const int*)knn.as<int>(), d_knn, d_eigens, d_features, d_feat_planes);
-                if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-                    mrs::set_error("k_feat_from_knn launch failed");
-                    st = MRS_ERR_HIP;
-                }
+        // the selection (k_knn_cov<30>: 5 waves per SIMD, no fp64 state) hands the neighbour indices to k_feat_from_knn through a scratch buffer
+        // in blocks of 64 points, slot-major (knn_at)
+        mrs::Scratch knn;
+        st = knn.alloc(knn_ints(h_offsets[batch], batch, k) * sizeof(int), s);
+        if (st == MRS_OK) {
+            if (core_s && atoi(core_s) == 1) {
+                st = launch_knn_select(h, 0, k, knn.as<int>(), s);
+            } else if ((st = knn_dev_switches(s)) == MRS_OK) {
+                launch_knn_cov(h, 0, 0, batch, longest, k, knn.as<int>(), s);
+                st = knn_dbg_report(s);
             }
         }
-        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-            mrs::set_error("k_knn_features launch failed");
-            st = MRS_ERR_HIP;
+        if (st == MRS_OK) {
+            hipLaunchKernelGGL(k_feat_from_knn, dim3((unsigned)((longest + 255) / 256), batch), dim3(256), 0, s, (const float4*)h->d_pts[0],
+                               (const int64_t*)h->d_offs[0], k, (const int*)knn.as<int>(), d_knn, d_eigens, d_features, d_feat_planes);
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+                mrs::set_error("point-feature kernels failed: %s", hipGetErrorString(hipGetLastError()));
+                st = MRS_ERR_HIP;
+            }
         }
     }
     if (!cached) mrs_gicp_batch_destroy(h);
