@@ -343,7 +343,8 @@ __device__ __forceinline__ void knn_walk(const float4* __restrict__ pts, int n, 
             const int tt = ch * 64 + tl;
             float dmin;
             const bool mh = quads_hit(H.mlo[tt * 64 + lane], H.mhi[tt * 64 + lane], qlo, qhi, qT, wide, q, T, dmin);
-            const unsigned long long mmask = __ballot(mh);
+            // (minis past the cloud's end have empty boxes, at distance +inf -- which an infinite bound, a cloud smaller than k, would accept)
+            const unsigned long long mmask = __ballot(mh && (tt * 64 + lane) * 16 < n);
             const int cnt = __builtin_popcountll(mmask);
             unsigned long long left = mmask;         // ids(r) is asked for r = 0, 1, 2, ... in turn
             stream_minis(pts, n, cnt,
@@ -1497,8 +1498,41 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_select(const float4* __restr
     }
 }
 
-// G2 tail: covariance of the k neighbours (double, neighbours summed in (distance, index) order like k_knn_cov) + PLANE regularisation.
-// One point per lane; knn = k_knn_select's output.  knn_out optional, ORIGINAL indexing.
+// Second moments of a point's k neighbours in ONE pass over them: sums of d and d d^T with d = p - q taken about the query point q
+// (fp64; |d| is a neighbourhood radius, so the subtraction  sum d d^T - n m m^T  cancels a few digits of 16 at most), instead of a pass
+// for the mean and a second one about it: half the gathers (30 random 16-byte reads per point instead of 60).
+// cv: full symmetric 3x3 of  sum (p - mean)(p - mean)^T  (not yet divided); returns the number of neighbours.
+template <int KMAX, bool WANT_Z>
+__device__ __forceinline__ int neighbour_moments(const float4* __restrict__ pts, const int* __restrict__ nb /* slot s at nb[64 s] */, int k, const float4& q,
+                                                 double (&cv)[9], float (&nz)[KMAX])
+{
+    double sd[3] = {0, 0, 0}, sc[6] = {0, 0, 0, 0, 0, 0};
+    int cnt = 0;
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) {
+        if (WANT_Z) nz[s] = 0.0f;
+        if (s < k) {
+            const int j = nb[s << 6];
+            if (j >= 0) {
+                const float4 p = pts[j];
+                const double dx = (double)p.x - (double)q.x, dy = (double)p.y - (double)q.y, dz = (double)p.z - (double)q.z;
+                sd[0] += dx; sd[1] += dy; sd[2] += dz;
+                sc[0] += dx * dx; sc[1] += dx * dy; sc[2] += dx * dz;
+                sc[3] += dy * dy; sc[4] += dy * dz; sc[5] += dz * dz;
+                if (WANT_Z) nz[s] = p.z;
+                ++cnt;
+            }
+        }
+    }
+    const double inv = 1.0 / (double)cnt;
+    cv[0] = sc[0] - sd[0] * sd[0] * inv; cv[1] = sc[1] - sd[0] * sd[1] * inv; cv[2] = sc[2] - sd[0] * sd[2] * inv;
+    cv[4] = sc[3] - sd[1] * sd[1] * inv; cv[5] = sc[4] - sd[1] * sd[2] * inv; cv[8] = sc[5] - sd[2] * sd[2] * inv;
+    cv[3] = cv[1]; cv[6] = cv[2]; cv[7] = cv[5];
+    return cnt;
+}
+
+// G2 tail: covariance of the k neighbours (fp64) + PLANE regularisation.  One point per lane; knn = the selection's output (knn_at).
+// knn_out optional, ORIGINAL indexing.
 __global__ __launch_bounds__(256) void k_cov_from_knn(const float4* __restrict__ pts_all, const int64_t* __restrict__ offs, int k,
                                                      const int* __restrict__ knn, double* __restrict__ cov_all, int* __restrict__ knn_out)
 {
@@ -1508,39 +1542,25 @@ __global__ __launch_bounds__(256) void k_cov_from_knn(const float4* __restrict__
     const float4* pts = pts_all + o;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int* nb = knn + knn_at(o, c, i, k, 0);       // slot s at nb[64 s]: one row per wave and slot
-        double mean[3] = {0, 0, 0};
-        int cnt = 0;
-        for (int s = 0; s < k; ++s) {
-            const int j = nb[s << 6];
-            if (j < 0) continue;
-            const float4 p = pts[j];
-            mean[0] += (double)p.x; mean[1] += (double)p.y; mean[2] += (double)p.z;
-            ++cnt;
-        }
-        mean[0] /= cnt; mean[1] /= cnt; mean[2] /= cnt;
-        double cv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int s = 0; s < k; ++s) {
-            const int j = nb[s << 6];
-            if (j < 0) continue;
-            const float4 p = pts[j];
-            const double dx = (double)p.x - mean[0], dy = (double)p.y - mean[1], dz = (double)p.z - mean[2];
-            cv[0] += dx * dx; cv[1] += dx * dy; cv[2] += dx * dz;
-            cv[4] += dy * dy; cv[5] += dy * dz; cv[8] += dz * dz;
-        }
-        cv[3] = cv[1]; cv[6] = cv[2]; cv[7] = cv[5];
+        const float4 q = pts[i];
+        double cv[9];
+        float unused[32];
+        const int cnt = neighbour_moments<32, false>(pts, nb, k, q, cv, unused);
         for (int a = 0; a < 9; ++a) cv[a] /= cnt;
         double nrm[3];
         smallest_eigvec(cv, nrm);
         double* out = cov_all + kCovDoubles * (size_t)(o + i);      // the unit normal: C = I - 0.999 n n^T is rebuilt by the readers (cov6_from_normal)
         out[0] = nrm[0]; out[1] = nrm[1]; out[2] = nrm[2];
         if (knn_out) {
-            const int oi = __float_as_int(pts[i].w);
+            const int oi = __float_as_int(q.w);
             for (int s = 0; s < k; ++s) knn_out[(size_t)(o + oi) * k + s] = nb[s << 6] >= 0 ? __float_as_int(pts[nb[s << 6]].w) : -1;
         }
     }
 }
 
-// N1 tail: covariance / eigenvalues / the 13 features of every point from its k neighbours (neighbours summed in (distance, index) order)
+// N1 tail: covariance P^T P / (k - 1) (util.py:123-131) -> eigenvalues of the 3x3 and of its xy 2x2 block, both descending (util.py:134-158) ->
+// the 13 hand-crafted features of every point from its k neighbours.  Outputs in the caller's ORIGINAL point order; feat_planes (optional)
+// receives the channel-major [9][n] planes x,y,z,C,O,E,L2,dZ,vZ that generate_RINGplusplus feeds to the feature BEV (util.py:220-228).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_feat_from_knn(const float4* __restrict__ pts_all, const int64_t* __restrict__ offs, int k,
                                                       const int* __restrict__ knn, int* __restrict__ knn_out, float* __restrict__ eig_out,
                                                       float* __restrict__ feat_out, float* __restrict__ feat_planes)
@@ -1553,29 +1573,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         const int* nb = knn + knn_at(o, c, i, k, 0);       // slot s at nb[64 s]
         const float4 q = pts[i];
         const int oi = __float_as_int(q.w);
-        double mean[3] = {0, 0, 0};
+        double cv[9];
         float nz[32];
-        int cnt = 0;
-#pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            nz[s] = 0.0f;
-            if (s < k && nb[s << 6] >= 0) {
-                const float4 p = pts[nb[s << 6]];
-                mean[0] += (double)p.x; mean[1] += (double)p.y; mean[2] += (double)p.z;
-                nz[s] = p.z;
-                ++cnt;
-            }
-        }
-        mean[0] /= cnt; mean[1] /= cnt; mean[2] /= cnt;
-        double cv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int s = 0; s < k; ++s) {
-            if (nb[s << 6] < 0) continue;
-            const float4 p = pts[nb[s << 6]];
-            const double dx = (double)p.x - mean[0], dy = (double)p.y - mean[1], dz = (double)p.z - mean[2];
-            cv[0] += dx * dx; cv[1] += dx * dy; cv[2] += dx * dz;
-            cv[4] += dy * dy; cv[5] += dy * dz; cv[8] += dz * dz;
-        }
-        cv[3] = cv[1]; cv[6] = cv[2]; cv[7] = cv[5];
+        const int cnt = neighbour_moments<32, true>(pts, nb, k, q, cv, nz);
         for (int a = 0; a < 9; ++a) cv[a] /= (double)(cnt - 1);
         double w[3];
         sym3_eigvals(cv, w);
