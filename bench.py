@@ -681,9 +681,9 @@ def build_legs(device, chunks):
     out["ringpp_build"] = {"scans_per_s": S / tot * 1e3, "batch": S, "k": 30,
                            "ms": {"knn_k30_features": ms_feat, "feature_bev_9_planes": ms_fbev, "radon_6_channels": ms_radon, "row_fft_magnitude": ms_fft},
                            "knn_points_per_s": S * N_POINTS / ms_feat * 1e3,
-                           "bound": "k_knn_cov<32, SPLIT> + k_feat_from_knn: a latency-bound traversal (4 waves per SIMD) -- exact k = 30 nearest of every point "
-                                    "by culled brute force over the Morton-ordered cloud (two passes: the 32 smallest distances by a v_med3_f32 chain, then "
-                                    "the indices within the k-th distance from the minis pass 1 noted), eigenvalues in fp64; inputs stay L2 resident "
+                           "bound": "k_knn_cov<30> + k_feat_from_knn: VALU-bound (36 k vector instructions per 64 queries, 5 waves per SIMD) -- exact k = 30 nearest of every point "
+                                    "by culled brute force over the Morton-ordered cloud (pass 1: the 30 smallest distances by a v_med3_f32 chain fed from noted candidates; "
+                                    "pass 2: the indices within the k-th distance from the minis pass 1 noted; order by rank), eigenvalues in fp64; inputs stay L2 resident "
                                     "(16 B per point in, 36 B per point out), so no HBM or MFMA roof applies"}
     del planes, fb, sino, imgs
     # ingest: raw clouds as the ROS message delivers them (x, y, z, intensity), ~130 k points before down-sampling

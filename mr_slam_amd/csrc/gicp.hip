@@ -300,7 +300,7 @@ __device__ __forceinline__ void stream_minis(const float4* __restrict__ pts, int
 // do wave-wide bookkeeping first); a dead lane's bound is ignored.  NEAREST: tiles nearest first (pass 1: bounds shrink); otherwise tiles
 // and minis in index order (pass 2 without the list of pass 1: candidates must arrive in ascending index order).  rec(id): every mini visited.
 template <bool NEAREST, class Bound, class Visit, class Rec>
-__device__ __forceinline__ void knn_walk(const float4* __restrict__ pts, int n, const Hier& H, bool live, const float4& q, int home_tile,
+__device__ __forceinline__ int knn_walk(const float4* __restrict__ pts, int n, const Hier& H, bool live, const float4& q, int home_tile,
                                          Bound bound, Visit visit, Rec rec)
 {
     const int lane = threadIdx.x & 63;
@@ -308,6 +308,7 @@ __device__ __forceinline__ void knn_walk(const float4* __restrict__ pts, int n, 
     quad_box(live, q, qlo, qhi);
     const int nchunks = (H.ntiles + 63) >> 6;
     const int hc = min(home_tile, H.ntiles - 1) >> 6;
+    int visited = 0;        // tiles (returned: a development counter)
     for (int ci = 0; ci < nchunks; ++ci) {
         const int ch = !NEAREST ? ci : (ci == 0 ? hc : (ci <= hc ? ci - 1 : ci));       // NEAREST: the chunk of the wave's own tile first
         const int t = ch * 64 + lane;
@@ -339,6 +340,7 @@ __device__ __forceinline__ void knn_walk(const float4* __restrict__ pts, int n, 
                 tl = (int)__builtin_ctzll(tmask);
             }
             tmask &= ~(1ull << tl);
+            ++visited;
             if (lane == tl) key = INFINITY;
             const int tt = ch * 64 + tl;
             float dmin;
@@ -352,6 +354,7 @@ __device__ __forceinline__ void knn_walk(const float4* __restrict__ pts, int n, 
                          q.x, q.y, q.z, visit);
         }
     }
+    return visited;
 }
 
 // Exact 1-NN of P query points per lane over the Morton-ordered cloud tgt[0..m): squared distance and (sorted-space) index; `maxc2` is
@@ -670,6 +673,7 @@ __device__ void smallest_eigvec(const double* c, double* n_out)
 // development counters (MRS_KNN_DBG=1 prints them): per wave -- candidate groups of 8 visited in pass 1, groups in which some lane noted
 // a candidate, chain passes (seed excluded), pass 2 groups, entries ranked, query waves
 __device__ unsigned long long g_knn_dbg[8];
+__device__ unsigned long long g_knn_clk[4];       // wave clocks spent in the seed / the pass-1 walk / pass 2; tiles visited in pass 1
 __device__ int g_knn_dbg_on;       // set by the host when MRS_KNN_DBG is in the environment
 __device__ unsigned long long g_knn_trace[2 * 65536];       // MRS_KNN_DBG=1: (start, end) of every workgroup of the last launch on the 100 MHz wall clock
 __device__ int g_knn_norec;        // development aid (MRS_KNN_REC=0): pass 2 walks the hierarchy again instead of revisiting pass 1's minis
@@ -721,6 +725,7 @@ __device__ __forceinline__ int knn_two_pass(int* __restrict__ list, const float4
 {
     static_assert(KMAX <= 32 && KMAX >= kKnnBuf, "rank mask is 32 bits; the note buffer lives in the list");
     const int tid = (int)threadIdx.x;
+    const long long t_begin = g_knn_dbg_on ? clock64() : 0;
     float dk[KMAX];
 #pragma unroll
     for (int s = 0; s < KMAX; ++s) dk[s] = INFINITY;
@@ -741,6 +746,7 @@ __device__ __forceinline__ int knn_two_pass(int* __restrict__ list, const float4
     float* const buf = reinterpret_cast<float*>(list);
     int nb = 0;                     // candidates noted since the last flush
     int c_g1 = 0, c_ins = 0, c_chain = 0, c_g2 = 0;
+    const long long t_seed = g_knn_dbg_on ? clock64() : 0;
     auto flush = [&]() {
 #pragma unroll 1
         for (int s = 0; s < kKnnBuf; ++s) {
@@ -752,7 +758,7 @@ __device__ __forceinline__ int knn_two_pass(int* __restrict__ list, const float4
         nb = 0;
     };
     int nrec = 0;       // wave-uniform
-    knn_walk<true>(pts, n, H, live, q, home_tile,
+    const int c_tiles = knn_walk<true>(pts, n, H, live, q, home_tile,
                [&]() { if (__any(nb > 0)) flush(); return dk[KMAX - 1]; },       // before every tile: bounds up to date
                [&](int j0, const float (&dd)[8]) {
                    ++c_g1;
@@ -772,6 +778,7 @@ __device__ __forceinline__ int knn_two_pass(int* __restrict__ list, const float4
                    ++nrec;
                });
     if (__any(nb > 0)) flush();
+    const long long t_walk = g_knn_dbg_on ? clock64() : 0;
     // pass 2: the candidates within the k-th distance, home range included, in ascending index order
     const int kk = k < KMAX ? k : KMAX;
     float tau = dk[KMAX - 1];
@@ -815,6 +822,7 @@ __device__ __forceinline__ int knn_two_pass(int* __restrict__ list, const float4
     } else {
         knn_walk<false>(pts, n, H, live, q, 0, [&]() { return tau; }, visit2, [](int) {});
     }
+    const long long t_pass2 = g_knn_dbg_on ? clock64() : 0;
     cnt = min(cnt, kk);       // (cannot exceed it: nless candidates are closer than tau, at most room ties were taken)
     // order: rank = #{dk < d} + the equal ones placed before (entries arrive in ascending index order)
     int most = cnt;
@@ -825,6 +833,8 @@ __device__ __forceinline__ int knn_two_pass(int* __restrict__ list, const float4
         atomicAdd(&g_knn_dbg[4], (unsigned long long)c_g2); atomicAdd(&g_knn_dbg[5], (unsigned long long)most);
         atomicAdd(&g_knn_dbg[6], 1ull);
         atomicMax(&g_knn_dbg[7], (unsigned long long)c_g1); atomicMax(&g_knn_dbg[0], (unsigned long long)c_chain);
+        atomicAdd(&g_knn_clk[0], (unsigned long long)(t_seed - t_begin)); atomicAdd(&g_knn_clk[1], (unsigned long long)(t_walk - t_seed));
+        atomicAdd(&g_knn_clk[2], (unsigned long long)(t_pass2 - t_walk)); atomicAdd(&g_knn_clk[3], (unsigned long long)c_tiles);
     }
     unsigned used = 0;
     int j = cnt > 0 ? list[tid] : 0;
@@ -2364,6 +2374,10 @@ int knn_dbg_report(hipStream_t s)
                     "entries ranked %.1f; %llu waves; the busiest wave: %llu groups in pass 1, %llu chain passes\n", c[1] / w, c[2] / w, c[3] / w, c[4] / w, c[5] / w, c[6], c[7], c[0]);
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     MRS_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_knn_dbg), z, sizeof(z)));
+    unsigned long long ck[4];
+    MRS_HIP_TRY(hipMemcpyFromSymbol(ck, HIP_SYMBOL(g_knn_clk), sizeof(ck)));
+    fprintf(stderr, "[knn dbg] per query wave: clocks in the seed %.0f, the pass-1 walk %.0f, pass 2 %.0f; tiles visited in pass 1 %.1f\n", ck[0] / w, ck[1] / w, ck[2] / w, ck[3] / w);
+    MRS_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_knn_clk), z, sizeof(ck)));
     if (const char* path = getenv("MRS_KNN_TRACE_FILE")) {       // (start, end) of every workgroup of the launch just finished, raw uint64 pairs
         std::vector<unsigned long long> tr(2 * 65536);
         MRS_HIP_TRY(hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(g_knn_trace), tr.size() * sizeof(unsigned long long)));

@@ -55,6 +55,6 @@ del g, srcs, tgts
 from mr_slam_amd import pointfeat
 NS = int(os.environ.get("MRS_PMC_FEAT_SCANS", "64"))
 pts = whole[0, :NS].permute(0, 2, 1).reshape(NS * bench.N_POINTS, 3).contiguous()
-pointfeat.point_features(pts, np.arange(NS + 1, dtype=np.int64) * bench.N_POINTS, 30, want=("planes",))      # k_knn_features (RING++ front end)
+pointfeat.point_features(pts, np.arange(NS + 1, dtype=np.int64) * bench.N_POINTS, 30, want=("planes",))      # k_knn_cov<30> + k_feat_from_knn (RING++ front end)
 torch.cuda.synchronize()
 print("pmc targets done")
