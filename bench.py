@@ -508,7 +508,7 @@ def gicp_leg(device_index, rank, n_pairs, iters):
                                                           "note": "VALU-pipe busy fraction from the PMC pass of the same shape: profiles/*_pmc.json"},
         "k_nn_scan_g (round-4 search, every point, warm)": {"bound": "latency", "ms": kms["search_round4_all"], "queries_per_s": n_src / kms["search_round4_all"] * 1e3},
         "k_nn_certify (unchanged pose)": dict(hbm(n_src * 44, kms["certify"]), bound="hbm", note="16 B point + 4 B seed + 4 B bound in, 4 B index + 4 B bound out, "
-                                              "16 B neighbour (round 5: streamed from the copy k_linearize keeps beside the source point, index in .w): 44 B per source point"),
+                                              "16 B neighbour (gathered: keeping a copy beside the source point was built and bought nothing, DESIGN.md 4): 44 B per source point"),
         "certify + work-list search after a 1 mm step": {"ms": kms["certify_plus_worklist_1mm"], "worklist_queries": kcnt["worklist_queries_1mm"],
                                                          "share_of_points_searched": kcnt["worklist_queries_1mm"] / max(n_src, 1)},
         "k_knn_cov (selection)": dict(hbm(knn_bytes, kms["knn_select"]), bound="valu", clouds_per_s=n_pairs / kms["knn_select"] * 1e3),

@@ -271,9 +271,11 @@ __device__ __forceinline__ void cand_dist(const Cand8& a, int j0, int n, float q
     }
 }
 
-// the candidates of the minis `ids(r)`, r = 0 .. count - 1 (wave-uniform), 8 at a time: visit(first index, 8 squared distances)
+// the candidates of the minis `ids(r)`, r = 0 .. count - 1 (wave-uniform), 8 at a time: visit(first index, the 8 candidates).  The visitor
+// starts with cand_pin() on a coordinate of its query: its arithmetic then stays behind the requests for the next 8.
+__device__ __forceinline__ void cand_pin(float& x) { asm volatile("" : "+v"(x)); }      // (volatile asm statements keep their order)
 template <class Ids, class Visit>
-__device__ __forceinline__ void stream_minis(const float4* __restrict__ pts, int n, int count, Ids ids, float qx, float qy, float qz, Visit visit)
+__device__ __forceinline__ void stream_minis(const float4* __restrict__ pts, int count, Ids ids, Visit visit)
 {
     if (count <= 0) return;
     Cand8 A, B;
@@ -282,22 +284,17 @@ __device__ __forceinline__ void stream_minis(const float4* __restrict__ pts, int
     for (int r = 0; r < count; ++r) {
         cand_arrived(A);
         cand_request(B, pts, j0 + 8);
-        asm volatile("" : "+v"(qx));          // (the arithmetic on A reads qx: it stays behind the requests for B)
-        float dd[8];
-        cand_dist(A, j0, n, qx, qy, qz, dd);
-        visit(j0, dd);
+        visit(j0, A);
         cand_arrived(B);
         const int jn = r + 1 < count ? ids(r + 1) * 16 : j0;
         if (r + 1 < count) cand_request(A, pts, jn);
-        asm volatile("" : "+v"(qx));
-        cand_dist(B, j0 + 8, n, qx, qy, qz, dd);
-        visit(j0 + 8, dd);
+        visit(j0 + 8, B);
         j0 = jn;
     }
 }
 
 // Walk of the hierarchy for the 64 queries of a wave.  bound(): the lane's current bound (called by the whole wave before every tile; it may
-// do wave-wide bookkeeping first); a dead lane's bound is ignored.  NEAREST: tiles nearest first (pass 1: bounds shrink); otherwise tiles
+// do wave-wide bookkeeping first); a dead lane's bound is ignored.  visit(first index, 8 candidates): see stream_minis.  NEAREST: tiles nearest first (pass 1: bounds shrink); otherwise tiles
 // and minis in index order (pass 2 without the list of pass 1: candidates must arrive in ascending index order).  rec(id): every mini visited.
 template <bool NEAREST, class Bound, class Visit, class Rec>
 __device__ __forceinline__ int knn_walk(const float4* __restrict__ pts, int n, const Hier& H, bool live, const float4& q, int home_tile,
@@ -349,9 +346,7 @@ __device__ __forceinline__ int knn_walk(const float4* __restrict__ pts, int n, c
             const unsigned long long mmask = __ballot(mh && (tt * 64 + lane) * 16 < n);
             const int cnt = __builtin_popcountll(mmask);
             unsigned long long left = mmask;         // ids(r) is asked for r = 0, 1, 2, ... in turn
-            stream_minis(pts, n, cnt,
-                         [&](int) { const int m = (int)__builtin_ctzll(left); left &= left - 1; rec(tt * 64 + m); return tt * 64 + m; },
-                         q.x, q.y, q.z, visit);
+            stream_minis(pts, cnt, [&](int) { const int m = (int)__builtin_ctzll(left); left &= left - 1; rec(tt * 64 + m); return tt * 64 + m; }, visit);
         }
     }
     return visited;
@@ -360,6 +355,7 @@ __device__ __forceinline__ int knn_walk(const float4* __restrict__ pts, int n, c
 // Exact 1-NN of P query points per lane over the Morton-ordered cloud tgt[0..m): squared distance and (sorted-space) index; `maxc2` is
 // the rejection radius (inf = none).  seed: any valid target index per query (last pass's neighbour, or the Morton seed of a cold
 // start): its distance is the initial bound.  Waves are independent (no barrier inside).
+constexpr int kNNRejMax = 256;     // minis a wave of nn_scan may reject before it changes to the quad-box walk
 template <int P>
 __device__ __forceinline__ void nn_scan(const float4* __restrict__ tgt, int m, const Hier& H, float maxc2,
                                         const float (&qx)[P], const float (&qy)[P], const float (&qz)[P],
@@ -390,12 +386,17 @@ __device__ __forceinline__ void nn_scan(const float4* __restrict__ tgt, int m, c
         return w;
     };
     const int lane = threadIdx.x & 63;
-    for (int tb = 0; tb < H.ntiles; tb += 64) {
+    // A wave whose queries straddle a jump of the Morton curve has a box the size of the scene: every mini passes the two coarse tests and is
+    // then rejected by `need`, one dependent round trip each (such a workgroup lived 1.4 ms, the median one 0.08 ms: the tail of every
+    // launch, and most of a small one).  The walk counts its rejections; past kNNRejMax it is abandoned for the k-NN selection's walk
+    // (quad boxes, per-query tests at the jump, nearest tile first), which starts over with the bounds found so far.
+    int rejected = 0;
+    for (int tb = 0; tb < H.ntiles && rejected <= kNNRejMax; tb += 64) {
         const int t = tb + lane;
         bool hit = false;
         if (t < H.ntiles) hit = box_box_d2(H.tlo[t], H.thi[t], lo, hi) * 0.9999f <= reach;
         unsigned long long tmask = __ballot(hit);
-        while (tmask) {
+        while (tmask && rejected <= kNNRejMax) {
             const int tt = tb + (int)__builtin_ctzll(tmask);
             tmask &= tmask - 1;
             const bool mhit = box_box_d2(H.mlo[tt * 64 + lane], H.mhi[tt * 64 + lane], lo, hi) * 0.9999f <= reach;
@@ -403,7 +404,7 @@ __device__ __forceinline__ void nn_scan(const float4* __restrict__ tgt, int m, c
             while (mmask) {
                 const int mm = (int)__builtin_ctzll(mmask);
                 mmask &= mmask - 1;
-                if (!__any(need(H.mlo[tt * 64 + mm], H.mhi[tt * 64 + mm]))) continue;
+                if (!__any(need(H.mlo[tt * 64 + mm], H.mhi[tt * 64 + mm]))) { ++rejected; continue; }
                 const int j0 = tt * kTile + mm * 16;
                 float4 c16[16];        // all 16 candidates requested before the first use (wave-uniform addresses: scalar loads)
 #pragma unroll
@@ -421,6 +422,22 @@ __device__ __forceinline__ void nn_scan(const float4* __restrict__ tgt, int m, c
                     }
                 }
             }
+        }
+    }
+    if (rejected > kNNRejMax) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const float4 q = make_float4(qx[p], qy[p], qz[p], 0.f);
+            const int home_tile = __builtin_amdgcn_readfirstlane(max(seed[p], 0)) >> 10;
+            knn_walk<true>(tgt, m, H, live[p], q, home_tile, [&]() { return fminf(best[p], maxc2); },
+                           [&](int j0, const Cand8& cand) {
+                               float x = q.x, d[8];
+                               cand_pin(x);
+                               cand_dist(cand, j0, m, x, q.y, q.z, d);
+                               const float mn = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])), fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
+                               if (live[p] && mn < best[p]) { best[p] = mn; grp[p] = j0; }
+                           },
+                           [](int) {});
         }
     }
     // resolve the index inside the winning group of 8
@@ -675,6 +692,7 @@ __device__ void smallest_eigvec(const double* c, double* n_out)
 __device__ unsigned long long g_knn_dbg[8];
 __device__ unsigned long long g_knn_clk[4];       // wave clocks spent in the seed / the pass-1 walk / pass 2; tiles visited in pass 1
 __device__ int g_knn_dbg_on;       // set by the host when MRS_KNN_DBG is in the environment
+__device__ unsigned long long g_nn_trace[2 * 65536];        // the same for k_nn_scan (MRS_NN_TRACE_FILE, written by mrs_gicp_batch_profile)
 __device__ unsigned long long g_knn_trace[2 * 65536];       // MRS_KNN_DBG=1: (start, end) of every workgroup of the last launch on the 100 MHz wall clock
 __device__ int g_knn_norec;        // development aid (MRS_KNN_REC=0): pass 2 walks the hierarchy again instead of revisiting pass 1's minis
 
@@ -760,8 +778,11 @@ __device__ __forceinline__ int knn_two_pass(int* __restrict__ list, const float4
     int nrec = 0;       // wave-uniform
     const int c_tiles = knn_walk<true>(pts, n, H, live, q, home_tile,
                [&]() { if (__any(nb > 0)) flush(); return dk[KMAX - 1]; },       // before every tile: bounds up to date
-               [&](int j0, const float (&dd)[8]) {
+               [&](int j0, const Cand8& cand) {
                    ++c_g1;
+                   float qx = q.x, dd[8];
+                   cand_pin(qx);
+                   cand_dist(cand, j0, n, qx, q.y, q.z, dd);
                    const float T = dk[KMAX - 1];
                    const float mn = fminf(fminf(fminf(dd[0], dd[1]), fminf(dd[2], dd[3])), fminf(fminf(dd[4], dd[5]), fminf(dd[6], dd[7])));
                    if (!__any(live && mn < T)) return;
@@ -793,8 +814,11 @@ __device__ __forceinline__ int knn_two_pass(int* __restrict__ list, const float4
     if (!live) tau = -1.0f;
     const int room = kk - nless;                  // exact ties with tau that belong to the k nearest
     int cnt = 0, nt = 0;
-    auto visit2 = [&](int j0, const float (&dd)[8]) {
+    auto visit2 = [&](int j0, const Cand8& cand) {
         ++c_g2;
+        float qx = q.x, dd[8];
+        cand_pin(qx);
+        cand_dist(cand, j0, n, qx, q.y, q.z, dd);
         const float mn = fminf(fminf(fminf(dd[0], dd[1]), fminf(dd[2], dd[3])), fminf(fminf(dd[4], dd[5]), fminf(dd[6], dd[7])));
         if (!__any(mn <= tau)) return;
 #pragma unroll
@@ -818,7 +842,7 @@ __device__ __forceinline__ int knn_two_pass(int* __restrict__ list, const float4
         if (lane < nrec) rec_ids[rank] = id;
         nnc::wave_lds_sync();
         // (no box test: nearly every one of them holds a candidate of some lane, and the test would be a round trip per mini)
-        stream_minis(pts, n, nrec, [&](int r) { return __builtin_amdgcn_readfirstlane(rec_ids[r]); }, q.x, q.y, q.z, visit2);
+        stream_minis(pts, nrec, [&](int r) { return __builtin_amdgcn_readfirstlane(rec_ids[r]); }, visit2);
     } else {
         knn_walk<false>(pts, n, H, live, q, 0, [&]() { return tau; }, visit2, [](int) {});
     }
@@ -1030,6 +1054,8 @@ __global__ __launch_bounds__(kNNThreads) void k_nn_scan(
     float glo[3];
     const float gsc = morton_grid(tgt_bbox, pair, glo);
     const int per_block = kNNThreads * P;
+    const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if (g_knn_dbg_on && threadIdx.x == 0 && wg < 65536) g_nn_trace[2 * wg] = wall_clock64();
     for (int base = blockIdx.x * per_block; base < n; base += gridDim.x * per_block) {
         float qx[P], qy[P], qz[P];
         int si[P], seed[P];
@@ -1056,6 +1082,10 @@ __global__ __launch_bounds__(kNNThreads) void k_nn_scan(
                 nn_seed[so + si[p]] = bidx[p];
                 if (lb_out) lb_out[so + si[p]] = 0.0f;     // this search leaves no certificate
             }
+    }
+    if (g_knn_dbg_on && wg < 65536) {
+        __syncthreads();
+        if (threadIdx.x == 0) g_nn_trace[2 * wg + 1] = wall_clock64();
     }
 }
 
@@ -1369,6 +1399,8 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(4, 4
     float glo[3];
     const float gsc = morton_grid(tgt_bbox, pair, glo);
     nnc::GrpLds& L = lds[threadIdx.x >> 6];
+    const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if (g_knn_dbg_on && threadIdx.x == 0 && wg < 65536) g_nn_trace[2 * wg] = wall_clock64();
     for (int base = 0; base < n; base += kNNThreads) {
         const unsigned long long t_wave = PROF ? __builtin_readcyclecounter() : 0ull;
         const int w = base + (int)threadIdx.x;
@@ -1419,6 +1451,10 @@ __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(4, 4
             // every point that was not evaluated lies beyond the final radius (radii only shrink while the search runs)
             C.lb[so + i] = bidx >= 0 ? fminf(sqrtf(second), sqrtf(radius2()) * 0.9999f) : 0.0f;
         }
+    }
+    if (g_knn_dbg_on && wg < 65536) {
+        __syncthreads();
+        if (threadIdx.x == 0) g_nn_trace[2 * wg + 1] = wall_clock64();
     }
 }
 
@@ -3120,7 +3156,20 @@ int mrs_gicp_batch_profile(mrs_gicp_batch* h, const double* h_poses, int32_t rep
     auto fail = [&](int code) { return code; };      // `guard` cleans up
     if ((st = upload(0, 0.0)) != MRS_OK) return fail(st);
     round3();                                         // seeds + correspondences at the poses
+    if ((st = knn_dev_switches(s)) != MRS_OK) return fail(st);
     if ((st = timed(out_ms[2], round3)) != MRS_OK) return fail(st);
+    // MRS_NN_TRACE_FILE: (start, end) of every workgroup of the last k_nn_scan launch (MRS_NN_TRACE_KERNEL=4: of k_nn_scan_g over every point), raw uint64 pairs
+    auto dump_trace = [&](int which) -> int {
+        const char* path = mrs::dev_env("MRS_NN_TRACE_FILE");
+        const char* k = mrs::dev_env("MRS_NN_TRACE_KERNEL");
+        if (!path || (k ? atoi(k) : 3) != which) return MRS_OK;
+        std::vector<unsigned long long> tr(2 * 65536);
+        MRS_HIP_TRY(hipStreamSynchronize(s));
+        MRS_HIP_TRY(hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(g_nn_trace), tr.size() * sizeof(unsigned long long)));
+        if (FILE* f = fopen(path, "wb")) { fwrite(tr.data(), sizeof(unsigned long long), tr.size(), f); fclose(f); }
+        return MRS_OK;
+    };
+    if ((st = dump_trace(3)) != MRS_OK) return fail(st);
     if ((st = timed(out_ms[0], [&]() {
              launch_linearize(lin_grid, s, h->d_pts[0], h->d_offs[0], h->d_cov[0], h->d_pts[1], h->d_offs[1], h->d_cov[1],
                                 h->d_state, h->d_corr, h->d_partial, h->max_blocks);
@@ -3133,6 +3182,7 @@ int mrs_gicp_batch_profile(mrs_gicp_batch* h, const double* h_poses, int32_t rep
         out_counts[0] = (int64_t)h->n_seed; out_counts[1] = c;
     }
     if ((st = timed(out_ms[4], round4_all)) != MRS_OK) return fail(st);      // leaves certificates at the poses
+    if ((st = dump_trace(4)) != MRS_OK) return fail(st);
     store_pose();
     if ((st = timed(out_ms[3], certify)) != MRS_OK) return fail(st);
     if ((st = upload(1, 0.0)) != MRS_OK) return fail(st);
