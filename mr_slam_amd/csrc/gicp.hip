@@ -2869,9 +2869,12 @@ static int ensure_state(mrs_gicp_batch* h)
     // workgroups of the reduction kernels (k_linearize, k_linearize_voxel, k_fitness) per pair: every workgroup walks kLinChunks blocks of 1024
     // points before its 28 wave reductions + LDS round (one per 1024 points, the ds_bpermute butterflies were 38 % of the LDS pipe's time and
     // a third of the kernel's instructions: profiles/r04_pmc.json).  The partial sums are added in workgroup order (k_lm_update): a fixed order
-    // for a given cloud size, the same for every search setting.
+    // for a given cloud size and batch size, the same for every search setting.
+    // A small batch (the node's one pair at a time: 39 blocks of 1024 points) cannot afford that: 10 workgroups on 256 compute units; below four
+    // workgroups per compute unit every block of 1024 points gets its own workgroup (k_linearize 25.7 -> 11 us per launch for one pair of 39 k points).
     static const char* const ch_s = mrs::dev_env("MRS_LIN_CHUNKS");
-    const int chunks = ch_s ? std::max(1, atoi(ch_s)) : kLinChunks;
+    const int cus = h->ctx->num_cu > 0 ? h->ctx->num_cu : 256;
+    const int chunks = ch_s ? std::max(1, atoi(ch_s)) : ((int64_t)h->n_pairs * blocks_for_points((int)longest) >= (int64_t)4 * kLinChunks * cus ? kLinChunks : 1);
     const int mb = (blocks_for_points((int)longest) + chunks - 1) / chunks;
     h->longest_src = (int)longest;
     if (!h->d_state) {
@@ -3247,22 +3250,25 @@ int mrs_gicp_batch_fitness(mrs_gicp_batch* h, const double* h_poses, double max_
     mrs::Scratch poses, part;
     st = poses.alloc((size_t)h->n_pairs * 16 * sizeof(double), s);
     if (st != MRS_OK) return st;
-    st = part.alloc((size_t)h->n_pairs * h->max_blocks * 2 * sizeof(double), s);
+    // one round of the search (512 source points) per workgroup: the reduction kernels' grid (max_blocks: up to 4096 points per workgroup) left one
+    // pair of 39 k points to 10 workgroups, 337 us for a search that takes 90
+    const int fb = std::max(1, (h->longest_src + 2 * kNNThreads - 1) / (2 * kNNThreads));
+    st = part.alloc((size_t)h->n_pairs * fb * 2 * sizeof(double), s);
     if (st != MRS_OK) return st;
     // pageable host memory: a blocking copy (hipMemcpyAsync from a caller's stack array may be deferred past the launch)
     MRS_HIP_TRY(hipStreamSynchronize(s));
     MRS_HIP_TRY(hipMemcpy(poses.p, h_poses, (size_t)h->n_pairs * 16 * sizeof(double), hipMemcpyHostToDevice));
-    MRS_HIP_TRY(hipMemsetAsync(part.p, 0, (size_t)h->n_pairs * h->max_blocks * 2 * sizeof(double), s));
-    hipLaunchKernelGGL(k_fitness, dim3(h->max_blocks, h->n_pairs), dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0],
+    MRS_HIP_TRY(hipMemsetAsync(part.p, 0, (size_t)h->n_pairs * fb * 2 * sizeof(double), s));
+    hipLaunchKernelGGL(k_fitness, dim3(fb, h->n_pairs), dim3(kNNThreads), 0, s, h->d_pts[0], h->d_offs[0],
                        h->d_pts[1], h->d_offs[1], h->d_tile_base[1], h->d_tlo[1], h->d_thi[1], h->d_mlo[1], h->d_mhi[1], poses.as<double>(), max_range,
-                       part.as<double>(), h->max_blocks, (const int*)h->d_seed);
+                       part.as<double>(), fb, (const int*)h->d_seed);
     MRS_HIP_TRY(hipGetLastError());
-    std::vector<double> hp((size_t)h->n_pairs * h->max_blocks * 2);
+    std::vector<double> hp((size_t)h->n_pairs * fb * 2);
     MRS_HIP_TRY(hipMemcpyAsync(hp.data(), part.p, hp.size() * sizeof(double), hipMemcpyDeviceToHost, s));
     MRS_HIP_TRY(hipStreamSynchronize(s));
     for (int p = 0; p < h->n_pairs; ++p) {
         double sum = 0, cnt = 0;
-        for (int b = 0; b < h->max_blocks; ++b) { sum += hp[((size_t)p * h->max_blocks + b) * 2]; cnt += hp[((size_t)p * h->max_blocks + b) * 2 + 1]; }
+        for (int b = 0; b < fb; ++b) { sum += hp[((size_t)p * fb + b) * 2]; cnt += hp[((size_t)p * fb + b) * 2 + 1]; }
         h_scores[p] = cnt > 0 ? sum / cnt : DBL_MAX;  // pcl: std::numeric_limits<double>::max() when empty
     }
     return MRS_OK;
