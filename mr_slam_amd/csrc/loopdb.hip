@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_sig_nearest(const float* __restrict__ q
 // rows: 120-point inverse transforms as two in-register 60-point codelets (even / odd samples; 80 lanes) + one radix-2 step;
 // columns: 40-point direct transforms (192 k complex multiply-adds spread over 960 work items, the lane's 40 inputs in registers).
 constexpr int kPR = 40, kPS = 120, kPhaseThreads = 512;
-__global__ __launch_bounds__(kPhaseThreads) void k_disco_phase_one(const float2* __restrict__ spectra, const unsigned long long* __restrict__ best,
+__global__ __launch_bounds__(kPhaseThreads) void k_disco_phase_one(const float2* __restrict__ spectra, unsigned long long* __restrict__ best,
                                                                    const float2* __restrict__ cur, const float2* __restrict__ tw,
                                                                    int* __restrict__ out_index, float* __restrict__ out_d2, int* __restrict__ out_arg)
 {
@@ -74,7 +74,8 @@ __global__ __launch_bounds__(kPhaseThreads) void k_disco_phase_one(const float2*
     __shared__ float bv[kPhaseThreads / 64];
     __shared__ int bi[kPhaseThreads / 64];
     const int t = threadIdx.x;
-    const int idx = (int)(unsigned)(*best & 0xffffffffull);
+    const unsigned long long won = *best;                      // (distance bits, index) of the nearest signature
+    const int idx = (int)(unsigned)(won & 0xffffffffull);
     const float2* a = spectra + (size_t)idx * kPR * kPS;
     for (int i = t; i < kPR * kPS; i += kPhaseThreads) {
         const float2 x = a[i], y = cur[i];                     // x conj(y)
@@ -136,9 +137,13 @@ __global__ __launch_bounds__(kPhaseThreads) void k_disco_phase_one(const float2*
     if (t == 0) {
         for (int w = 1; w < kPhaseThreads / 64; ++w)
             if (bv[w] > bestv || (bv[w] == bestv && bi[w] < bidx)) { bestv = bv[w]; bidx = bi[w]; }
+        // the three results go straight to pinned host memory (no copy after the kernel: the stream synchronisation that follows makes them
+        // visible), and `best` is armed for the next query (no memset before it)
         *out_arg = bidx;
         *out_index = idx;
-        *out_d2 = __uint_as_float((unsigned)(*best >> 32));
+        *out_d2 = __uint_as_float((unsigned)(won >> 32));
+        __threadfence_system();
+        *best = ~0ull;
     }
 }
 
@@ -153,9 +158,9 @@ struct mrs_loopdb {
     size_t in_floats = 0;                     // floats of a descriptor in the reference's form (what append / query take)
     float* d_entries = nullptr;               // RING / RING++: [cap + 1][C] DMA-tiled planes (one entry of slack); DiSCO: spectra [cap][R][S] complex64
     float* d_sigs = nullptr;                  // DiSCO: [cap][dim]
-    float* d_dist = nullptr;                  // [cap]
-    int32_t* d_angle = nullptr;               // [cap]
-    float* h_dist = nullptr;                  // pinned [cap]
+    float* d_dist = nullptr;                  // [2 cap]: [n] distances, [n] angles
+    int32_t* d_angle = nullptr;               // = d_dist + n of the query at hand (one allocation, one copy)
+    float* h_dist = nullptr;                  // pinned [2 cap]
     int32_t* h_angle = nullptr;
     float* d_in = nullptr;                    // one descriptor in the reference's form (device copy of a host argument)
     float* d_tmp = nullptr;                   // RING++: the normalised channels
@@ -180,9 +185,7 @@ void free_arrays(mrs_loopdb* db)
     if (db->d_entries) (void)hipFree(db->d_entries);
     if (db->d_sigs) (void)hipFree(db->d_sigs);
     if (db->d_dist) (void)hipFree(db->d_dist);
-    if (db->d_angle) (void)hipFree(db->d_angle);
     if (db->h_dist) (void)hipHostFree(db->h_dist);
-    if (db->h_angle) (void)hipHostFree(db->h_angle);
     db->d_entries = db->d_sigs = db->d_dist = nullptr;
     db->d_angle = nullptr; db->h_dist = nullptr; db->h_angle = nullptr;
 }
@@ -199,10 +202,10 @@ int reserve_locked(mrs_loopdb* db, int want)
     MRS_HIP_TRY(hipMalloc(&ne, ((size_t)cap + slack) * db->entry_floats * sizeof(float)));
     if (slack) MRS_HIP_TRY(hipMemsetAsync(ne + (size_t)cap * db->entry_floats, 0, db->entry_floats * sizeof(float), db->s));
     if (db->kind == MRS_LOOPDB_DISCO) MRS_HIP_TRY(hipMalloc(&ns, (size_t)cap * db->sig_dim * sizeof(float)));
-    MRS_HIP_TRY(hipMalloc(&nd, (size_t)cap * sizeof(float)));
-    MRS_HIP_TRY(hipMalloc(&na, (size_t)cap * sizeof(int32_t)));
-    MRS_HIP_TRY(hipHostMalloc(&hd, (size_t)cap * sizeof(float), hipHostMallocDefault));
-    MRS_HIP_TRY(hipHostMalloc(&ha, (size_t)cap * sizeof(int32_t), hipHostMallocDefault));
+    // distances and angles of a query lie back to back ([n] floats, [n] ints: the angles start at element n, wherever n stands) so that ONE copy
+    // brings both to the host; d_dist / h_dist own the 2 x cap elements, d_angle / h_angle are not separate allocations
+    MRS_HIP_TRY(hipMalloc(&nd, (size_t)2 * cap * sizeof(float)));
+    MRS_HIP_TRY(hipHostMalloc(&hd, (size_t)2 * cap * sizeof(float), hipHostMallocDefault));
     if (db->n > 0) {
         MRS_HIP_TRY(hipMemcpyAsync(ne, db->d_entries, (size_t)db->n * db->entry_floats * sizeof(float), hipMemcpyDeviceToDevice, db->s));
         if (ns) MRS_HIP_TRY(hipMemcpyAsync(ns, db->d_sigs, (size_t)db->n * db->sig_dim * sizeof(float), hipMemcpyDeviceToDevice, db->s));
@@ -291,12 +294,12 @@ int mrs_loopdb_create(mrs_ctx* ctx, int32_t kind, int32_t channels, int32_t capa
     LDB_TRY(hipStreamCreateWithFlags(&db->s, hipStreamNonBlocking));
     LDB_TRY(hipEventCreateWithFlags(&db->ev_in, hipEventDisableTiming));
     LDB_TRY(hipEventCreateWithFlags(&db->ev_out, hipEventDisableTiming));
-    db->stage_bytes = std::max(db->in_floats, (size_t)db->sig_dim) * sizeof(float);
+    db->stage_bytes = (kind == MRS_LOOPDB_DISCO ? db->in_floats + (size_t)db->sig_dim : db->in_floats) * sizeof(float);      // DiSCO: signature | spectrum in one slot
     for (Pinned& p : db->stage) {
         LDB_TRY(hipHostMalloc(&p.p, db->stage_bytes, hipHostMallocDefault));
         LDB_TRY(hipEventCreateWithFlags(&p.ev, hipEventDisableTiming));
     }
-    LDB_TRY(hipMalloc(&db->d_in, std::max(db->in_floats, (size_t)db->sig_dim) * sizeof(float)));
+    LDB_TRY(hipMalloc(&db->d_in, (db->in_floats + (size_t)db->sig_dim) * sizeof(float)));
     LDB_TRY(hipMalloc(&db->d_tmp, db->in_floats * sizeof(float)));
     LDB_TRY(hipMalloc(&db->d_query, std::max((size_t)channels * kSpecFloats, db->entry_floats) * sizeof(float)));
     if (kind == MRS_LOOPDB_DISCO) {
@@ -306,6 +309,7 @@ int mrs_loopdb_create(mrs_ctx* ctx, int32_t kind, int32_t channels, int32_t capa
         LDB_TRY(hipMalloc(&db->d_tw, tw.size() * sizeof(float)));
         LDB_TRY(hipMemcpy(db->d_tw, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
         LDB_TRY(hipMalloc(&db->d_best, sizeof(unsigned long long)));
+        LDB_TRY(hipMemset(db->d_best, 0xff, sizeof(unsigned long long)));       // armed; k_disco_phase_one re-arms it after every query
         LDB_TRY(hipMalloc(&db->d_small, 4 * sizeof(int32_t)));
         LDB_TRY(hipHostMalloc(&db->h_small, 4 * sizeof(int32_t), hipHostMallocDefault));
     }
@@ -411,10 +415,11 @@ int mrs_loopdb_query(mrs_loopdb* db, const void* descriptor, int32_t form, float
     if (n == 0) return MRS_OK;                             // `for idx in range(0)`: no candidates, no work
     int st = to_half_spectrum(db, descriptor, form, db->d_query, (hipStream_t)stream);
     if (st != MRS_OK) return st;
+    db->d_angle = reinterpret_cast<int32_t*>(db->d_dist + n);
+    db->h_angle = reinterpret_cast<int32_t*>(db->h_dist + n);
     st = mrs_ring_corr_fft_sweep_tiled(db->ctx, db->d_query, db->d_entries, n, db->channels, db->d_dist, db->d_angle, db->s);
     if (st != MRS_OK) return st;
-    MRS_HIP_TRY(hipMemcpyAsync(db->h_dist, db->d_dist, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, db->s));
-    MRS_HIP_TRY(hipMemcpyAsync(db->h_angle, db->d_angle, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, db->s));
+    MRS_HIP_TRY(hipMemcpyAsync(db->h_dist, db->d_dist, (size_t)2 * n * sizeof(float), hipMemcpyDeviceToHost, db->s));
     MRS_HIP_TRY(hipStreamSynchronize(db->s));
     // `if dist < cfg.dist_threshold: idxs.append(idx) ...` in index order (main_RING.py:133-140)
     int cnt = 0;
@@ -472,13 +477,18 @@ int mrs_loopdb_query_disco(mrs_loopdb* db, const float* signature, const float* 
         st = join_in(db, (hipStream_t)stream);
         if (st != MRS_OK) return st;
     } else {
-        st = upload(db, signature, (size_t)db->sig_dim * sizeof(float), db->d_in);
-        if (st != MRS_OK) return st;
-        st = upload(db, spectrum, db->entry_floats * sizeof(float), db->d_query);
-        if (st != MRS_OK) return st;
-        sig = db->d_in; spec = db->d_query;
+        // signature | spectrum through ONE pinned slot and ONE copy
+        Pinned& p = db->stage[db->stage_next];
+        db->stage_next = (db->stage_next + 1) % kStageSlots;
+        if (p.used) MRS_HIP_TRY(hipEventSynchronize(p.ev));
+        const size_t sb = (size_t)db->sig_dim * sizeof(float), eb = db->entry_floats * sizeof(float);
+        memcpy(p.p, signature, sb);
+        memcpy(static_cast<char*>(p.p) + sb, spectrum, eb);
+        MRS_HIP_TRY(hipMemcpyAsync(db->d_in, p.p, sb + eb, hipMemcpyHostToDevice, db->s));
+        MRS_HIP_TRY(hipEventRecord(p.ev, db->s));
+        p.used = true;
+        sig = db->d_in; spec = db->d_in + db->sig_dim;
     }
-    MRS_HIP_TRY(hipMemsetAsync(db->d_best, 0xff, sizeof(unsigned long long), db->s));
     const int blocks = std::max(1, std::min((n + 3) / 4, 4 * (db->ctx->num_cu > 0 ? db->ctx->num_cu : 256)));
     hipLaunchKernelGGL(k_sig_nearest, dim3(blocks), dim3(256), 0, db->s, sig, db->d_sigs, n, db->sig_dim, db->d_best);
     const size_t lds = (size_t)(2 * db->R * db->S + db->S + db->R) * sizeof(float2);
@@ -487,10 +497,9 @@ int mrs_loopdb_query_disco(mrs_loopdb* db, const float* signature, const float* 
         db->phase_attr_set = true;
     }
     hipLaunchKernelGGL(k_disco_phase_one, dim3(1), dim3(kPhaseThreads), lds, db->s, reinterpret_cast<const float2*>(db->d_entries), db->d_best,
-                       reinterpret_cast<const float2*>(spec), reinterpret_cast<const float2*>(db->d_tw), db->d_small,
-                       reinterpret_cast<float*>(db->d_small + 1), db->d_small + 2);
+                       reinterpret_cast<const float2*>(spec), reinterpret_cast<const float2*>(db->d_tw), db->h_small,
+                       reinterpret_cast<float*>(db->h_small + 1), db->h_small + 2);
     MRS_HIP_TRY(hipGetLastError());
-    MRS_HIP_TRY(hipMemcpyAsync(db->h_small, db->d_small, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, db->s));
     MRS_HIP_TRY(hipStreamSynchronize(db->s));
     *h_index = db->h_small[0];
     memcpy(h_dist2, &db->h_small[1], sizeof(float));
