@@ -3360,25 +3360,30 @@ int mrs_pointfeat_batch(mrs_ctx* ctx, const float* d_points, int32_t stride_floa
         int64_t longest = 0;
         for (int i = 0; i < batch; ++i) longest = std::max(longest, h_offsets[i + 1] - h_offsets[i]);
         static const char* const core_s = mrs::dev_env("MRS_NN_CORE");      // development aid: 1 = the round-4 k-NN kernel (slower here)
+        const bool core4 = core_s && atoi(core_s) == 1;
         // the selection (k_knn_cov<30>: 5 waves per SIMD, no fp64 state) hands the neighbour indices to k_feat_from_knn through a scratch buffer
-        // in blocks of 64 points, slot-major (knn_at)
+        // in blocks of 64 points, slot-major (knn_at); clouds go through in chunks that keep the buffer below 1 GiB (64 scans of 120 k points
+        // at k = 30 are 0.92 GB: one chunk)
+        const int64_t per_cloud = (int64_t)(knn_ints(longest, 1, k) * sizeof(int));
+        const char* const lim_s = mrs::dev_env("MRS_FEAT_CHUNK_MB");        // development aid (the tests): a small limit forces several chunks
+        const int64_t limit = lim_s ? std::max<int64_t>(1, atoll(lim_s)) << 20 : (1ll << 30);
+        const int chunk = core4 ? batch : (int)std::max<int64_t>(1, std::min<int64_t>(batch, limit / per_cloud));
         mrs::Scratch knn;
-        st = knn.alloc(knn_ints(h_offsets[batch], batch, k) * sizeof(int), s);
-        if (st == MRS_OK) {
-            if (core_s && atoi(core_s) == 1) {
-                st = launch_knn_select(h, 0, k, knn.as<int>(), s);
-            } else if ((st = knn_dev_switches(s)) == MRS_OK) {
-                launch_knn_cov(h, 0, 0, batch, longest, k, knn.as<int>(), s);
-                st = knn_dbg_report(s);
-            }
+        st = knn.alloc(core4 ? knn_ints(h_offsets[batch], batch, k) * sizeof(int) : (size_t)chunk * per_cloud, s);
+        if (st == MRS_OK && !core4) st = knn_dev_switches(s);
+        for (int c0 = 0; st == MRS_OK && c0 < batch; c0 += chunk) {
+            const int nc = std::min(chunk, batch - c0);
+            int* const kn = knn.as<int>() - (size_t)h_offsets[c0] * k;       // the kernels index by global point number (see compute_covariances)
+            if (core4) st = launch_knn_select(h, 0, k, kn, s);
+            else launch_knn_cov(h, 0, c0, nc, longest, k, kn, s);
+            if (st != MRS_OK) break;
+            hipLaunchKernelGGL(k_feat_from_knn, dim3((unsigned)((longest + 255) / 256), nc), dim3(256), 0, s, (const float4*)h->d_pts[0],
+                               (const int64_t*)h->d_offs[0] + c0, k, (const int*)kn, d_knn, d_eigens, d_features, d_feat_planes);
         }
-        if (st == MRS_OK) {
-            hipLaunchKernelGGL(k_feat_from_knn, dim3((unsigned)((longest + 255) / 256), batch), dim3(256), 0, s, (const float4*)h->d_pts[0],
-                               (const int64_t*)h->d_offs[0], k, (const int*)knn.as<int>(), d_knn, d_eigens, d_features, d_feat_planes);
-            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-                mrs::set_error("point-feature kernels failed: %s", hipGetErrorString(hipGetLastError()));
-                st = MRS_ERR_HIP;
-            }
+        if (st == MRS_OK && !core4) st = knn_dbg_report(s);
+        if (st == MRS_OK && (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) {
+            mrs::set_error("point-feature kernels failed: %s", hipGetErrorString(hipGetLastError()));
+            st = MRS_ERR_HIP;
         }
     }
     if (!cached) mrs_gicp_batch_destroy(h);

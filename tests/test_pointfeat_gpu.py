@@ -119,3 +119,36 @@ def test_cached_container_reuse_and_concurrent_callers(dev):
         [t.join() for t in ths]
         for (k0, f0), (k1, f1) in zip(first, res):
             assert np.array_equal(k0, k1) and np.array_equal(f0.view(np.int32), f1.view(np.int32))
+
+
+def test_batched_clouds_in_chunks_equal_one_pass(dev):
+    """A batch whose neighbour lists would not fit the scratch limit goes through the selection and the feature tail in chunks of clouds
+    (1 GiB by default; the development switch MRS_FEAT_CHUNK_MB makes it small): ragged clouds, 1 / 2 / all clouds per chunk, same bits;
+    and every cloud of the batch equals the same cloud processed alone."""
+    import os
+    import torch
+    from mr_slam_amd import pointfeat, synth
+    sizes = [5000, 1300, 64, 9000, 2500]
+    clouds = [synth.lidar_scan(80 + i, n) for i, n in enumerate(sizes)]
+    pts = torch.from_numpy(np.concatenate(clouds)).to(dev)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    want = ("knn", "eigens", "features", "planes")
+    ref = {k: v.cpu().numpy() for k, v in pointfeat.point_features(pts, offs, 30, want=want).items()}
+    old = {v: os.environ.get(v) for v in ("MRS_DEV", "MRS_FEAT_CHUNK_MB")}
+    try:
+        os.environ["MRS_DEV"] = "1"
+        for mb in ("1", "2"):           # 9000 points x 30 neighbours = 1.1 MB: one cloud per chunk; two small ones together at 2 MB
+            os.environ["MRS_FEAT_CHUNK_MB"] = mb
+            got = pointfeat.point_features(pts, offs, 30, want=want)
+            for k in want:
+                assert np.array_equal(ref[k].view(np.int32), got[k].cpu().numpy().view(np.int32)), (mb, k)
+    finally:
+        for v, x in old.items():
+            if x is None:
+                os.environ.pop(v, None)
+            else:
+                os.environ[v] = x
+    for i, pc in enumerate(clouds):
+        one = pointfeat.point_features(torch.from_numpy(pc).to(dev), np.array([0, sizes[i]], np.int64), 30, want=("knn", "features"))
+        assert np.array_equal(one["knn"].cpu().numpy(), ref["knn"][offs[i]:offs[i + 1]]), i
+        assert np.array_equal(one["features"].cpu().numpy().view(np.int32), ref["features"][offs[i]:offs[i + 1]].view(np.int32)), i
