@@ -1052,108 +1052,77 @@ def main():
             fin = torch.cuda.Event(); fin.record()
             sweep_batches.append((launches[0], fin))
 
-    def step(record):
-        def mark():
-            e = torch.cuda.Event(enable_timing=True)
-            e.record()
-            return e
+    # ---- one step = every launch of the shard once.  The descriptor part is common; what follows it (correlation against the candidates,
+    # the top-1 sweep, the exchange between ranks) is one function per exchange mode: step_local (N = 1), step_allgather, step_fetch.
+    def mark():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def begin_step():
         if RING_DB:
             parity[0] ^= 1                             # this step writes the other set of slots
         else:
             spec32[CH:] = spec32[CH - DEPTH:CH]        # last launches of the previous step = databases of this step's first
-        for c, (xyz, offs) in enumerate(chunks):
-            g = launch_no[0]; launch_no[0] += 1
-            if FUSE:
-                if c % FUSE == 0:                  # rasterise + Radon + normalise the scans of the next FUSE launches in one kernel
-                    ng = min(FUSE, CH - c)
-                    ef0 = mark() if record else None
-                    ring.ring_descriptors_fused(whole[c:c + ng].view(-1), group_offs[:ng * B + 1], raw=False, normalized=True,
-                                                out_norm=norm_group[:ng * B])
+
+    def descriptors(c, xyz, offs, record):
+        """Normalised sinograms of launch c.  Fused kernel: the scans of the next FUSE launches are rasterised + Radon-transformed + normalised
+        when the first of them comes up (N = 1 with grouped correlation: their half spectra, correlations and side-stream sweeps are issued
+        there too).  Returns (norm [B,120,120], e0, e1, e2): the events around the two stand-alone kernels, None where they do not apply."""
+        if FUSE:
+            if c % FUSE == 0:                  # rasterise + Radon + normalise the scans of the next FUSE launches in one kernel
+                ng = min(FUSE, CH - c)
+                ef0 = mark() if record else None
+                ring.ring_descriptors_fused(whole[c:c + ng].view(-1), group_offs[:ng * B + 1], raw=False, normalized=True,
+                                            out_norm=norm_group[:ng * B])
+                if record:
+                    ev["bev_radon"].append((ef0, mark(), ng))
+                if GROUP_CORR:                 # half spectra (kept: database entries) + correlation with the candidates, all launches of the group
+                    ec0 = mark() if record else None
+                    ring.spectrum_corr_pairs_db(norm_group[:ng * B], spec_flat, flat_cand[parity[0] if RING_DB else 0][c:c + ng].view(-1),
+                                                out=(out_dist[c:c + ng].view(-1), out_ang[c:c + ng].view(-1)),
+                                                spec_out=spec32[wslot(c):wslot(c) + ng].view(-1, 61, 120))
                     if record:
-                        ev["bev_radon"].append((ef0, mark(), ng))
-                    if GROUP_CORR:                 # half spectra (kept: database entries) + correlation with the candidates, all launches of the group
-                        ec0 = mark() if record else None
-                        ring.spectrum_corr_pairs_db(norm_group[:ng * B], spec_flat, flat_cand[parity[0] if RING_DB else 0][c:c + ng].view(-1),
-                                                    out=(out_dist[c:c + ng].view(-1), out_ang[c:c + ng].view(-1)),
-                                                    spec_out=spec32[wslot(c):wslot(c) + ng].view(-1, 61, 120))
-                        if record:
-                            ev["corr"].append((ec0, mark(), ng))
-                        if SIDE_SWEEP:
-                            issue_side_sweeps(range(c, c + ng), record)
-                norm = norm_group[(c % FUSE) * B:(c % FUSE + 1) * B]
-                e0 = e1 = None
-                e2 = mark() if record else None
+                        ev["corr"].append((ec0, mark(), ng))
+                    if SIDE_SWEEP:
+                        issue_side_sweeps(range(c, c + ng), record)
+            return norm_group[(c % FUSE) * B:(c % FUSE + 1) * B], None, None, (mark() if record else None)
+        e0 = mark() if record else None
+        bev.cart_bev(xyz, offs, 1, 1, 120, 120, 1, out=img.view(B, -1))
+        e1 = mark() if record else None
+        _, norm = plan.forward(img.view(B, 120, 120), raw=False, normalized=True)
+        return norm, e0, e1, (mark() if record else None)
+
+    def note_launch(e0, e1, e2, e3, e4, waited=None):
+        if not FUSE:
+            ev["bev"].append((e0, e1)); ev["radon"].append((e1, e2))
+        if not GROUP_CORR:
+            ev["corr"].append((e2, e3, 1))
+        if not SIDE_SWEEP:
+            ev["sweep"].append((e3, e4, 1))
+        if waited is not None:
+            ev["wait"].append(waited)
+
+    def step_local(record):
+        """N = 1: candidates and the swept database are this GPU's own entries."""
+        begin_step()
+        for c, (xyz, offs) in enumerate(chunks):
+            launch_no[0] += 1
+            norm, e0, e1, e2 = descriptors(c, xyz, offs, record)
+            db = spec32[db_slot(c)]
+            if GROUP_CORR:
+                spec = spec32[wslot(c)]                # written by the group's correlation launch
             else:
-                e0 = mark() if record else None
-                bev.cart_bev(xyz, offs, 1, 1, 120, 120, 1, out=img.view(B, -1))
-                e1 = mark() if record else None
-                _, norm = plan.forward(img.view(B, 120, 120), raw=False, normalized=True)
-                e2 = mark() if record else None
-            if EXCH == "allgather":
-                ew0 = mark() if record else None
-                while len(pending) >= DEPTH:           # the compute stream waits for the exchange of launch g - DEPTH
-                    pending.pop(0)[0].wait()           # (stream-side wait, the host does not block)
-                ew1 = mark() if record else None
-                db = gathered[(g - DEPTH) % (DEPTH + 1)]
-                # half spectrum of the new descriptors (kept: database entries; fp16 replica for the other ranks) +
-                # correlation with their candidates out of the replicated database, one launch
-                if REP32:
-                    db = torch.view_as_complex(db)
-                spec, spec16, _, _ = ring.spectrum_corr_pairs_db(norm, db, cand_idx[c], want_f16=not REP32, out=(out_dist[c], out_ang[c]),
-                                                                 spec_out=spec32[c])
-                if REP32:
-                    spec16 = torch.view_as_real(spec32[c])         # the exact entry itself travels
-            elif EXCH == "fetch":
-                if c == 0:                             # the first fetches of the step read the slots copied at its start
-                    for L in range(min(FETCH_AHEAD, CH)):
-                        fetch_q[L] = fetch_plans[L].fetch(spec32[db_slot(L)], async_op=True)
-                work, finish = fetch_q.pop(c)
-                ew0 = mark() if record else None
-                if work is not None:
-                    work.wait()                        # the compute stream waits for the rows requested FETCH_AHEAD launches ago
-                ew1 = mark() if record else None
-                rows = finish()                        # [B,61,120] complex64: the candidates' exact entries, in request order
-                last_fetched[0] = rows
-                spec, spec16, _, _ = ring.spectrum_corr_pairs_db(norm, rows, ident_idx, out=(out_dist[c], out_ang[c]), spec_out=spec32[c])
-                db = None
-            elif GROUP_CORR:
-                db = spec32[db_slot(c)]
-                spec = spec32[wslot(c)]
-            else:
-                db = spec32[db_slot(c)]
                 spec, spec16, _, _ = ring.spectrum_corr_pairs_db(norm, db, cand_idx[c], out=(out_dist[c], out_ang[c]), spec_out=spec32[wslot(c)])
             e3 = mark() if record else None
-            if EXCH == "fetch":
-                # the rows of launch c + FETCH_AHEAD: slot c + FETCH_AHEAD - DEPTH <= c is written on every owner by now
-                L = c + FETCH_AHEAD
-                if L < CH:
-                    fetch_q[L] = fetch_plans[L].fetch(spec32[db_slot(L)], async_op=True)
-                # this launch's query to every rank; the sharded top-1 sweep of the PREVIOUS launch's queries on the side stream
-                done = torch.cuda.Event(); done.record()
-                with torch.cuda.stream(side):
-                    side.wait_event(done)
-                    qw = dist.all_gather_into_tensor(q_all[c % 2], torch.view_as_real(spec32[c, :1]).contiguous(), async_op=True)
-                    sweep_pending.append((c, qw))
-                    if len(sweep_pending) > 1:
-                        run_sharded_sweep(*sweep_pending.pop(0))
-            elif SIDE_SWEEP:
+            if SIDE_SWEEP:
                 if not GROUP_CORR:
                     issue_side_sweeps((c,), record)
             else:
-                d, a = ring.corr_sweep_fft(spec[:1], db)   # one new query against the whole (replicated) database
+                d, a = ring.corr_sweep_fft(spec[:1], db)   # one new query against the whole database
                 torch.min(d, 1, out=(sweep_val[c:c + 1], sweep_row[c:c + 1]))
-            e4 = mark() if record else None
-            if EXCH == "allgather":
-                pending.append((dist.all_gather_into_tensor(gathered[g % (DEPTH + 1)], spec16, async_op=True), spec16))
             if record:
-                if not FUSE:
-                    ev["bev"].append((e0, e1)); ev["radon"].append((e1, e2))
-                if not GROUP_CORR:
-                    ev["corr"].append((e2, e3, 1))
-                if not SIDE_SWEEP:
-                    ev["sweep"].append((e3, e4, 1))
-                if dist_on:
-                    ev["wait"].append((ew0, ew1))
+                note_launch(e0, e1, e2, e3, mark())
         if SIDE_SWEEP:
             # lag: the step's last batch of sweeps may still run while the next step starts.  Its launches (>= DEPTH) read only this step's
             # set of slots, which the next step does not write; the step after that waits (here) for later events of the same stream
@@ -1162,12 +1131,34 @@ def main():
             else:
                 torch.cuda.current_stream().wait_stream(side)  # every sweep of the step is done before the step ends
             sweep_batches.clear()
-        if EXCH == "fetch":
-            with torch.cuda.stream(side):              # the last launch's sweep; the compute stream joins the side stream at the step's end
-                while sweep_pending:
-                    run_sharded_sweep(*sweep_pending.pop(0))
-            torch.cuda.current_stream().wait_stream(side)
-        if EXCH == "allgather" and rescorer is not None:
+
+    def step_allgather(record):
+        """N > 1, replicated database: every launch's new entries go to every rank (fp16 replicas or exact fp32), DEPTH launches ahead of their use."""
+        begin_step()
+        for c, (xyz, offs) in enumerate(chunks):
+            g = launch_no[0]; launch_no[0] += 1
+            norm, e0, e1, e2 = descriptors(c, xyz, offs, record)
+            ew0 = mark() if record else None
+            while len(pending) >= DEPTH:           # the compute stream waits for the exchange of launch g - DEPTH
+                pending.pop(0)[0].wait()           # (stream-side wait, the host does not block)
+            ew1 = mark() if record else None
+            db = gathered[(g - DEPTH) % (DEPTH + 1)]
+            # half spectrum of the new descriptors (kept: database entries; fp16 replica for the other ranks) +
+            # correlation with their candidates out of the replicated database, one launch
+            if REP32:
+                db = torch.view_as_complex(db)
+            spec, spec16, _, _ = ring.spectrum_corr_pairs_db(norm, db, cand_idx[c], want_f16=not REP32, out=(out_dist[c], out_ang[c]),
+                                                             spec_out=spec32[c])
+            if REP32:
+                spec16 = torch.view_as_real(spec32[c])         # the exact entry itself travels
+            e3 = mark() if record else None
+            d, a = ring.corr_sweep_fft(spec[:1], db)   # one new query against the whole (replicated) database
+            torch.min(d, 1, out=(sweep_val[c:c + 1], sweep_row[c:c + 1]))
+            e4 = mark() if record else None
+            pending.append((dist.all_gather_into_tensor(gathered[g % (DEPTH + 1)], spec16, async_op=True), spec16))
+            if record:
+                note_launch(e0, e1, e2, e3, e4, (ew0, ew1))
+        if rescorer is not None:
             # exact re-scoring of the candidates whose replica score is within 2e-3 of the acceptance threshold: global row r
             # of launch c's database = descriptor r % B of rank r // B, built in launch c - DEPTH
             slot = torch.tensor([db_slot(c) for c in range(CH)], device=device)
@@ -1179,6 +1170,46 @@ def main():
             d2, a2 = rescorer.rescore(out_dist.view(-1), out_ang.view(-1), flat_rows, spec32[:CH].reshape(-1, 61, 120),
                                       lambda rows: (rows % NDB) // B, lambda rows: (rows // NDB) * B + rows % B, exact)
             out_dist.view(-1).copy_(d2); out_ang.view(-1).copy_(a2)
+
+    def step_fetch(record):
+        """N > 1, sharded database: every launch fetches exactly the candidate rows it needs (exact fp32, FETCH_AHEAD launches early) and its
+        swept query visits every rank's shard on a side stream."""
+        begin_step()
+        for c, (xyz, offs) in enumerate(chunks):
+            launch_no[0] += 1
+            norm, e0, e1, e2 = descriptors(c, xyz, offs, record)
+            if c == 0:                             # the first fetches of the step read the slots copied at its start
+                for L in range(min(FETCH_AHEAD, CH)):
+                    fetch_q[L] = fetch_plans[L].fetch(spec32[db_slot(L)], async_op=True)
+            work, finish = fetch_q.pop(c)
+            ew0 = mark() if record else None
+            if work is not None:
+                work.wait()                        # the compute stream waits for the rows requested FETCH_AHEAD launches ago
+            ew1 = mark() if record else None
+            rows = finish()                        # [B,61,120] complex64: the candidates' exact entries, in request order
+            last_fetched[0] = rows
+            spec, spec16, _, _ = ring.spectrum_corr_pairs_db(norm, rows, ident_idx, out=(out_dist[c], out_ang[c]), spec_out=spec32[c])
+            e3 = mark() if record else None
+            # the rows of launch c + FETCH_AHEAD: slot c + FETCH_AHEAD - DEPTH <= c is written on every owner by now
+            L = c + FETCH_AHEAD
+            if L < CH:
+                fetch_q[L] = fetch_plans[L].fetch(spec32[db_slot(L)], async_op=True)
+            # this launch's query to every rank; the sharded top-1 sweep of the PREVIOUS launch's queries on the side stream
+            done = torch.cuda.Event(); done.record()
+            with torch.cuda.stream(side):
+                side.wait_event(done)
+                qw = dist.all_gather_into_tensor(q_all[c % 2], torch.view_as_real(spec32[c, :1]).contiguous(), async_op=True)
+                sweep_pending.append((c, qw))
+                if len(sweep_pending) > 1:
+                    run_sharded_sweep(*sweep_pending.pop(0))
+            if record:
+                note_launch(e0, e1, e2, e3, mark(), (ew0, ew1))
+        with torch.cuda.stream(side):              # the last launch's sweep; the compute stream joins the side stream at the step's end
+            while sweep_pending:
+                run_sharded_sweep(*sweep_pending.pop(0))
+        torch.cuda.current_stream().wait_stream(side)
+
+    step = {None: step_local, "allgather": step_allgather, "fetch": step_fetch}[EXCH]
 
     def fence():
         if dist_on:
