@@ -166,10 +166,10 @@ __device__ __forceinline__ float wave_max(float v)
 
 // ---- the traversal of the k-NN selection ------------------------------------------------------------------------------------------
 // No LDS tile, no workgroup barrier: a WAVE (its queries are 64 consecutive Morton-ordered points, i.e. spatially compact) walks the
-// two-level box hierarchy on its own.  What bounds this kernel is not arithmetic but the LENGTH OF ITS DEPENDENCY CHAINS: a wave of
-// k_knn_cov<30> lived 0.9 ms for ~30 k VALU instructions (a SIMD with five such waves was busy a third of the time), because every mini
-// cost two dependent round trips to the L2 (its box -> test -> its 16 candidates -> distances), taken one after the other.  And a
-// wave whose 64 queries straddle a jump of the Morton curve has a bounding box the size of the scene: tested against THAT box, every mini
+// two-level box hierarchy on its own.  What bounded the round-3 / round-4 form of this walk (one bounding box per wave, a per-mini test, then
+// the mini's candidates) was not arithmetic but the LENGTH OF ITS DEPENDENCY CHAINS: a workgroup of k_knn_cov<30> lived 0.9 ms (0.55 ms now)
+// because every mini cost two dependent round trips to the L2 (its box -> test -> its 16 candidates -> distances), taken one after the other.
+// And a wave whose 64 queries straddle a jump of the Morton curve has a bounding box the size of the scene: tested against THAT box, every mini
 // of the cloud passed the coarse test and was then rejected one round trip at a time -- 3 ms for one wave, the tail of the whole launch.
 //   * coarse tests against QUAD boxes: the queries of 4 consecutive lanes share a box and a bound (16 per wave; a jump of the curve
 //     spoils one of them, not the wave).  Lane l tests tile / mini l against the 16 quads (v_readlane broadcasts, ~20 VALU instructions
@@ -294,8 +294,9 @@ __device__ __forceinline__ void stream_minis(const float4* __restrict__ pts, int
 }
 
 // Walk of the hierarchy for the 64 queries of a wave.  bound(): the lane's current bound (called by the whole wave before every tile; it may
-// do wave-wide bookkeeping first); a dead lane's bound is ignored.  visit(first index, 8 candidates): see stream_minis.  NEAREST: tiles nearest first (pass 1: bounds shrink); otherwise tiles
-// and minis in index order (pass 2 without the list of pass 1: candidates must arrive in ascending index order).  rec(id): every mini visited.
+// do wave-wide bookkeeping first); a dead lane's bound is ignored.  visit(first index, 8 candidates): see stream_minis.  NEAREST: tiles nearest
+// first (pass 1: bounds shrink); otherwise tiles and minis in index order (pass 2 without the list of pass 1: candidates must arrive in
+// ascending index order).  rec(id): every mini visited.  Returns the number of tiles visited (a development counter).
 template <bool NEAREST, class Bound, class Visit, class Rec>
 __device__ __forceinline__ int knn_walk(const float4* __restrict__ pts, int n, const Hier& H, bool live, const float4& q, int home_tile,
                                          Bound bound, Visit visit, Rec rec)
