@@ -181,6 +181,11 @@ __device__ __forceinline__ float wave_max(float v)
 //     (scalar loads return out of order, so only lgkmcnt(0) exists: an empty asm that reads one register of the current half makes the
 //     compiler wait for it before the next requests are issued -- everything outstanding during the arithmetic belongs to the next half).
 // Conservative at every level (0.9999 slack on the box distances), so the neighbours found are the exact ones.
+#ifndef MRS_KNN_QUAD
+#define MRS_KNN_QUAD 4
+#endif
+constexpr int kQL = MRS_KNN_QUAD;        // lanes per group of the coarse tests (4: "quads"; 8 was measured: see DESIGN.md 4)
+constexpr int kQG = 64 / kQL;
 __device__ __forceinline__ float lane_f(float v, int l) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l)); }
 __device__ __forceinline__ float first_f(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
 
@@ -192,15 +197,16 @@ __device__ __forceinline__ void quad_box(bool live, const float4& q, float (&lo)
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int o = 1; o < 4; o <<= 1) {
+        for (int o = 1; o < kQL; o <<= 1) {
             lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64));
             hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64));
         }
 }
 __device__ __forceinline__ float quad_max(float v)
 {
-    v = fmaxf(v, __shfl_xor(v, 1, 64));
-    return fmaxf(v, __shfl_xor(v, 2, 64));
+#pragma unroll
+    for (int o = 1; o < kQL; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
 }
 
 // does THIS lane's box (blo, bhi) come within the bound of any query of the wave?  16 quad tests (box against the quad's box and largest
@@ -212,19 +218,19 @@ __device__ __forceinline__ bool quads_hit(const float4& blo, const float4& bhi, 
     bool hit = false;
     dmin = INFINITY;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
+    for (int g = 0; g < kQG; ++g) {
         if (wide >> g & 1) {        // wave-uniform
 #pragma unroll
-            for (int l = 4 * g; l < 4 * g + 4; ++l) {
+            for (int l = kQL * g; l < kQL * g + kQL; ++l) {
                 const float d = box_point_d2(blo, bhi, lane_f(q.x, l), lane_f(q.y, l), lane_f(q.z, l));
                 hit |= d * 0.9999f <= lane_f(T, l);         // a dead lane's T is -1
                 dmin = fminf(dmin, lane_f(T, l) >= 0.0f ? d : INFINITY);
             }
         } else {
-            const float l[3] = {lane_f(qlo[0], 4 * g), lane_f(qlo[1], 4 * g), lane_f(qlo[2], 4 * g)};
-            const float h[3] = {lane_f(qhi[0], 4 * g), lane_f(qhi[1], 4 * g), lane_f(qhi[2], 4 * g)};
+            const float l[3] = {lane_f(qlo[0], kQL * g), lane_f(qlo[1], kQL * g), lane_f(qlo[2], kQL * g)};
+            const float h[3] = {lane_f(qhi[0], kQL * g), lane_f(qhi[1], kQL * g), lane_f(qhi[2], kQL * g)};
             const float d = box_box_d2(blo, bhi, l, h);
-            hit |= d * 0.9999f <= lane_f(qT, 4 * g);
+            hit |= d * 0.9999f <= lane_f(qT, kQL * g);
             dmin = fminf(dmin, d);
         }
     }
@@ -239,7 +245,7 @@ __device__ __forceinline__ unsigned wide_quads(const float (&qlo)[3], const floa
     const unsigned long long m = __ballot(w);
     unsigned out = 0;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) out |= (unsigned)(m >> (4 * g) & 1ull) << g;
+    for (int g = 0; g < kQG; ++g) out |= (unsigned)(m >> (kQL * g) & 1ull) << g;
     return out;
 }
 
