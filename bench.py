@@ -812,6 +812,130 @@ def dropin_latency_leg(scan):
     return out
 
 
+
+# ------------------------------------------------------------------------------------------------ the result line
+COMPACT_LIMIT = 4096      # bytes: the driver keeps a bounded tail of stdout; round 5's 21 KB line could not be parsed
+
+
+def _sig(x, digits=5):
+    """floats to `digits` significant digits, NaN / inf to None (strict JSON), recursively"""
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    if isinstance(x, (np.floating, float)):
+        x = float(x)
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, np.integer):
+        return int(x)
+    if isinstance(x, np.bool_):
+        return bool(x)
+    return x
+
+
+def _strict(x):
+    """the detail block as strict JSON: numpy scalars to Python, NaN / inf to None, full precision"""
+    if isinstance(x, dict):
+        return {str(k): _strict(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_strict(v) for v in x]
+    if isinstance(x, (np.floating, float)):
+        x = float(x)
+        return None if (x != x or x in (float("inf"), float("-inf"))) else x
+    if isinstance(x, np.integer):
+        return int(x)
+    if isinstance(x, np.bool_):
+        return bool(x)
+    return x
+
+
+def _get(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d or d[k] is None:
+            return None
+        d = d[k]
+    return d
+
+
+def compact_line(d, detail_name):
+    """The contract line: the driver's fields + the scalars the targets are stated in, <= COMPACT_LIMIT bytes.  Every block of the full result
+    (`d`, written to `detail_name`) that is not a scalar of the contract stays in the detail file."""
+    r, g, sw = d.get("roofline") or {}, d.get("gicp") or {}, d.get("sweeps") or {}
+    cfg = d.get("config") or {}
+    roof = {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch")}
+    roof["kernel"] = (roof["kernel"] or "").split(" (")[0]
+    scal = {
+        "bev_scatter_frac": r.get("bev_scatter_frac"), "polar_frac": r.get("polar_frac"),
+        "frac_of_max_hbm_only_march_only": r.get("frac_of_max_hbm_only_march_only"),
+        "gicp_iters_per_s": g.get("iters_per_s"), "gicp_iters_per_s_natural": _get(g, "natural", "iters_per_s"),
+        "gicp_iters_per_s_cold5": _get(g, "cold", "iters_per_s"), "gicp_searched_fraction": g.get("searched_fraction"),
+        "gicp_natural_pairs_per_s": _get(g, "natural", "pairs_per_s"), "gicp_pairs_per_s_incl_covariances": g.get("pairs_per_s_incl_covariances"),
+        "gicp_linearize_frac": r.get("gicp_linearize_frac"), "gicp_nn_certify_frac": r.get("gicp_nn_certify_frac"),
+        "gicp_cov_from_knn_frac": _get(g, "roofline", "k_cov_from_knn", "frac"), "gicp_cov_from_knn_ms": r.get("gicp_cov_from_knn_ms"),
+        "gicp_knn_select_ms": r.get("gicp_knn_select_ms"),
+        "ring_q1_frac": _get(sw, "ring_q1", "hbm_frac"), "ringpp_q1_frac": _get(sw, "ringpp_q1", "hbm_frac"),
+        "ring_q4_pairs_per_s": _get(sw, "ring_q4", "pairs_per_s"), "ringpp_q4_pairs_per_s": _get(sw, "ringpp_q4", "pairs_per_s"),
+        "disco_q1_ms": _get(sw, "disco_q1", "ms"),
+        "node_twin_pairs_per_s": _get(d, "node_shape", "twin_pairs_per_s"),
+        "node_unchanged_loop_pairs_per_s": _get(d, "node_shape", "reference_loop_through_dropin", "pairs_per_s"),
+        "pygicp_align_ms": _get(d, "dropin_latency", "pygicp_align_downsampled_ms"),
+        "ringpp_build_scans_per_s": _get(d, "builds", "ringpp_build", "scans_per_s"),
+        "host_fed_scans_per_s": _get(d, "builds", "ingest_from_host", "scans_per_s"),
+        "host_fed_frac_of_copy": _get(d, "builds", "ingest_from_host", "frac_of_pinned_copy"),
+    }
+    roof.update({k: v for k, v in scal.items() if v is not None})
+    cb = d.get("cpu_baseline")
+    out = {k: d.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                 "dtype", "data")}
+    out["config"] = {"workload": cfg.get("workload"),
+                     **{k: cfg.get(k) for k in ("pairs_per_rank_per_step", "launches_per_step", "points_per_scan", "exchange", "exchange_impl")}}
+    out["timed_region_s"] = d.get("timed_region_s")
+    v = d.get("verify")
+    out["verify"] = {"ok": v.get("ok"), "checked": v.get("checked")} if v else None
+    out["roofline"] = roof
+    if cb:
+        out["cpu_baseline"] = {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                               "sample": (cb.get("sample") or "")[:160], "gicp_iters_per_s": _get(cb, "gicp", "iters_per_s")}
+    pg = _get(d, "exchange", "process_group")
+    if pg:
+        out["exchange"] = {"process_group": pg, "impl": _get(d, "exchange", "impl"), "verify_ok": _get(d, "exchange", "verify", "ok")}
+    out["detail"] = detail_name
+    keep_exact = {"value": out["value"], "ms_per_step": out["ms_per_step"], "timed_region_s": out["timed_region_s"]}
+    out = _sig(out)
+    out.update({k: (None if v is None else float(v)) for k, v in keep_exact.items()})
+    out["roofline"]["frac"] = None if roof.get("frac") is None else float(roof["frac"])
+    out["roofline"]["achieved"] = None if roof.get("achieved") is None else float(roof["achieved"])
+    out["roofline"]["traffic"] = roof.get("traffic")
+    text = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    while len(text) >= COMPACT_LIMIT and len(out["roofline"]) > 8:      # never reached today (~2.5 KB); a later block must not break the driver's parser
+        out["roofline"].popitem()
+        text = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    assert len(text) < COMPACT_LIMIT, len(text)
+    return text
+
+
+def emit(detail, detail_file):
+    """Full result -> `detail_file` (strict JSON, one object); the compact contract line -> the LAST line of stdout, nothing after it."""
+    detail = _strict(detail)
+    name = None
+    if detail_file:
+        with open(detail_file, "w") as f:
+            json.dump(detail, f, allow_nan=False)
+            f.write("\n")
+        name = os.path.basename(detail_file)
+    text = compact_line(detail, name)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    try:   # librccl printf()s a banner into libc's stdout buffer, which would otherwise be flushed at exit, after the JSON
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    print(text, flush=True)
+
+
 # ------------------------------------------------------------------------------------------------------------ main
 def free_port():
     import socket
@@ -850,6 +974,8 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="only the headline step (+ GICP unless --gicp-pairs 0)")
     ap.add_argument("--verify", type=int, default=8, help="after the timed region: this many random outputs of the last fused launch against the "
                     "oracle (N = 1, fused step only; 0 = skip)")
+    ap.add_argument("--detail-file", default="bench_detail.json", help="every block of the result (kernel times, legs, rooflines per kernel, the CPU "
+                    "baseline's settings) as one JSON object; the last stdout line is the compact contract line (< 4 KB).  '' = no file")
     ap.add_argument("--verify-exchange", action="store_true", help="N > 1: re-derive the last launch's scores from the exact remote entries")
     ap.add_argument("--exchange", choices=("fetch", "allgather"), default="fetch", help="N > 1: how candidate rows and the swept database reach a rank. "
                     "fetch (default): the database stays sharded, a pre-planned all-to-all brings exactly the candidate rows asked for (exact fp32) and "
@@ -1528,14 +1654,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if line is not None:
-        sys.stdout.flush()
-        sys.stderr.flush()
-        try:   # librccl printf()s a banner into libc's stdout buffer, which would otherwise be flushed at exit, after the JSON
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except OSError:
-            pass
-        print(json.dumps(line), flush=True)     # the ONE JSON line, last thing on stdout
+        emit(line, args.detail_file)
 
 
 if __name__ == "__main__":

@@ -40,3 +40,32 @@ def test_free_port_is_bindable():
     port = bench.free_port()
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
         so.bind(("127.0.0.1", port))
+
+
+def test_compact_line_is_small_strict_json():
+    """The driver keeps a bounded tail of stdout: the contract line must stay under 4 KB of strict JSON whatever the detail blocks hold
+    (round 5's 21 KB line left BENCH_r05.parsed null).  Input: a full result of an earlier round kept under profiles/, plus NaN / inf / numpy
+    scalars planted in it."""
+    import json
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_default.json")))
+    d["roofline"]["polar_frac"] = float("nan")
+    d["roofline"]["bev_scatter_frac"] = np.float32(0.82)
+    d["sweeps"]["ring_q1"]["hbm_frac"] = float("inf")
+    d["exchange"] = {"process_group": {"backend": "nccl", "world_size": 8, "gpus_flag": 8, "devices_visible": 8}, "impl": "cabi", "verify": {"ok": True}}
+    text = bench.compact_line(bench._strict(d), "bench_detail.json")
+    assert len(text.encode()) < bench.COMPACT_LIMIT and "\n" not in text
+
+    def bad(c):
+        raise ValueError(c)
+    c = json.loads(text, parse_constant=bad)
+    assert c["value"] == d["value"] and c["ms_per_step"] == d["ms_per_step"] and c["roofline"]["frac"] == d["roofline"]["frac"]
+    assert c["roofline"]["traffic"] == d["roofline"]["traffic"] and "polar_frac" not in c["roofline"] and "ring_q1_frac" not in c["roofline"]
+    assert abs(c["roofline"]["bev_scatter_frac"] - 0.82) < 1e-6 and c["cpu_baseline"]["kind"] == "port" and c["exchange"]["process_group"]["world_size"] == 8
+    assert c["verify"] == {"ok": True, "checked": 8} and c["detail"] == "bench_detail.json"
+    # strict detail: NaN / inf become null
+    s = bench._strict({"a": float("nan"), "b": [np.int64(3), float("-inf")], "c": np.bool_(True)})
+    assert s == {"a": None, "b": [3, None], "c": True}

@@ -1,4 +1,5 @@
-"""bench.py prints ONE JSON line with the fields the driver reads (small configuration, one GPU)."""
+"""bench.py prints ONE compact JSON line (< 4 KB, strict JSON: the driver keeps a bounded tail of stdout) with the fields the driver reads, and
+writes every other block to the detail file (small configuration, one GPU)."""
 import json
 import os
 import subprocess
@@ -10,15 +11,44 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra_env=None, extra_args=()):
+def _strict_loads(text):
+    def bad(c):
+        raise ValueError(f"not strict JSON: {c}")
+    return json.loads(text, parse_constant=bad)          # NaN / Infinity are refused
+
+
+def _check_compact(last_line, detail):
+    """the LAST stdout line: strict JSON under 4 KB that carries the contract fields, and whose scalars are the detail file's"""
+    assert len(last_line.encode()) < 4096, len(last_line)
+    c = _strict_loads(last_line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "timed_region_s", "roofline"):
+        assert k in c, k
+    assert c["value"] == detail["value"] and c["ms_per_step"] == detail["ms_per_step"] and c["n_gpus"] == detail["n_gpus"]
+    assert "workload" in c["config"] and "model" not in c["config"] and c["config"]["launches_per_step"] == detail["config"]["launches_per_step"]
+    r = c["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["frac"] == detail["roofline"]["frac"] and r["algorithmic_bytes_per_launch"] == detail["roofline"]["algorithmic_bytes_per_launch"]
+    if "cpu_baseline" in detail:
+        b = c["cpu_baseline"]
+        assert b["kind"] in ("port", "reference") and b["value"] > 0 and b["cores"] >= 1 and b["sample"] and b["unit"] == "pairs/s"
+    return c
+
+
+def _run(extra_env=None, extra_args=(), tmp=None):
+    import tempfile
     env = dict(os.environ)
     env.update(extra_env or {})
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "32",
-                        "--chunks", "3", "--cpu-sample", "8", "--gicp-pairs", "2", "--gicp-iters", "6", *extra_args],
-                       capture_output=True, text=True, env=env, timeout=600)
-    assert p.returncode == 0, p.stderr[-2000:]
-    lines = [l for l in p.stdout.splitlines() if l.strip()]
-    return json.loads(lines[-1])          # the JSON is the LAST line of stdout
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "detail.json")
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "32",
+                            "--chunks", "3", "--cpu-sample", "8", "--gicp-pairs", "2", "--gicp-iters", "6", "--detail-file", path, *extra_args],
+                           capture_output=True, text=True, env=env, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [l for l in p.stdout.splitlines() if l.strip()]
+        d = _strict_loads(open(path).read())          # every block of the result
+    d["_compact"] = _check_compact(lines[-1], d)      # the contract line is the LAST line of stdout
+    return d
 
 
 def test_bench_line_contract():
@@ -50,6 +80,15 @@ def test_bench_line_contract():
     assert 0 < d["gicp"]["natural"]["searched_fraction"] <= 1.0 and d["gicp"]["kernel_counts"]["correspondences"] > 0
     for leg in ("roofline_polar", "roofline_radon", "sweeps", "pipeline_shard", "dropin_latency"):
         assert leg in d, leg
+    # the compact line carries the targets' scalars out of those blocks
+    cr = d["_compact"]["roofline"]
+    for k in ("bev_scatter_frac", "polar_frac", "frac_of_max_hbm_only_march_only", "gicp_iters_per_s", "gicp_iters_per_s_natural", "gicp_searched_fraction",
+              "gicp_natural_pairs_per_s", "gicp_pairs_per_s_incl_covariances", "gicp_linearize_frac", "gicp_nn_certify_frac", "gicp_cov_from_knn_frac",
+              "ring_q1_frac", "ringpp_q1_frac", "ring_q4_pairs_per_s", "node_twin_pairs_per_s"):
+        assert isinstance(cr[k], float) and cr[k] > 0, k
+    assert d["_compact"]["verify"] == {"ok": True, "checked": 8} and d["_compact"]["detail"] == "detail.json"
+    assert abs(cr["gicp_iters_per_s"] - d["gicp"]["iters_per_s"]) < 1e-4 * cr["gicp_iters_per_s"]
+    assert d["_compact"]["cpu_baseline"]["gicp_iters_per_s"] > 0
     assert d["roofline_polar"]["bound"] == "hbm" and d["sweeps"]["ring_q1"]["pairs_per_s"] > 0 and d["sweeps"]["disco_q4"]["queries_per_s"] > 0
     # round 5: the one-query sweeps on the database's resident (DMA-tiled) format next to the row layout; the node's shape; GICP protocols
     for k in ("ring_q1", "ring_q1_row_layout", "ringpp_q1", "ringpp_q1_row_layout", "disco_q1"):
@@ -126,13 +165,19 @@ def test_bench_collective_path_on_one_gpu():
 def _two_ranks(port, extra):
     env = dict(os.environ)
     env.update({"MRS_BENCH_BACKEND": "gloo", "MRS_BENCH_SHARE_GPU": "1"})
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "32",
-           "--chunks", "3", "--gicp-pairs", "2", "--gicp-iters", "4", "--no-extra-legs", "--verify-exchange", *extra]
-    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
-    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
-    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
-    return json.loads(lines[-1])
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "detail.json")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "32",
+               "--chunks", "3", "--gicp-pairs", "2", "--gicp-iters", "4", "--no-extra-legs", "--verify-exchange", "--detail-file", path, *extra]
+        p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+        assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+        lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+        d = _strict_loads(open(path).read())
+    d["_compact"] = _check_compact(lines[-1], d)
+    assert d["_compact"]["exchange"]["process_group"]["world_size"] == 2
+    return d
 
 
 def test_bench_two_ranks_share_one_gpu_over_gloo():
@@ -163,11 +208,15 @@ def test_bench_bare_gpus_flag_starts_the_ranks():
     rank 0 prints the one JSON line with n_gpus == 2.  Test mode: both ranks on the one GPU over gloo.  Without that mode the same command on a
     one-GPU box must fail loudly instead of measuring one rank."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    import tempfile
+    td = tempfile.mkdtemp()
+    path = os.path.join(td, "detail.json")
     args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "32", "--chunks", "3",
-            "--gicp-pairs", "0", "--no-extra-legs", "--exchange", "allgather", "--replica", "f32", "--verify-exchange"]
+            "--gicp-pairs", "0", "--no-extra-legs", "--exchange", "allgather", "--replica", "f32", "--verify-exchange", "--detail-file", path]
     p = subprocess.run(args, capture_output=True, text=True, env=dict(env, MRS_BENCH_BACKEND="gloo", MRS_BENCH_SHARE_GPU="1"), timeout=900)
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
-    d = json.loads([l for l in p.stdout.splitlines() if l.strip().startswith("{")][-1])
+    d = _strict_loads(open(path).read())
+    _check_compact([l for l in p.stdout.splitlines() if l.strip().startswith("{")][-1], d)
     assert d["n_gpus"] == 2 and d["config"]["exchange"] == "allgather" and d["config"]["pairs_per_rank_per_step"] == 96
     x = d["exchange"]
     assert x["process_group"] == {"backend": "gloo", "world_size": 2, "gpus_flag": 2, "devices_visible": x["process_group"]["devices_visible"]}
