@@ -39,6 +39,7 @@
 
 #include "common.hpp"
 #include "nn_core.hpp"
+#include "eig3.hpp"
 
 namespace {
 
@@ -635,48 +636,7 @@ __global__ __launch_bounds__(256) void k_boxes(const float4* __restrict__ pts, c
     }
 }
 
-// eigenvector of the smallest eigenvalue of a symmetric 3x3 (cyclic Jacobi, double)
-__device__ void smallest_eigvec(const double* c, double* n_out)
-{
-    double a[9], v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    for (int i = 0; i < 9; ++i) a[i] = c[i];
-    for (int sweep = 0; sweep < 30; ++sweep) {
-        const double off = a[1] * a[1] + a[2] * a[2] + a[5] * a[5];
-        if (off < 1e-300) break;
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int q = p + 1; q < 3; ++q) {
-                const double apq = a[3 * p + q];
-                if (apq == 0.0) continue;
-                const double theta = (a[3 * q + q] - a[3 * p + p]) / (2.0 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const double akp = a[3 * k + p], akq = a[3 * k + q];
-                    a[3 * k + p] = cs * akp - sn * akq;
-                    a[3 * k + q] = sn * akp + cs * akq;
-                }
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const double apk = a[3 * p + k], aqk = a[3 * q + k];
-                    a[3 * p + k] = cs * apk - sn * aqk;
-                    a[3 * q + k] = sn * apk + cs * aqk;
-                }
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const double vkp = v[3 * k + p], vkq = v[3 * k + q];
-                    v[3 * k + p] = cs * vkp - sn * vkq;
-                    v[3 * k + q] = sn * vkp + cs * vkq;
-                }
-            }
-    }
-    int s = 0;
-    if (a[4] < a[0]) s = 1;
-    if (a[8] < a[4 * s]) s = 2;
-    n_out[0] = v[s]; n_out[1] = v[3 + s]; n_out[2] = v[6 + s];
-}
+// smallest_eigvec / sym3_eigvals: eig3.hpp (closed form + Rayleigh-quotient steps; the cyclic Jacobi of rounds 1-5 is gone)
 
 // ---- exact k nearest neighbours in two passes ----------------------------------------------------------------------------------
 // A sorted insertion that carries the index costs ~8 VALU instructions per slot and, in SIMT, every lane of a wave pays for every
@@ -976,44 +936,6 @@ __global__ void k_features_from_neighbors(const float* __restrict__ pts /* [n][3
         point_features(eig + (size_t)i * 5, nz, k, f);
         for (int j = 0; j < 13; ++j) feat[(size_t)i * 13 + j] = f[j];
     }
-}
-
-// eigenvalues (descending) of a symmetric 3x3 by cyclic Jacobi in double
-__device__ void sym3_eigvals(const double* c, double* w)
-{
-    double a[9];
-    for (int i = 0; i < 9; ++i) a[i] = c[i];
-    for (int sweep = 0; sweep < 30; ++sweep) {
-        const double off = a[1] * a[1] + a[2] * a[2] + a[5] * a[5];
-        if (off < 1e-300) break;
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int q = p + 1; q < 3; ++q) {
-                const double apq = a[3 * p + q];
-                if (apq == 0.0) continue;
-                const double theta = (a[3 * q + q] - a[3 * p + p]) / (2.0 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
-#pragma unroll
-                for (int kk = 0; kk < 3; ++kk) {
-                    const double akp = a[3 * kk + p], akq = a[3 * kk + q];
-                    a[3 * kk + p] = cs * akp - sn * akq;
-                    a[3 * kk + q] = sn * akp + cs * akq;
-                }
-#pragma unroll
-                for (int kk = 0; kk < 3; ++kk) {
-                    const double apk = a[3 * p + kk], aqk = a[3 * q + kk];
-                    a[3 * p + kk] = cs * apk - sn * aqk;
-                    a[3 * q + kk] = sn * apk + cs * aqk;
-                }
-            }
-    }
-    double x = a[0], y = a[4], z = a[8], t;
-    if (x < y) { t = x; x = y; y = t; }
-    if (y < z) { t = y; y = z; z = t; }
-    if (x < y) { t = x; x = y; y = t; }
-    w[0] = x; w[1] = y; w[2] = z;
 }
 
 __device__ __forceinline__ bool inv3_sym(const double* a, double* r)
@@ -1601,7 +1523,7 @@ __global__ __launch_bounds__(256) void k_cov_from_knn(const float4* __restrict__
         const int cnt = neighbour_moments<32, false>(pts, nb, k, q, cv, unused);
         for (int a = 0; a < 9; ++a) cv[a] /= cnt;
         double nrm[3];
-        smallest_eigvec(cv, nrm);
+        mrs::smallest_eigvec(cv, nrm);
         double* out = cov_all + kCovDoubles * (size_t)(o + i);      // the unit normal: C = I - 0.999 n n^T is rebuilt by the readers (cov6_from_normal)
         out[0] = nrm[0]; out[1] = nrm[1]; out[2] = nrm[2];
         if (knn_out) {
@@ -1631,7 +1553,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         const int cnt = neighbour_moments<32, true>(pts, nb, k, q, cv, nz);
         for (int a = 0; a < 9; ++a) cv[a] /= (double)(cnt - 1);
         double w[3];
-        sym3_eigvals(cv, w);
+        mrs::sym3_eigvals(cv, w);
         const double hm = 0.5 * (cv[0] + cv[4]), hd = 0.5 * (cv[0] - cv[4]);
         const double rad = sqrt(hd * hd + cv[1] * cv[1]);
         float e[5] = {(float)w[0], (float)w[1], (float)w[2], (float)(hm + rad), (float)(hm - rad)};
