@@ -1476,27 +1476,59 @@ __global__ __launch_bounds__(kNNThreads) void k_knn_select(const float4* __restr
 // Second moments of a point's k neighbours in ONE pass over them: sums of d and d d^T with d = p - q taken about the query point q
 // (fp64; |d| is a neighbourhood radius, so the subtraction  sum d d^T - n m m^T  cancels a few digits of 16 at most), instead of a pass
 // for the mean and a second one about it: half the gathers (30 random 16-byte reads per point instead of 60).
+// Memory schedule (round 6): rounds 1-5 walked the slots one by one behind two data-dependent branches each, so that a wave sat out an index
+// load AND a dependent gather per neighbour, ~30 round trips in a row (10 k cycles per wave for ~4 k cycles of arithmetic).  Now the slots
+// are taken in chunks of kMomChunk: the indices of a chunk (one coalesced 256-byte row per slot and wave; slots past k re-read slot k - 1) are
+// requested two chunks ahead of the sums and its points one chunk ahead, so that loads of 2 x kMomChunk neighbours are in flight while a chunk is summed.  An empty slot (-1: a cloud with fewer than k points)
+// gathers the query itself and contributes exact zeros, so the sums are those of the slot-by-slot loop bit for bit.
 // cv: full symmetric 3x3 of  sum (p - mean)(p - mean)^T  (not yet divided); returns the number of neighbours.
+constexpr int kMomChunk = 5;      // 15 / 20 / 30 neighbours (GICP default, the oracle's k, RING++) are whole chunks
 template <int KMAX, bool WANT_Z>
-__device__ __forceinline__ int neighbour_moments(const float4* __restrict__ pts, const int* __restrict__ nb /* slot s at nb[64 s] */, int k, const float4& q,
-                                                 double (&cv)[9], float (&nz)[KMAX])
+__device__ __forceinline__ int neighbour_moments(const float4* __restrict__ pts, const int* __restrict__ nb /* slot s at nb[64 s] */, int k, int self,
+                                                 const float4& q, double (&cv)[9], float (&nz)[KMAX])
 {
+    constexpr int NCH = (KMAX + kMomChunk - 1) / kMomChunk;
+    int idx[3][kMomChunk];                                 // chunk c lives in [c % 3]: indices run two chunks ahead of the sums, points one
+    float px[2][kMomChunk], py[2][kMomChunk], pz[2][kMomChunk];
+    auto indices = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < kMomChunk; ++j) idx[c % 3][j] = nb[min(c * kMomChunk + j, k - 1) << 6];
+    };
+    auto gather = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < kMomChunk; ++j) {
+            const int id = idx[c % 3][j];
+            const float4 p = pts[id >= 0 ? id : self];
+            px[c & 1][j] = p.x; py[c & 1][j] = p.y; pz[c & 1][j] = p.z;
+        }
+    };
     double sd[3] = {0, 0, 0}, sc[6] = {0, 0, 0, 0, 0, 0};
     int cnt = 0;
+    indices(0);
+    if (NCH > 1) indices(1);
+    gather(0);
 #pragma unroll
-    for (int s = 0; s < KMAX; ++s) {
-        if (WANT_Z) nz[s] = 0.0f;
-        if (s < k) {
-            const int j = nb[s << 6];
-            if (j >= 0) {
-                const float4 p = pts[j];
-                const double dx = (double)p.x - (double)q.x, dy = (double)p.y - (double)q.y, dz = (double)p.z - (double)q.z;
+    for (int c = 0; c < NCH; ++c) {
+        if (c * kMomChunk < k) {                                       // uniform: k is a kernel argument
+            if (c + 2 < NCH && (c + 2) * kMomChunk < k) indices(c + 2);
+            if (c + 1 < NCH && (c + 1) * kMomChunk < k) gather(c + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < kMomChunk; ++j) {
+                const int s = c * kMomChunk + j;
+                const bool ok = s < k && idx[c % 3][j] >= 0;
+                const float fx = px[c & 1][j], fy = py[c & 1][j], fz = pz[c & 1][j];
+                const double dx = ok ? (double)fx - (double)q.x : 0.0, dy = ok ? (double)fy - (double)q.y : 0.0, dz = ok ? (double)fz - (double)q.z : 0.0;
                 sd[0] += dx; sd[1] += dy; sd[2] += dz;
                 sc[0] += dx * dx; sc[1] += dx * dy; sc[2] += dx * dz;
                 sc[3] += dy * dy; sc[4] += dy * dz; sc[5] += dz * dz;
-                if (WANT_Z) nz[s] = p.z;
-                ++cnt;
+                if (WANT_Z && s < KMAX) nz[s] = ok ? fz : 0.0f;
+                cnt += ok ? 1 : 0;
             }
+        } else if (WANT_Z) {
+#pragma unroll
+            for (int j = 0; j < kMomChunk; ++j)
+                if (c * kMomChunk + j < KMAX) nz[c * kMomChunk + j] = 0.0f;
         }
     }
     const double inv = 1.0 / (double)cnt;
@@ -1520,7 +1552,7 @@ __global__ __launch_bounds__(256) void k_cov_from_knn(const float4* __restrict__
         const float4 q = pts[i];
         double cv[9];
         float unused[32];
-        const int cnt = neighbour_moments<32, false>(pts, nb, k, q, cv, unused);
+        const int cnt = neighbour_moments<32, false>(pts, nb, k, i, q, cv, unused);
         for (int a = 0; a < 9; ++a) cv[a] /= cnt;
         double nrm[3];
         mrs::smallest_eigvec(cv, nrm);
@@ -1550,7 +1582,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         const int oi = __float_as_int(q.w);
         double cv[9];
         float nz[32];
-        const int cnt = neighbour_moments<32, true>(pts, nb, k, q, cv, nz);
+        const int cnt = neighbour_moments<32, true>(pts, nb, k, i, q, cv, nz);
         for (int a = 0; a < 9; ++a) cv[a] /= (double)(cnt - 1);
         double w[3];
         mrs::sym3_eigvals(cv, w);
