@@ -551,21 +551,28 @@ def sweep_legs(device, spec_pool, n_db=10_000):
     def entry(nq, ms, bytes_per_entry, **kw):
         return dict({"pairs_per_s": nq * n_db / ms * 1e3, "ms": ms, "db_entries": n_db, "bytes_per_entry": bytes_per_entry,
                      "db_gbs": n_db * bytes_per_entry / ms / 1e6, "hbm_frac": n_db * bytes_per_entry / ms / 1e6 / HBM_PEAK_GBS}, **kw)
+    TILED = 58624                                                      # MRS_RING_TILED_ENTRY_BYTES: what the tiled sweep streams per plane
     tiled = ring.spec_to_tiled(db)
     q1 = spec_pool[:1].contiguous()
-    out["ring_q1"] = entry(1, ev_ms(lambda: ring.corr_sweep_fft_tiled(q1, tiled), reps=10, warm=3), 58560, layout="dma-tiled (mrs_loopdb)")
+    out["ring_q1"] = entry(1, ev_ms(lambda: ring.corr_sweep_fft_tiled(q1, tiled), reps=10, warm=3), TILED, layout="dma-tiled (mrs_loopdb)")
     out["ring_q1_row_layout"] = entry(1, ev_ms(lambda: ring.corr_sweep_fft(q1, db), reps=10, warm=3), 58560)
-    del tiled
+    # several queries per sweep (round 6): the one-query LDS-DMA pipeline per (query, entry), the queries' workgroups grouped per XCD so that
+    # the entry leaves HBM once (profiles/r06_sweep_mq.md); hbm_frac = database bytes streamed ONCE per launch / time
+    for nq in (4, 8):
+        q = spec_pool[:nq].contiguous()
+        out[f"ring_q{nq}"] = entry(nq, ev_ms(lambda: ring.corr_sweep_fft_tiled_q(q, tiled)), TILED, layout="dma-tiled (mrs_loopdb_query_multi)")
     q = spec_pool[:4].contiguous()
-    out["ring_q4"] = entry(4, ev_ms(lambda: ring.corr_sweep_fft(q, db)), 58560)
+    out["ring_q4_row_layout"] = entry(4, ev_ms(lambda: ring.corr_sweep_fft(q, db)), 58560)
+    del tiled
     db6 = torch.stack([db.roll(k, 0) for k in range(6)], 1).contiguous()   # RING++: [n_db][6][61][120] = 351 360 B each
     tiled6 = ring.spec_to_tiled(db6)
     q1 = db6[:1].contiguous()
-    out["ringpp_q1"] = entry(1, ev_ms(lambda: ring.corr_sweep_fft_tiled(q1, tiled6), reps=3, warm=1), 351360, layout="dma-tiled (mrs_loopdb)")
+    out["ringpp_q1"] = entry(1, ev_ms(lambda: ring.corr_sweep_fft_tiled(q1, tiled6), reps=3, warm=1), 6 * TILED, layout="dma-tiled (mrs_loopdb)")
+    q = db6[:4].contiguous()
+    out["ringpp_q4"] = entry(4, ev_ms(lambda: ring.corr_sweep_fft_tiled_q(q, tiled6), reps=3, warm=1), 6 * TILED, layout="dma-tiled (mrs_loopdb_query_multi)")
     del tiled6
     out["ringpp_q1_row_layout"] = entry(1, ev_ms(lambda: ring.corr_sweep_fft(q1, db6), reps=3, warm=1), 351360)
-    q = db6[:4].contiguous()
-    out["ringpp_q4"] = entry(4, ev_ms(lambda: ring.corr_sweep_fft(q, db6), reps=3, warm=1), 351360)
+    out["ringpp_q4_row_layout"] = entry(4, ev_ms(lambda: ring.corr_sweep_fft(q, db6), reps=3, warm=1), 351360)
     del db6
     # DiSCO (disco_ros/main.py:284-291): nearest 1024-d signature over the database, then ONE phase correlation
     g = torch.Generator(device=device).manual_seed(3)
@@ -876,7 +883,8 @@ def compact_line(d, detail_name):
         "gicp_cov_from_knn_frac": _get(g, "roofline", "k_cov_from_knn", "frac"), "gicp_cov_from_knn_ms": r.get("gicp_cov_from_knn_ms"),
         "gicp_knn_select_ms": r.get("gicp_knn_select_ms"),
         "ring_q1_frac": _get(sw, "ring_q1", "hbm_frac"), "ringpp_q1_frac": _get(sw, "ringpp_q1", "hbm_frac"),
-        "ring_q4_pairs_per_s": _get(sw, "ring_q4", "pairs_per_s"), "ringpp_q4_pairs_per_s": _get(sw, "ringpp_q4", "pairs_per_s"),
+        "ring_q4_pairs_per_s": _get(sw, "ring_q4", "pairs_per_s"), "ring_q8_pairs_per_s": _get(sw, "ring_q8", "pairs_per_s"),
+        "ringpp_q4_pairs_per_s": _get(sw, "ringpp_q4", "pairs_per_s"),
         "disco_q1_ms": _get(sw, "disco_q1", "ms"),
         "node_twin_pairs_per_s": _get(d, "node_shape", "twin_pairs_per_s"),
         "node_unchanged_loop_pairs_per_s": _get(d, "node_shape", "reference_loop_through_dropin", "pairs_per_s"),

@@ -438,6 +438,13 @@ int mrs_ring_corr_fft_sweep_blocks(mrs_ctx* ctx, const float* d_spec, const int6
 int mrs_ring_spec_to_tiled(mrs_ctx* ctx, const float* d_half_spec, int32_t n, float* d_tiled, mrs_stream stream);
 int mrs_ring_corr_fft_sweep_tiled(mrs_ctx* ctx, const float* d_query_spec, const float* d_db_tiled, int32_t n_db, int32_t channels, float* d_dist,
                                   int32_t* d_angle, mrs_stream stream);
+/* The same for n_query queries at once ([n_query][channels][61][120] complex64, row layout; d_dist / d_angle [n_query][n_db]): one robot's scan
+ * against the other robots' lists, or the three callbacks' scans against one list (main_RING.py:241-390; BASELINE configs[3]).  Every
+ * (query, entry) goes through the one-query pipeline unchanged (bit-identical results); the workgroups that sweep the same entries for
+ * different queries share an XCD, so an entry is fetched from HBM once per launch and served to the others by that XCD's L2.  Launches of at
+ * most 32 (channels = 1) / 8 (channels > 1) queries; more are split. */
+int mrs_ring_corr_fft_sweep_tiled_q(mrs_ctx* ctx, const float* d_query_spec, int32_t n_query, const float* d_db_tiled, int32_t n_db, int32_t channels,
+                                    float* d_dist, int32_t* d_angle, mrs_stream stream);
 
 /* One launch for the new-descriptor side of a batch of loop checks: half spectra of n_pairs freshly normalised
  * sinograms (d_half_spec and/or its fp16 replica, either may be null) and their correlation with one candidate
@@ -577,10 +584,19 @@ int mrs_loopdb_clear(mrs_loopdb* db);
 int mrs_loopdb_append(mrs_loopdb* db, const void* descriptor, int32_t form, int32_t count, mrs_stream stream);
 /* The candidate loop of detect_loop_icp (main_RING.py:133-140): scores `descriptor` against every entry with one sweep and returns, in
  * index order, the entries with dist < dist_threshold (float32 comparison): h_index / h_dist / h_angle [max_out] and *h_count (the number
- * that qualified; when it exceeds max_out only the first max_out were written).  h_all_dist / h_all_angle (optional, [size]) receive the
- * score of every entry.  Blocking; an empty database returns *h_count = 0 without device work. */
+ * that qualified; when it exceeds max_out only the first max_out were written).  h_all_dist / h_all_angle (optional, [all_capacity]) receive
+ * the scores of the first min(n, all_capacity) entries, *h_n (optional) the number of entries n this call scored -- another thread may append
+ * between the caller's mrs_loopdb_size and this call, so arrays are never written past all_capacity.  Blocking; an empty database returns
+ * *h_count = 0 without device work. */
 int mrs_loopdb_query(mrs_loopdb* db, const void* descriptor, int32_t form, float dist_threshold, int32_t max_out, int32_t* h_index,
-                     float* h_dist, int32_t* h_angle, int32_t* h_count, float* h_all_dist, int32_t* h_all_angle, mrs_stream stream);
+                     float* h_dist, int32_t* h_angle, int32_t* h_count, int32_t all_capacity, float* h_all_dist, int32_t* h_all_angle, int32_t* h_n,
+                     mrs_stream stream);
+/* `count` descriptors (consecutive in memory, all in the same form; 1 .. 1024) against every entry in ONE sweep
+ * (mrs_ring_corr_fft_sweep_tiled_q): the shape of one robot's scan against several lists, of the three callbacks' scans against one list
+ * (main_RING.py:241-390), and of BASELINE configs[3].  h_all_dist / h_all_angle [count][all_capacity]: row q = the scores of query q over
+ * the first min(n, all_capacity) entries; *h_n = n.  Same bits as `count` calls of mrs_loopdb_query.  Blocking. */
+int mrs_loopdb_query_multi(mrs_loopdb* db, const void* descriptors, int32_t form, int32_t count, int32_t all_capacity, float* h_all_dist,
+                           int32_t* h_all_angle, int32_t* h_n, mrs_stream stream);
 /* DiSCO: signature float32 [1024], spectrum complex64 [40][120] (DiSCO.forward's two outputs, disco_ros/models/DiSCO.py:315-334). */
 int mrs_loopdb_append_disco(mrs_loopdb* db, const float* signature, const float* spectrum, int32_t on_device, mrs_stream stream);
 /* disco_ros/main.py:284-291 in two launches: nearest signature (squared L2, ties to the lower index) and phase_corr(FFT_candidates[idx],

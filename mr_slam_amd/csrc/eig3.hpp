@@ -13,6 +13,8 @@
 //   polish      : one step of Rayleigh-quotient iteration  v <- adj(A - (v^T A v) I) v  on the smallest eigenvector;
 //   degenerate  : exactly collinear neighbours (rank 1) give a unit vector orthogonal to the line; the zero matrix and multiples of the
 //                 identity give (1, 0, 0), like the Jacobi this replaces.
+// Products feeding sums may contract to FMAs here (the library is otherwise built with -ffp-contract=off): nothing is compared bit for bit
+// with this solver's output, and an FMA only removes a rounding.
 // Compiled for the device by hipcc and for the host by g++ (tests/test_eig3.py checks this very text against LAPACK and the oracle).
 #pragma once
 #include <cmath>
@@ -44,6 +46,9 @@ MRS_HD double eig3_scale(const double* c, Sym3& s)
 
 MRS_HD void eig3_cross(const double* a, const double* b, double* c)
 {
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
     c[0] = a[1] * b[2] - a[2] * b[1];
     c[1] = a[2] * b[0] - a[0] * b[2];
     c[2] = a[0] * b[1] - a[1] * b[0];
@@ -63,6 +68,9 @@ struct Eig3Stages {
 
 MRS_HD void eig3_stages(const Sym3& s, Eig3Stages& g)
 {
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
     const double q = (s.a00 + s.a11 + s.a22) * (1.0 / 3.0);
     const double b00 = s.a00 - q, b11 = s.a11 - q, b22 = s.a22 - q;
     const double off = s.a01 * s.a01 + s.a02 * s.a02 + s.a12 * s.a12;
@@ -124,6 +132,9 @@ MRS_HD void eig3_stages(const Sym3& s, Eig3Stages& g)
 // unit eigenvector of the smallest eigenvalue of the symmetric 3x3 `c` (row-major, 9 doubles) -> n_out[3]
 MRS_HD void smallest_eigvec(const double* c, double* n_out)
 {
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
     Sym3 s;
     eig3_scale(c, s);
     Eig3Stages g;
@@ -166,6 +177,9 @@ MRS_HD void smallest_eigvec(const double* c, double* n_out)
 // eigenvalues of the symmetric 3x3 `c`, DESCENDING (w[0] >= w[1] >= w[2])
 MRS_HD void sym3_eigvals(const double* c, double* w)
 {
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
     Sym3 s;
     const double m = eig3_scale(c, s);
     Eig3Stages g;

@@ -1487,6 +1487,7 @@ template <int KMAX, bool WANT_Z>
 __device__ __forceinline__ int neighbour_moments(const float4* __restrict__ pts, const int* __restrict__ nb /* slot s at nb[64 s] */, int k, int self,
                                                  const float4& q, double (&cv)[9], float (&nz)[KMAX])
 {
+#pragma clang fp contract(fast)
     constexpr int NCH = (KMAX + kMomChunk - 1) / kMomChunk;
     int idx[3][kMomChunk];                                 // chunk c lives in [c % 3]: indices run two chunks ahead of the sums, points one
     float px[2][kMomChunk], py[2][kMomChunk], pz[2][kMomChunk];

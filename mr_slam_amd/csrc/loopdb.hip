@@ -199,18 +199,32 @@ int reserve_locked(mrs_loopdb* db, int want)
     float *ne = nullptr, *ns = nullptr, *nd = nullptr, *hd = nullptr;
     int32_t *na = nullptr, *ha = nullptr;
     const size_t slack = db->kind == MRS_LOOPDB_DISCO ? 0 : 1;   // the tiled sweep reads up to 1 KiB past the last entry
-    MRS_HIP_TRY(hipMalloc(&ne, ((size_t)cap + slack) * db->entry_floats * sizeof(float)));
-    if (slack) MRS_HIP_TRY(hipMemsetAsync(ne + (size_t)cap * db->entry_floats, 0, db->entry_floats * sizeof(float), db->s));
-    if (db->kind == MRS_LOOPDB_DISCO) MRS_HIP_TRY(hipMalloc(&ns, (size_t)cap * db->sig_dim * sizeof(float)));
-    // distances and angles of a query lie back to back ([n] floats, [n] ints: the angles start at element n, wherever n stands) so that ONE copy
-    // brings both to the host; d_dist / h_dist own the 2 x cap elements, d_angle / h_angle are not separate allocations
-    MRS_HIP_TRY(hipMalloc(&nd, (size_t)2 * cap * sizeof(float)));
-    MRS_HIP_TRY(hipHostMalloc(&hd, (size_t)2 * cap * sizeof(float), hipHostMallocDefault));
-    if (db->n > 0) {
-        MRS_HIP_TRY(hipMemcpyAsync(ne, db->d_entries, (size_t)db->n * db->entry_floats * sizeof(float), hipMemcpyDeviceToDevice, db->s));
-        if (ns) MRS_HIP_TRY(hipMemcpyAsync(ns, db->d_sigs, (size_t)db->n * db->sig_dim * sizeof(float), hipMemcpyDeviceToDevice, db->s));
+    // every failure path releases what this call has allocated so far (the out-of-memory case must not get worse on retry)
+    auto grow = [&]() -> hipError_t {
+        hipError_t e = hipMalloc(&ne, ((size_t)cap + slack) * db->entry_floats * sizeof(float));
+        if (e != hipSuccess) return e;
+        if (slack && (e = hipMemsetAsync(ne + (size_t)cap * db->entry_floats, 0, db->entry_floats * sizeof(float), db->s)) != hipSuccess) return e;
+        if (db->kind == MRS_LOOPDB_DISCO && (e = hipMalloc(&ns, (size_t)cap * db->sig_dim * sizeof(float))) != hipSuccess) return e;
+        // distances and angles of a query lie back to back ([n] floats, [n] ints: the angles start at element n, wherever n stands) so that ONE
+        // copy brings both to the host; d_dist / h_dist own the 2 x cap elements, d_angle / h_angle are not separate allocations
+        if ((e = hipMalloc(&nd, (size_t)2 * cap * sizeof(float))) != hipSuccess) return e;
+        if ((e = hipHostMalloc(&hd, (size_t)2 * cap * sizeof(float), hipHostMallocDefault)) != hipSuccess) return e;
+        if (db->n > 0) {
+            if ((e = hipMemcpyAsync(ne, db->d_entries, (size_t)db->n * db->entry_floats * sizeof(float), hipMemcpyDeviceToDevice, db->s)) != hipSuccess) return e;
+            if (ns && (e = hipMemcpyAsync(ns, db->d_sigs, (size_t)db->n * db->sig_dim * sizeof(float), hipMemcpyDeviceToDevice, db->s)) != hipSuccess) return e;
+        }
+        return hipStreamSynchronize(db->s);
+    };
+    const hipError_t e = grow();
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(db->s);
+        if (ne) (void)hipFree(ne);
+        if (ns) (void)hipFree(ns);
+        if (nd) (void)hipFree(nd);
+        if (hd) (void)hipHostFree(hd);
+        mrs::set_error("growing a loop database to %d entries failed: %s", cap, hipGetErrorString(e));
+        return MRS_ERR_HIP;
     }
-    MRS_HIP_TRY(hipStreamSynchronize(db->s));
     free_arrays(db);
     db->d_entries = ne; db->d_sigs = ns; db->d_dist = nd; db->d_angle = na; db->h_dist = hd; db->h_angle = ha;
     db->cap = cap;
@@ -402,16 +416,19 @@ int mrs_loopdb_append(mrs_loopdb* db, const void* descriptor, int32_t form, int3
 }
 
 int mrs_loopdb_query(mrs_loopdb* db, const void* descriptor, int32_t form, float dist_threshold, int32_t max_out, int32_t* h_index,
-                     float* h_dist, int32_t* h_angle, int32_t* h_count, float* h_all_dist, int32_t* h_all_angle, mrs_stream stream)
+                     float* h_dist, int32_t* h_angle, int32_t* h_count, int32_t all_capacity, float* h_all_dist, int32_t* h_all_angle, int32_t* h_n,
+                     mrs_stream stream)
 {
     MRS_REQUIRE(db && descriptor && h_count, "null pointer");
     MRS_REQUIRE(db->kind != MRS_LOOPDB_DISCO, "DiSCO databases are queried with mrs_loopdb_query_disco");
     MRS_REQUIRE(form == MRS_LOOPDB_FORM_HOST || form == MRS_LOOPDB_FORM_DEVICE || form == MRS_LOOPDB_FORM_DEVICE_SPEC, "unknown form");
     MRS_REQUIRE(max_out >= 0 && (max_out == 0 || (h_index && h_dist && h_angle)), "output arrays");
+    MRS_REQUIRE(all_capacity >= 0 && (all_capacity == 0 || h_all_dist || h_all_angle), "all_capacity without an array");
     MRS_HIP_TRY(hipSetDevice(db->ctx->device));
     std::lock_guard<std::mutex> lk(db->mu);
     *h_count = 0;
     const int n = db->n;
+    if (h_n) *h_n = n;                                     // the entries this call scored (another thread may append right after)
     if (n == 0) return MRS_OK;                             // `for idx in range(0)`: no candidates, no work
     int st = to_half_spectrum(db, descriptor, form, db->d_query, (hipStream_t)stream);
     if (st != MRS_OK) return st;
@@ -429,8 +446,59 @@ int mrs_loopdb_query(mrs_loopdb* db, const void* descriptor, int32_t form, float
             ++cnt;
         }
     *h_count = cnt;                                         // may exceed max_out: the caller then asks again with larger arrays
-    if (h_all_dist) memcpy(h_all_dist, db->h_dist, (size_t)n * sizeof(float));
-    if (h_all_angle) memcpy(h_all_angle, db->h_angle, (size_t)n * sizeof(int32_t));
+    const size_t m = (size_t)std::min(n, all_capacity);     // never past the caller's arrays, whatever was appended since it sized them
+    if (h_all_dist) memcpy(h_all_dist, db->h_dist, m * sizeof(float));
+    if (h_all_angle) memcpy(h_all_angle, db->h_angle, m * sizeof(int32_t));
+    return MRS_OK;
+}
+
+int mrs_loopdb_query_multi(mrs_loopdb* db, const void* descriptors, int32_t form, int32_t count, int32_t all_capacity, float* h_all_dist,
+                           int32_t* h_all_angle, int32_t* h_n, mrs_stream stream)
+{
+    MRS_REQUIRE(db && descriptors && h_all_dist && h_all_angle && h_n, "null pointer");
+    MRS_REQUIRE(db->kind != MRS_LOOPDB_DISCO, "DiSCO databases are queried with mrs_loopdb_query_disco");
+    MRS_REQUIRE(form == MRS_LOOPDB_FORM_HOST || form == MRS_LOOPDB_FORM_DEVICE || form == MRS_LOOPDB_FORM_DEVICE_SPEC, "unknown form");
+    MRS_REQUIRE(count >= 1 && count <= 1024 && all_capacity >= 0, "count in 1..1024");
+    MRS_HIP_TRY(hipSetDevice(db->ctx->device));
+    std::lock_guard<std::mutex> lk(db->mu);
+    const int n = db->n;
+    *h_n = n;
+    if (n == 0) return MRS_OK;
+    const int C = db->channels;
+    const size_t spec_floats = (size_t)C * kSpecFloats;
+    mrs::Scratch qbuf, out;
+    int st = qbuf.alloc((size_t)count * spec_floats * sizeof(float), db->s);
+    if (st != MRS_OK) return st;
+    st = out.alloc((size_t)count * 2 * n * sizeof(float), db->s);
+    if (st != MRS_OK) return st;
+    float* d_q = qbuf.as<float>();
+    if (form == MRS_LOOPDB_FORM_DEVICE_SPEC) {
+        st = join_in(db, (hipStream_t)stream);
+        if (st != MRS_OK) return st;
+        MRS_HIP_TRY(hipMemcpyAsync(d_q, descriptors, (size_t)count * spec_floats * sizeof(float), hipMemcpyDeviceToDevice, db->s));
+    } else {
+        const size_t step = db->kind == MRS_LOOPDB_RING ? (size_t)kA * kD * 2 : db->in_floats;     // floats from one descriptor to the next in the caller's array
+        for (int i = 0; i < count; ++i) {
+            st = to_half_spectrum(db, static_cast<const float*>(descriptors) + (size_t)i * step, form, d_q + (size_t)i * spec_floats, (hipStream_t)stream);
+            if (st != MRS_OK) return st;
+        }
+    }
+    float* d_dist = out.as<float>();                                     // [count][n] distances, then [count][n] angles
+    int32_t* d_angle = reinterpret_cast<int32_t*>(d_dist + (size_t)count * n);
+    st = mrs_ring_corr_fft_sweep_tiled_q(db->ctx, d_q, count, db->d_entries, n, C, d_dist, d_angle, db->s);
+    if (st != MRS_OK) return st;
+    const size_t m = (size_t)std::min(n, all_capacity);
+    if (m > 0) {
+        MRS_HIP_TRY(hipMemcpy2DAsync(h_all_dist, (size_t)all_capacity * sizeof(float), d_dist, (size_t)n * sizeof(float), m * sizeof(float), count,
+                                     hipMemcpyDeviceToHost, db->s));
+        MRS_HIP_TRY(hipMemcpy2DAsync(h_all_angle, (size_t)all_capacity * sizeof(int32_t), d_angle, (size_t)n * sizeof(int32_t), m * sizeof(int32_t), count,
+                                     hipMemcpyDeviceToHost, db->s));
+    }
+    if (form != MRS_LOOPDB_FORM_HOST) {
+        MRS_HIP_TRY(hipEventRecord(db->ev_out, db->s));
+        MRS_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, db->ev_out, 0));
+    }
+    MRS_HIP_TRY(hipStreamSynchronize(db->s));
     return MRS_OK;
 }
 

@@ -205,7 +205,8 @@ struct FftCorrP {
     float denom;  // 0.15 * C * A * D
     const long long* db_first;   // optional (sweeps): query q sweeps the ndb entries that start at entry db_first[q] of DB (NULL: entry 0)
     const long long* q_row;      // optional (sweeps): query q is entry q_row[q] of Q (NULL: entry q)
-    float2* mc_partial;          // k_ring_sweep_dma<MC>: per-lane |corr| sums of every (channel, candidate, half): [C][ndb][128]
+    float2* mc_partial;          // k_ring_sweep_dma<MC>: per-lane |corr| sums of every (query, channel, candidate, half): [nq][C][ndb][128]
+    int units;                   // k_ring_sweep_dma with nq > 1: (channel, slice) units of the launch (see there); 0 otherwise
 };
 
 __device__ __forceinline__ float2 load_spec(const float2* p) { return *p; }
@@ -527,10 +528,20 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_sweep_dma(const float2* __r
     // MC (RING++, C channels): a workgroup keeps ONE channel for its lifetime (its query plane is staged once, no barrier ever after) and
     // shares the candidates with the other workgroups of that channel; the per-lane sums go to p.mc_partial and k_ring_mc_finish adds
     // the channels in order, so the bits are those of the channel-outer kernel (k_ring_sweep_mc).
+    // Several queries per launch (round 6, p.units > 0): workgroup i -> XCD x = i % 8 (where the hardware puts it: MI355X_MICROARCH.md, "block b runs
+    // on XCD b % 8" -- a speed assumption only), k = i / 8; query k % nq, unit (k / nq) * 8 + x.  The nq workgroups that sweep the SAME unit's
+    // candidates for different queries therefore sit on ONE XCD and, doing the same work per candidate, move through the database in step: an
+    // entry is fetched from HBM once and served to the other nq - 1 workgroups by that XCD's L2 (the DMA loads of this form use the default
+    // cache policy, not `nt`).  Every (query, candidate) is scored by the one-query pipeline unchanged: same bits.
+    const bool multi = p.units > 0;
+    const int bx = multi ? (int)((blockIdx.x >> 3) / p.nq) * 8 + (int)(blockIdx.x & 7) : (int)blockIdx.x;     // (channel, slice) unit
+    const int nbx = multi ? p.units : (int)gridDim.x;
+    const int qy = multi ? (int)((blockIdx.x >> 3) % p.nq) : (int)blockIdx.y;                                    // query
+    if (multi && bx >= nbx) return;                      // grid padding (whole workgroup, before any barrier)
     const int C = MC ? p.channels : 1;
-    const int ch = MC ? (int)(blockIdx.x % C) : 0;
-    const int slice = MC ? (int)(blockIdx.x / C) : (int)blockIdx.x;
-    const int nslices = MC ? ((int)gridDim.x - ch + C - 1) / C : (int)gridDim.x;
+    const int ch = MC ? bx % C : 0;
+    const int slice = MC ? bx / C : bx;
+    const int nslices = MC ? (nbx - ch + C - 1) / C : nbx;
     const int c0 = SPLIT ? slice * (WAVES / 2) + (wave >> 1) : slice * WAVES + wave;
     const int cstride = nslices * (SPLIT ? WAVES / 2 : WAVES);
     const int my_half = SPLIT ? (wave & 1) : 0;
@@ -572,7 +583,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_sweep_dma(const float2* __r
         return u;
     };
 
-    const float2* const qsrc = Q + (size_t)(MC ? ch : (int)blockIdx.y) * qentry;
+    const float2* const qsrc = Q + ((size_t)qy * C + (size_t)ch) * qentry;           // queries are [nq][C][61][120], row layout
     if (QDMA) {
         // the query rides the same engine: 58 pieces of 1 KiB dealt to the waves (the last one 192 B: lanes 0-11), then the unit's
         // first RING elements behind them -- the barrier below needs only the former (vmcnt(RING)), the latter stay in flight across it
@@ -662,13 +673,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_sweep_dma(const float2* __r
 
         if (MC) {
             static_assert(!MC || !SPLIT, "the multi-channel form keeps both halves of a candidate on one wave");
-            p.mc_partial[((size_t)ch * p.ndb + c) * 128 + h * 64 + lane] = make_float2(w0, w1);
+            p.mc_partial[(((size_t)qy * C + ch) * p.ndb + c) * 128 + h * 64 + lane] = make_float2(w0, w1);
             if (h == 1) c = c_next;
         } else if (!SPLIT) {
             if (h == 0) { accA0 = w0; accA1 = w1; }
             else {
                 const float s0 = (accA0 + w0) * kOrtho120, s1 = (accA1 + w1) * kOrtho120;
-                const size_t o = (size_t)blockIdx.y * p.ndb + c;
+                const size_t o = (size_t)qy * p.ndb + c;
                 sweep_epilogue(s0, s1, lane, p.denom, dist + o, angle + o);
                 c = c_next;
             }
@@ -692,7 +703,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ring_sweep_dma(const float2* __r
                 const float s0 = (a0 + b0) * kOrtho120, s1 = (a1 + b1) * kOrtho120;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const size_t o = (size_t)blockIdx.y * p.ndb + c;
+                const size_t o = (size_t)qy * p.ndb + c;
                 sweep_epilogue(s0, s1, lane, p.denom, dist + o, angle + o);
             }
             c += cstride;
@@ -710,12 +721,14 @@ __global__ __launch_bounds__(256) void k_ring_mc_finish(const float2* __restrict
 {
     const int cand = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (cand >= ndb) return;
+    partial += (size_t)blockIdx.y * C * ndb * 128;       // query blockIdx.y
     float2 lo = make_float2(0.0f, 0.0f), hi = make_float2(0.0f, 0.0f);
     for (int c = 0; c < C; ++c) {
         const float2 a = partial[((size_t)c * ndb + cand) * 128 + lane], b = partial[((size_t)c * ndb + cand) * 128 + 64 + lane];
         lo.x += a.x; lo.y += a.y; hi.x += b.x; hi.y += b.y;
     }
-    sweep_epilogue((lo.x + hi.x) * kOrtho120, (lo.y + hi.y) * kOrtho120, lane, denom, dist + cand, angle + cand);
+    const size_t o = (size_t)blockIdx.y * ndb + cand;
+    sweep_epilogue((lo.x + hi.x) * kOrtho120, (lo.y + hi.y) * kOrtho120, lane, denom, dist + o, angle + o);
 }
 
 // [n][61][120] half spectra (row layout) -> the DMA-tiled entries above; grid = entries, 256 lanes
@@ -977,8 +990,18 @@ static hipError_t sweep_dma_launch_t(int num_cu, hipStream_t s, const float2* q,
         attr_set.fetch_or(1u << (dev & 31), std::memory_order_relaxed);
     }
     const int per_wg = SPLIT ? WAVES / 2 : WAVES;
-    int blocks = std::max(1, std::min(num_cu, (p.ndb + per_wg - 1) / per_wg));
-    if (MC) blocks = std::max(p.channels, std::min(num_cu, p.channels * ((p.ndb + per_wg - 1) / per_wg)));   // every channel needs a workgroup
+    const int C = MC ? p.channels : 1;
+    const int need = C * ((p.ndb + per_wg - 1) / per_wg);             // units that have work
+    if (p.nq > 1) {
+        // nq workgroups per unit, all of them on the unit's XCD (see the kernel): groups of 8 units x nq queries
+        FftCorrP pm = p;
+        pm.units = std::max(C, std::min(std::max(8, num_cu / (8 * p.nq) * 8), need));
+        const int grid = (pm.units + 7) / 8 * 8 * p.nq;
+        hipLaunchKernelGGL(kern, dim3(grid, 1), dim3(WAVES * 64), lds, s, q, db, pm, dist, angle);
+        return hipGetLastError();
+    }
+    int blocks = std::max(1, std::min(num_cu, need));
+    if (MC) blocks = std::max(p.channels, blocks);                    // every channel needs a workgroup
     hipLaunchKernelGGL(kern, dim3(blocks, 1), dim3(WAVES * 64), lds, s, q, db, p, dist, angle);
     return hipGetLastError();
 }
@@ -997,18 +1020,69 @@ static hipError_t sweep_dma_launch(int variant, int num_cu, hipStream_t s, const
     return hipErrorInvalidValue;
 }
 
-// RING++ (C channels), one query: channel-per-workgroup DMA sweep into per-lane partial sums + the finishing kernel
+// Several queries per sweep on the LDS-DMA pipeline: at most this many per launch (the queries of a launch share the compute units: 256 / (8 nq)
+// groups of 8 units each)
+constexpr int kSweepDmaMaxQ = 32;
+constexpr int kSweepDmaMaxQMc = 8;       // RING++: the partial sums of a launch are nq x C x ndb x 1 KiB of scratch
+constexpr int kSweepDmaMultiDefault = 10012;   // default cache policy (the other queries' workgroups find the entry in L2), priority, 12 waves
+
+// RING++ (C channels), p.nq queries (<= kSweepDmaMaxQMc): channel-per-workgroup DMA sweep into per-lane partial sums + the finishing kernel
 static int sweep_dma_mc(mrs_ctx* ctx, hipStream_t s, const float2* q, const float2* db, FftCorrP p, float* dist, int* angle, bool tiled)
 {
     mrs::Scratch part;
-    int st = part.alloc((size_t)p.channels * p.ndb * 128 * sizeof(float2), s);
+    int st = part.alloc((size_t)p.nq * p.channels * p.ndb * 128 * sizeof(float2), s);
     if (st != MRS_OK) return st;
     p.mc_partial = part.as<float2>();
     const int num_cu = ctx->num_cu > 0 ? ctx->num_cu : 256;
-    if (tiled) MRS_HIP_TRY((sweep_dma_launch_t<8, false, 1, true, true, true>(num_cu, s, q, db, p, dist, angle)));
-    else MRS_HIP_TRY((sweep_dma_launch_t<8, false, 1, false, true, true>(num_cu, s, q, db, p, dist, angle)));
-    hipLaunchKernelGGL(k_ring_mc_finish, dim3((p.ndb + 3) / 4), dim3(256), 0, s, p.mc_partial, p.ndb, p.channels, p.denom, dist, angle);
+    if (p.nq > 1) {
+        const char* v = mrs::dev_env("MRS_SWEEP_MQ_MC_WAVES");       // 12 waves (three per SIMD): 23.3-23.5 M pairs/s at 4 queries against 22.7 with 8
+        if (!v || atoi(v) == 12) {
+            if (tiled) MRS_HIP_TRY((sweep_dma_launch_t<12, false, 0, true, true, true>(num_cu, s, q, db, p, dist, angle)));
+            else MRS_HIP_TRY((sweep_dma_launch_t<12, false, 0, false, true, true>(num_cu, s, q, db, p, dist, angle)));
+        } else {
+            if (tiled) MRS_HIP_TRY((sweep_dma_launch_t<8, false, 0, true, true, true>(num_cu, s, q, db, p, dist, angle)));
+            else MRS_HIP_TRY((sweep_dma_launch_t<8, false, 0, false, true, true>(num_cu, s, q, db, p, dist, angle)));
+        }
+    } else {
+        if (tiled) MRS_HIP_TRY((sweep_dma_launch_t<8, false, 1, true, true, true>(num_cu, s, q, db, p, dist, angle)));
+        else MRS_HIP_TRY((sweep_dma_launch_t<8, false, 1, false, true, true>(num_cu, s, q, db, p, dist, angle)));
+    }
+    hipLaunchKernelGGL(k_ring_mc_finish, dim3((p.ndb + 3) / 4, p.nq), dim3(256), 0, s, p.mc_partial, p.ndb, p.channels, p.denom, dist, angle);
     MRS_HIP_TRY(hipGetLastError());
+    return MRS_OK;
+}
+
+// 1 .. any number of queries over exact fp32 entries (row layout or DMA-tiled) through the LDS-DMA pipeline, in launches of at most
+// kSweepDmaMaxQ (single channel) / kSweepDmaMaxQMc (RING++) queries; dist / angle are [n_q][ndb]
+static int sweep_dma_queries(mrs_ctx* ctx, hipStream_t s, const float2* q, int n_q, const float2* db, FftCorrP p, float* dist, int* angle, bool tiled)
+{
+    const int num_cu = ctx->num_cu > 0 ? ctx->num_cu : 256;
+    const int C = p.channels;
+    const int maxq = C > 1 ? kSweepDmaMaxQMc : kSweepDmaMaxQ;
+    const size_t qentry = (size_t)C * kHalf * kD;
+    for (int q0 = 0; q0 < n_q; q0 += maxq) {
+        p.nq = std::min(maxq, n_q - q0);
+        const float2* qq = q + (size_t)q0 * qentry;
+        float* dd = dist + (size_t)q0 * p.ndb;
+        int* aa = angle + (size_t)q0 * p.ndb;
+        if (C > 1) {
+            const int st = sweep_dma_mc(ctx, s, qq, db, p, dd, aa, tiled);
+            if (st != MRS_OK) return st;
+            continue;
+        }
+        if (tiled && p.nq == 2 && !mrs::dev_env("MRS_SWEEP_MQ_VARIANT")) {
+            // two queries over tiled entries: the pair of workgroups moves at the pace of the one that misses (213 us per 10 000 entries), two
+            // one-query sweeps at the HBM rate take 2 x 96 us
+            FftCorrP p1 = p;
+            p1.nq = 1;
+            for (int i = 0; i < 2; ++i)
+                MRS_HIP_TRY(sweep_dma_launch(kSweepDmaTiledDefault, num_cu, s, qq + (size_t)i * qentry, db, p1, dd + (size_t)i * p.ndb, aa + (size_t)i * p.ndb, true));
+            continue;
+        }
+        int variant = p.nq > 1 ? kSweepDmaMultiDefault : (tiled ? kSweepDmaTiledDefault : kSweepDmaDefault);
+        if (const char* v = mrs::dev_env(p.nq > 1 ? "MRS_SWEEP_MQ_VARIANT" : "MRS_SWEEP_VARIANT")) variant = atoi(v) > 0 ? atoi(v) : variant;
+        MRS_HIP_TRY(sweep_dma_launch(variant, num_cu, s, qq, db, p, dd, aa, tiled));
+    }
     return MRS_OK;
 }
 
@@ -1023,7 +1097,7 @@ static int corr_fft_launch(mrs_ctx* ctx, const float* d_q, int32_t n_q, const vo
     FftCorrP p;
     p.nq = n_q; p.ndb = n_db; p.pairwise = pairwise ? 1 : 0; p.channels = channels;
     p.denom = (float)(0.15 * channels * kA * kD);
-    p.db_first = d_db_first; p.q_row = d_q_row; p.mc_partial = nullptr;
+    p.db_first = d_db_first; p.q_row = d_q_row; p.mc_partial = nullptr; p.units = 0;
     MRS_REQUIRE(!(d_db_first || d_q_row) || (!pairwise && channels == 1 && std::is_same<DBT, float2>::value && n_q <= mrs::kMaxGridY),
                 "per-query database blocks: single-channel fp32 sweeps of at most 65535 queries");
     constexpr int NSLOT = 2;
@@ -1061,13 +1135,15 @@ static int corr_fft_launch(mrs_ctx* ctx, const float* d_q, int32_t n_q, const vo
                 bool launched = false;
                 if constexpr (std::is_same<DBT, float2>::value) {
                     // one query, exact entries (the node's loop: main_RING.py:133): the LDS-DMA pipeline, one workgroup per compute unit
-                    if (n_q == 1 && !d_corr && !d_db_first && !d_q_row) {
-                        int variant = kSweepDmaDefault;
-                        if (const char* v = mrs::dev_env("MRS_SWEEP_VARIANT")) variant = atoi(v);
-                        if (variant > 0) {
-                            MRS_HIP_TRY(sweep_dma_launch(variant, ctx->num_cu > 0 ? ctx->num_cu : 256, s, qq, dd, p, dist_c, angle_c));
-                            launched = true;
-                        }
+                    // ... and, since round 6, a few queries at once (one robot's scan against the other robots' lists: BASELINE configs[3]):
+                    // the same pipeline, the queries' workgroups grouped per XCD so that the entry is fetched from HBM once
+                    const char* v1 = mrs::dev_env("MRS_SWEEP_VARIANT");
+                    const char* vq = mrs::dev_env("MRS_SWEEP_MQ_VARIANT");
+                    const bool off = nq == 1 ? (v1 && atoi(v1) == 0) : (vq && atoi(vq) == 0);
+                    if (nq <= kSweepDmaMaxQ && !off && !d_corr && !d_db_first && !d_q_row) {
+                        const int st = sweep_dma_queries(ctx, s, qq, nq, dd, p, dist_c, angle_c, false);
+                        if (st != MRS_OK) return st;
+                        launched = true;
                     }
                 }
                 if constexpr (std::is_same<DBT, __half2>::value) {
@@ -1083,9 +1159,10 @@ static int corr_fft_launch(mrs_ctx* ctx, const float* d_q, int32_t n_q, const vo
                     MRS_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                     hipLaunchKernelGGL(kern, dim3(blocks, nq), dim3(NSLOT * kSlotThreads), lds, s, qq, dd, p, dist_c, angle_c, corr_c);
                 }
-            } else if (std::is_same<DBT, float2>::value && n_q == 1 && !d_corr && !(mrs::dev_env("MRS_SWEEP_VARIANT") && atoi(mrs::dev_env("MRS_SWEEP_VARIANT")) == 0)) {
-                // one query (the node's loop, main_RINGplusplus.py:131-134): LDS-DMA pipeline, one channel per workgroup
-                const int st = sweep_dma_mc(ctx, s, qq, reinterpret_cast<const float2*>(dd), p, dist_c, angle_c, false);
+            } else if (std::is_same<DBT, float2>::value && nq <= kSweepDmaMaxQMc && !d_corr &&
+                       !(mrs::dev_env(nq == 1 ? "MRS_SWEEP_VARIANT" : "MRS_SWEEP_MQ_VARIANT") && atoi(mrs::dev_env(nq == 1 ? "MRS_SWEEP_VARIANT" : "MRS_SWEEP_MQ_VARIANT")) == 0)) {
+                // one query (the node's loop, main_RINGplusplus.py:131-134) or a few: LDS-DMA pipeline, one channel per workgroup
+                const int st = sweep_dma_queries(ctx, s, qq, nq, reinterpret_cast<const float2*>(dd), p, dist_c, angle_c, false);
                 if (st != MRS_OK) return st;
             } else {
                 constexpr int MAXR = 8;
@@ -1129,24 +1206,24 @@ int mrs_ring_spec_to_tiled(mrs_ctx* ctx, const float* d_half_spec, int32_t n, fl
     return MRS_OK;
 }
 
-int mrs_ring_corr_fft_sweep_tiled(mrs_ctx* ctx, const float* d_query_spec, const float* d_db_tiled, int32_t n_db, int32_t channels, float* d_dist,
-                                  int32_t* d_angle, mrs_stream stream)
+int mrs_ring_corr_fft_sweep_tiled_q(mrs_ctx* ctx, const float* d_query_spec, int32_t n_query, const float* d_db_tiled, int32_t n_db, int32_t channels,
+                                    float* d_dist, int32_t* d_angle, mrs_stream stream)
 {
     MRS_REQUIRE(ctx && d_query_spec && d_db_tiled && d_dist && d_angle, "null pointer");
-    MRS_REQUIRE(n_db > 0 && channels > 0, "counts must be positive");
+    MRS_REQUIRE(n_query > 0 && n_db > 0 && channels > 0, "counts must be positive");
     MRS_HIP_TRY(hipSetDevice(ctx->device));
     FftCorrP p;
     p.nq = 1; p.ndb = n_db; p.pairwise = 0; p.channels = channels;
     p.denom = (float)(0.15 * channels * kA * kD);
-    p.db_first = nullptr; p.q_row = nullptr; p.mc_partial = nullptr;
-    if (channels > 1)
-        return sweep_dma_mc(ctx, (hipStream_t)stream, reinterpret_cast<const float2*>(d_query_spec), reinterpret_cast<const float2*>(d_db_tiled), p, d_dist,
-                            d_angle, true);
-    int variant = kSweepDmaTiledDefault;
-    if (const char* v = mrs::dev_env("MRS_SWEEP_VARIANT")) variant = atoi(v) > 0 ? atoi(v) : variant;
-    MRS_HIP_TRY(sweep_dma_launch(variant, ctx->num_cu > 0 ? ctx->num_cu : 256, (hipStream_t)stream, reinterpret_cast<const float2*>(d_query_spec),
-                                 reinterpret_cast<const float2*>(d_db_tiled), p, d_dist, d_angle, true));
-    return MRS_OK;
+    p.db_first = nullptr; p.q_row = nullptr; p.mc_partial = nullptr; p.units = 0;
+    return sweep_dma_queries(ctx, (hipStream_t)stream, reinterpret_cast<const float2*>(d_query_spec), n_query, reinterpret_cast<const float2*>(d_db_tiled), p,
+                             d_dist, d_angle, true);
+}
+
+int mrs_ring_corr_fft_sweep_tiled(mrs_ctx* ctx, const float* d_query_spec, const float* d_db_tiled, int32_t n_db, int32_t channels, float* d_dist,
+                                  int32_t* d_angle, mrs_stream stream)
+{
+    return mrs_ring_corr_fft_sweep_tiled_q(ctx, d_query_spec, 1, d_db_tiled, n_db, channels, d_dist, d_angle, stream);
 }
 
 int mrs_ring_corr_fft_sweep_blocks(mrs_ctx* ctx, const float* d_spec, const int64_t* d_query_row, int32_t n_query, const int64_t* d_db_first,

@@ -58,10 +58,7 @@ class LoopDatabase:
         self.channels = 1 if kind == "ring" else int(channels or 6)
         self._h = C.c_void_p()
         lib = _lib.load()
-        lib.mrs_loopdb_query.argtypes = None
         _lib.check(lib.mrs_loopdb_create(_lib.ctx(self.device), KIND[kind], self.channels, int(capacity), C.byref(self._h)))
-        self._cap_out = 0
-        self._out = None
 
     def __del__(self):
         try:
@@ -102,28 +99,62 @@ class LoopDatabase:
         _lib.check(_lib.load().mrs_loopdb_append(self._h, C.c_void_p(torch.view_as_real(spectra).data_ptr()), FORM_DEVICE_SPEC, int(n),
                                                  _lib.current_stream(self.device)))
 
-    def _buffers(self, n):
-        if self._cap_out < n:
-            cap = max(256, 1 << (n - 1).bit_length())
-            self._out = (np.empty(cap, np.int32), np.empty(cap, np.float32), np.empty(cap, np.int32))
-            self._cap_out = cap
-        return self._out
-
     def query(self, descriptor, threshold, want_all=False):
         """-> (idxs int32[m], dists float32[m], angles int32[m]) with dist < threshold, in index order
-        (+ (all_dists, all_angles) over every entry with want_all)."""
+        (+ (all_dists, all_angles) over every entry with want_all).
+        Thread-safe: the node's callbacks query one twin from concurrent rospy threads (callback1 and callback3 both score against TIRING2) and
+        ctypes drops the GIL during the call, so every call owns its output arrays; the entries scored are the n the C side reports (an
+        append from another thread between sizing the arrays and the sweep can neither overflow nor truncate them silently)."""
         p, form, keep = self._descriptor(descriptor)
-        n = len(self)
-        idx, dist, ang = self._buffers(max(n, 1))
-        cnt = C.c_int32(0)
-        alld = np.empty(n, np.float32) if want_all else None
-        alla = np.empty(n, np.int32) if want_all else None
-        _lib.check(_lib.load().mrs_loopdb_query(self._h, p, form, C.c_float(threshold), int(idx.size), _lib.ptr(idx), _lib.ptr(dist), _lib.ptr(ang),
-                                                C.byref(cnt), _lib.ptr(alld) if want_all else None, _lib.ptr(alla) if want_all else None,
-                                                self._stream(form)))
+        lib = _lib.load()
+        cap = max(len(self), 1) + 64                       # room for entries another thread appends before the sweep runs
+        while True:
+            idx, dist, ang = np.empty(cap, np.int32), np.empty(cap, np.float32), np.empty(cap, np.int32)
+            alld = np.empty(cap, np.float32) if want_all else None
+            alla = np.empty(cap, np.int32) if want_all else None
+            cnt, n = C.c_int32(0), C.c_int32(0)
+            _lib.check(lib.mrs_loopdb_query(self._h, p, form, C.c_float(threshold), int(cap), _lib.ptr(idx), _lib.ptr(dist), _lib.ptr(ang),
+                                            C.byref(cnt), int(cap) if want_all else 0, _lib.ptr(alld) if want_all else None,
+                                            _lib.ptr(alla) if want_all else None, C.byref(n), self._stream(form)))
+            if cnt.value <= cap and n.value <= cap:
+                break
+            cap = max(cnt.value, n.value) + 64             # the list grew by more than the slack meanwhile: once more, with room
         m = cnt.value
-        out = (idx[:m].copy(), dist[:m].copy(), ang[:m].copy())
-        return out + (alld, alla) if want_all else out
+        out = (idx[:m], dist[:m], ang[:m])
+        return out + (alld[:n.value], alla[:n.value]) if want_all else out
+
+    def query_multi(self, descriptors):
+        """Several new descriptors against every entry in ONE sweep (mrs_loopdb_query_multi): `descriptors` = a list / stacked tensor of
+        descriptors in one of the forms `query` takes -> (dists float32 [Q, n], angles int32 [Q, n]); row q carries the bits of
+        query(descriptors[q], want_all=True)."""
+        if isinstance(descriptors, (list, tuple)):
+            descriptors = torch.stack([torch.as_tensor(d) for d in descriptors])
+        q = descriptors
+        nq = int(q.shape[0])
+        is_spec = q.is_cuda and q.is_complex() and tuple(q.shape[-2:]) == (61, 120)
+        if is_spec:
+            t = q.to(torch.complex64).contiguous()
+            assert t.numel() == nq * self.channels * 61 * 120
+            form = FORM_DEVICE_SPEC
+        elif self.kind == "ring":
+            t = q.to(torch.complex64).contiguous()
+            assert t.numel() == nq * 120 * 120
+            form = FORM_DEVICE if t.is_cuda else FORM_HOST
+        else:
+            t = q.to(torch.float32).contiguous()
+            assert t.numel() == nq * self.channels * 120 * 120
+            form = FORM_DEVICE if t.is_cuda else FORM_HOST
+        ptr = C.c_void_p((torch.view_as_real(t) if t.is_complex() else t).data_ptr())
+        lib = _lib.load()
+        cap = max(len(self), 1) + 64
+        while True:
+            alld, alla = np.empty((nq, cap), np.float32), np.empty((nq, cap), np.int32)
+            n = C.c_int32(0)
+            _lib.check(lib.mrs_loopdb_query_multi(self._h, ptr, form, nq, int(cap), _lib.ptr(alld), _lib.ptr(alla), C.byref(n), self._stream(form)))
+            if n.value <= cap:
+                break
+            cap = n.value + 64
+        return alld[:, :n.value], alla[:, :n.value]
 
     def device_entries(self):
         """(device pointer, n, floats per entry) of the stored entries (tests)"""

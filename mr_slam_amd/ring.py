@@ -482,6 +482,23 @@ def corr_sweep_fft_tiled(query_spec, tiled, n_db=None):
     return dist, ang
 
 
+def corr_sweep_fft_tiled_q(query_specs, tiled, n_db=None):
+    """Q queries ([Q,C,61,120] / [Q,61,120] complex64, row layout) against a DMA-tiled database in one call (mrs_ring_corr_fft_sweep_tiled_q: the
+    one-query LDS-DMA pipeline, the queries' workgroups grouped per XCD): (dist [Q,n], angle [Q,n]), bit-identical to corr_sweep_fft(queries, db)."""
+    d = _dev(query_specs)
+    q = query_specs.contiguous()
+    channels = tiled.shape[1] // TILED_ENTRY_FLOATS
+    assert q.dtype == torch.complex64 and q.numel() % (channels * 61 * 120) == 0 and tiled.dtype == torch.float32 and tiled.is_contiguous()
+    nq = q.numel() // (channels * 61 * 120)
+    n = int(n_db if n_db is not None else tiled.shape[0] - 1)
+    assert 0 < n < tiled.shape[0], "the tiled array needs one entry of slack behind the last one"
+    dist = torch.empty((nq, n), dtype=torch.float32, device=q.device)
+    ang = torch.empty((nq, n), dtype=torch.int32, device=q.device)
+    _lib.check(_lib.load().mrs_ring_corr_fft_sweep_tiled_q(_lib.ctx(d), _lib.ptr(torch.view_as_real(q)), int(nq), _lib.ptr(tiled), n, int(channels),
+                                                           _lib.ptr(dist), _lib.ptr(ang), _lib.current_stream(d)))
+    return dist, ang
+
+
 def corr_sweep_fft_blocks(spec_pool, query_rows, db_first, n_db, out=None, check=False):
     """Several C1 sweeps in one launch: query q = entry query_rows[q] of spec_pool ([E,61,120] complex64) against the n_db entries that start
     at entry db_first[q] (int64 device tensors).  Returns (dist [Q,n_db], angle [Q,n_db]); bit-identical to corr_sweep_fft per query.

@@ -347,3 +347,85 @@ def test_exchange_through_the_c_abi_on_one_rank():
     assert torch.equal(torch.view_as_real(got), torch.view_as_real(spec[rows]))
     with pytest.raises(Exception):
         x.fetch_rows(spec, torch.tensor([48], device="cuda:0"))                # outside the database
+
+
+def test_one_twin_queried_from_two_threads_while_a_third_appends():
+    """callback1 and callback3 both score against TIRING2 on separate rospy threads (main_RING.py:284-288, 378-382), and ctypes
+    drops the GIL during mrs_loopdb_query.  Every call owns its output arrays and takes n from the C side: two threads hammering ONE twin with
+    different queries, while a third appends, must each get exactly their own serial answers over the entries their call scored."""
+    import threading
+    import torch
+    from mr_slam_amd import node, ring
+    N, EXTRA = 400, 200
+    norm = _norm_sinograms(N + EXTRA + 2, 77)
+    half = ring.half_spectrum(norm).contiguous()
+    db = node.LoopDatabase("ring", capacity=8)
+    db.extend_spectra(half[:N])
+    qs = [half[N + EXTRA:N + EXTRA + 1], half[N + EXTRA + 1:N + EXTRA + 2]]
+    full = [ring.corr_sweep_fft(q, half[:N + EXTRA]) for q in qs]           # scores over everything that will ever be in the list
+    want = [(d.cpu().numpy()[0], a.cpu().numpy()[0]) for d, a in full]
+    errors, counts = [], [0, 0]
+    stop = threading.Event()
+
+    def reader(t):
+        try:
+            wd, wa = want[t]
+            while not stop.is_set():
+                idx, d, a, alld, alla = db.query(qs[t], 0.7, want_all=True)
+                n = alld.size
+                assert N <= n <= N + EXTRA and alla.size == n
+                assert np.array_equal(alld, wd[:n]) and np.array_equal(alla, wa[:n]), "another thread's scores"
+                sel = np.nonzero(wd[:n] < np.float32(0.7))[0]
+                assert np.array_equal(idx, sel) and np.array_equal(d, wd[sel]) and np.array_equal(a, wa[sel])
+                counts[t] += 1
+        except Exception as e:                                  # noqa: BLE001
+            errors.append(repr(e))
+            stop.set()
+
+    def writer():
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for i in range(N, N + EXTRA):
+                    db.append(half[i:i + 1])
+        except Exception as e:                                  # noqa: BLE001
+            errors.append(repr(e))
+        finally:
+            stop.set()
+
+    th = [threading.Thread(target=reader, args=(0,)), threading.Thread(target=reader, args=(1,)), threading.Thread(target=writer)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errors, errors
+    assert len(db) == N + EXTRA and min(counts) >= 2, counts
+
+
+def test_query_multi_equals_single_queries_bit_for_bit():
+    """mrs_loopdb_query_multi: Q new descriptors against the list in ONE sweep (one robot's scan against several lists / the three callbacks at
+    once / BASELINE configs[3]) -- row q = the scores of query(descriptor q), for host TIRING tensors, device tensors, device half spectra, RING
+    and RING++."""
+    import torch
+    from mr_slam_amd import node, ring
+    N = 700
+    norm = _norm_sinograms(N + 5, 31)
+    half = ring.half_spectrum(norm).contiguous()
+    full = torch.cat([half, half[:, 1:60].flip(1).conj()], 1).contiguous()
+    db = node.LoopDatabase("ring", capacity=64)
+    db.extend_spectra(half[:N])
+    for nq in (1, 2, 3, 5):
+        singles = [db.query(full[N + i:N + i + 1], 2.0, want_all=True) for i in range(nq)]
+        for q in (full[N:N + nq].cpu(), full[N:N + nq], half[N:N + nq], [full[N + i].cpu() for i in range(nq)]):
+            D, A = db.query_multi(q)
+            assert D.shape == (nq, N)
+            for i in range(nq):
+                assert np.array_equal(D[i], singles[i][3]) and np.array_equal(A[i], singles[i][4]), (nq, i)
+    C = 6
+    g = torch.Generator(device="cuda:0").manual_seed(19)
+    tiring = torch.rand((60 + 3, C, 120, 120), device="cuda:0", generator=g) * 3.0
+    dbp = node.LoopDatabase("ringpp", channels=C, capacity=8)
+    for i in range(60):
+        dbp.append(tiring[i])
+    D, A = dbp.query_multi(tiring[60:63].cpu())
+    for i in range(3):
+        _, _, _, alld, alla = dbp.query(tiring[60 + i], 9.0, want_all=True)
+        assert np.array_equal(D[i], alld) and np.array_equal(A[i], alla)
+    assert node.LoopDatabase("ring").query_multi(full[:2])[0].shape == (2, 0)

@@ -514,3 +514,48 @@ def test_blocked_sweeps_equal_single_sweeps_bit_for_bit(dev):
         wd, wa = ring.corr_sweep_fft(pool[int(qrow[i]):int(qrow[i]) + 1], pool[int(first[i]):int(first[i]) + n_db])
         assert torch.equal(d[i], wd[0]) and torch.equal(a[i], wa[0]), i
     assert int(torch.argmin(d[0])) == 5 and int(torch.argmin(d[2])) == 50 and int(torch.argmin(d[4])) == 0     # the query itself where its slice holds it
+
+
+def test_several_queries_per_dma_sweep_equal_single_query_sweeps_bit_for_bit(dev):
+    """Round 6: mrs_ring_corr_fft_sweep_tiled_q (and the row-layout mrs_ring_corr_fft_sweep[_mc] with 2 .. 32 queries) run the one-query LDS-DMA
+    pipeline for Q queries in one launch, the queries' workgroups grouped per XCD.  Every (query, entry) must carry the bits of the
+    one-query sweep and of the register-staged k_ring_corr_fft (MRS_SWEEP_MQ_VARIANT=0 is only reachable under MRS_DEV, so the pairwise
+    kernel is the independent reference here): Q = 2, 4, 5 (groups with idle workgroups), 33 (two launches), databases smaller than one
+    round of a workgroup and ragged ones; RING++ with Q = 3 and 9 (two launches)."""
+    import torch
+    from mr_slam_amd import ring
+    g = torch.Generator(device=dev).manual_seed(21)
+    n_pool = 2500
+    sino = torch.rand((n_pool, 120, 120), device=dev, generator=g) * (torch.rand((n_pool, 120, 120), device=dev, generator=g) < 0.3)
+    pool = ring.half_spectrum(ring.normalize(sino[:, None])[:, 0]).contiguous()
+    for n_db in (2500, 2049, 61, 5):
+        db = pool[:n_db].contiguous()
+        tiled = ring.spec_to_tiled(db)
+        for nq in (2, 4, 5, 33):
+            qrows = torch.randint(0, n_pool, (nq,), device=dev, generator=g)
+            q = pool[qrows].contiguous()
+            d, a = ring.corr_sweep_fft_tiled_q(q, tiled)
+            assert d.shape == (nq, n_db)
+            dr, ar = ring.corr_sweep_fft(q, db)                     # row layout, same pipeline for nq <= 32
+            assert torch.equal(d, dr) and torch.equal(a, ar), (n_db, nq)
+            for qi in (0, nq - 1):
+                d1, a1 = ring.corr_sweep_fft_tiled(q[qi], tiled)    # the one-query form
+                assert torch.equal(d[qi], d1) and torch.equal(a[qi], a1), (n_db, nq, qi)
+            pick = torch.randint(0, n_db, (min(n_db, 64),), device=dev, generator=g)
+            wd, wa = ring.corr_pairs_fft(q[:1].expand(len(pick), -1, -1).contiguous(), db[pick].contiguous())
+            assert torch.equal(d[0, pick], wd) and torch.equal(a[0, pick], wa)
+    # RING++: 6 channels
+    C = 6
+    for n_pp in (700, 9):
+        idx = torch.randint(0, n_pool, (n_pp, C), device=dev, generator=g)
+        spp = pool[idx.reshape(-1)].reshape(n_pp, C, 61, 120).contiguous()
+        tiled = ring.spec_to_tiled(spp)
+        for nq in (3, 9):
+            q = spp[torch.randint(0, n_pp, (nq,), device=dev, generator=g)].contiguous()
+            d, a = ring.corr_sweep_fft_tiled_q(q, tiled)
+            for qi in range(nq):
+                d1, a1 = ring.corr_sweep_fft_tiled(q[qi], tiled)
+                assert torch.equal(d[qi], d1) and torch.equal(a[qi], a1), (n_pp, nq, qi)
+            pick = torch.randint(0, n_pp, (min(n_pp, 32),), device=dev, generator=g)
+            wd, wa = ring.corr_pairs_fft(q[1:2].expand(len(pick), -1, -1, -1).contiguous(), spp[pick].contiguous())
+            assert torch.equal(d[1, pick], wd) and torch.equal(a[1, pick], wa)
