@@ -33,6 +33,40 @@ const char* dev_env(const char* name)
     return on ? v : nullptr;
 }
 
+int side_acquire(mrs_ctx* ctx, SideSlot* out)
+{
+    {
+        std::lock_guard<std::mutex> lk(ctx->side_mu);
+        if (!ctx->side_free.empty()) {
+            *out = ctx->side_free.back();
+            ctx->side_free.pop_back();
+            return MRS_OK;
+        }
+    }
+    SideSlot sl;
+    hipError_t e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipHostMalloc(&sl.pinned, kSidePinnedInts * sizeof(int), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        if (sl.pinned) (void)hipHostFree(sl.pinned);
+        if (sl.join) (void)hipEventDestroy(sl.join);
+        if (sl.fork) (void)hipEventDestroy(sl.fork);
+        if (sl.stream) (void)hipStreamDestroy(sl.stream);
+        set_error("side stream slot: %s", hipGetErrorString(e));
+        return MRS_ERR_HIP;
+    }
+    *out = sl;
+    return MRS_OK;
+}
+
+void side_release(mrs_ctx* ctx, const SideSlot& slot)
+{
+    if (!slot.stream) return;
+    std::lock_guard<std::mutex> lk(ctx->side_mu);
+    ctx->side_free.push_back(slot);
+}
+
 // ---- scratch allocator (see common.hpp) -------------------------------------------------------------------------
 namespace {
 struct ScratchBlock {
@@ -189,6 +223,13 @@ int mrs_ctx_destroy(mrs_ctx* ctx)
         if (kv.second) (void)hipFree(kv.second);
     if (ctx->pointfeat_free)
         for (auto& kv : ctx->pointfeat_cache) ctx->pointfeat_free(kv.second);
+    for (auto& sl : ctx->side_free) {
+        (void)hipStreamSynchronize(sl.stream);
+        (void)hipHostFree(sl.pinned);
+        (void)hipEventDestroy(sl.join);
+        (void)hipEventDestroy(sl.fork);
+        (void)hipStreamDestroy(sl.stream);
+    }
     delete ctx;
     return MRS_OK;
 }

@@ -80,7 +80,23 @@ struct SectorLut {
 
 }  // namespace mrs
 
+namespace mrs {
+// A second stream + fork / join events + a small pinned buffer, kept in a per-context pool: a registration of one pair (the nodes' shape)
+// borrows one for the duration of mrs_gicp_batch_align.  Creating them per handle cost 0.4 ms per FastGICP object (the nodes construct one
+// per registration, main_RING.py:84); concurrent callers (three rospy callback threads) each get their own slot.
+struct SideSlot {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    int* pinned = nullptr;      // kSidePinnedInts ints
+};
+constexpr int kSidePinnedInts = 64;
+int side_acquire(mrs_ctx* ctx, SideSlot* out);   // MRS_OK / MRS_ERR_HIP
+void side_release(mrs_ctx* ctx, const SideSlot& slot);
+}  // namespace mrs
+
 struct mrs_ctx {
+    std::mutex side_mu;
+    std::vector<mrs::SideSlot> side_free;
     int device = 0;
     int num_cu = 0;
     size_t lds_bytes = 0;

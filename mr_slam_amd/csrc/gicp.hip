@@ -1902,6 +1902,7 @@ __global__ void k_lm_update(LmState* __restrict__ st, const double* __restrict__
     if (threadIdx.x != 0) return;
     const double y = sum[27];
     const int limit = prm.force_iters > 0 ? prm.force_iters : prm.max_iter;
+    if (S.phase == 0) n_next[3] = 1;                    // this tick carried a linearisation (= a nearest-neighbour pass): counted by the host
 
     if (S.phase == 0) {
         int t = 0;
@@ -2036,6 +2037,14 @@ __global__ void k_corr_to_original(const float4* __restrict__ src_all, const int
 
 }  // namespace
 
+// Small batches (<= kLmWindowPairs pairs: ONE registration at a time is how the nodes call it, main_RING.py:81-104, global_manager.cpp:2016-2021)
+// run the LM schedule in windows of kLmWindow ticks without a host round trip in between: every kernel of a tick gates itself on the pair's
+// device-side state (active / phase / motion), so a tick launched for a pair that has converged, or the search kernels of a tick that is an LM
+// trial, are empty launches.  The host reads the per-tick counters once per window instead of copying + synchronising after every tick
+// (rounds 1-5: ~10 round trips of 40-60 us per registration of two 35 k-point clouds).  Same kernels on the same state: same bits.
+constexpr int kLmWindowPairs = 8;
+constexpr int kLmWindow = 4;
+constexpr int kLmWindowMax = 16;
 // ------------------------------------------------------------------------------------------------
 struct mrs_gicp_batch {
     mrs_ctx* ctx = nullptr;
@@ -2842,7 +2851,7 @@ static int ensure_state(mrs_gicp_batch* h)
     if (!h->d_state) {
         MRS_HIP_TRY(hipMalloc(&h->d_state, h->n_pairs * sizeof(LmState)));
         MRS_HIP_TRY(hipMalloc(&h->d_nblocks, h->n_pairs * sizeof(int)));
-        MRS_HIP_TRY(hipMalloc(&h->d_nactive, 4 * sizeof(int)));
+        MRS_HIP_TRY(hipMalloc(&h->d_nactive, kLmWindowMax * 4 * sizeof(int)));
     }
     if (mb > h->cap_blocks) {
         if (h->d_partial) (void)hipFree(h->d_partial);
@@ -2920,6 +2929,25 @@ int mrs_gicp_batch_align(mrs_gicp_batch* h, const double* h_guess, double* h_fin
     MRS_HIP_TRY(hipSetDevice(h->ctx->device));
     hipStream_t s = (hipStream_t)stream;
     int st;
+    const bool small = h->n_pairs <= kLmWindowPairs;
+    // a second stream, two events and a pinned buffer from the context's pool for the duration of this call (small batches only)
+    struct Side {
+        mrs_ctx* ctx; mrs::SideSlot sl;
+        ~Side() { mrs::side_release(ctx, sl); }
+    } side{h->ctx, {}};
+    if (small && (st = mrs::side_acquire(h->ctx, &side.sl)) != MRS_OK) return st;
+    if (small && !h->cov_valid[0] && !h->cov_valid[1] && !mrs::dev_env("MRS_GICP_SERIAL_COV")) {
+        // both clouds are new (every registration of the nodes): a cloud of 30-40 k points fills 150 of the 256 compute units with one wave per
+        // SIMD, so the two k-NN + covariance passes run side by side on two streams instead of back to back
+        MRS_HIP_TRY(hipEventRecord(side.sl.fork, s));
+        MRS_HIP_TRY(hipStreamWaitEvent(side.sl.stream, side.sl.fork, 0));
+        st = mrs_gicp_batch_compute_covariances(h, 1, nullptr, (mrs_stream)side.sl.stream);
+        if (st != MRS_OK) return st;
+        MRS_HIP_TRY(hipEventRecord(side.sl.join, side.sl.stream));
+        st = mrs_gicp_batch_compute_covariances(h, 0, nullptr, stream);
+        if (st != MRS_OK) return st;
+        MRS_HIP_TRY(hipStreamWaitEvent(s, side.sl.join, 0));
+    }
     for (int w = 0; w < 2; ++w)
         if (!h->cov_valid[w]) { st = mrs_gicp_batch_compute_covariances(h, w, nullptr, stream); if (st != MRS_OK) return st; }
     st = ensure_state(h);
@@ -2945,6 +2973,29 @@ int mrs_gicp_batch_align(mrs_gicp_batch* h, const double* h_guess, double* h_fin
     const long max_ticks = (long)limit * (h->prm.lm_max_iter + 1) + 1;
     long ticks = 0, nn_ticks = 0;
     int next[3] = {h->n_pairs, 0, h->n_pairs};   // pairs to linearise (phase 0), pairs in an LM trial (phase 1), pairs of [0] that moved far
+    int window = kLmWindow;
+    if (const char* v = mrs::dev_env("MRS_GICP_WINDOW")) window = std::max(0, std::min(kLmWindowMax, atoi(v)));
+    if (small && window > 1 && h->prm.voxel_res <= 0.0) {
+        static_assert(kLmWindowMax * 4 <= mrs::kSidePinnedInts, "the slot's pinned buffer holds a window's counters");
+        int* const h_win = side.sl.pinned;
+        while (next[0] + next[1] > 0 && ticks < max_ticks) {
+            MRS_HIP_TRY(hipMemsetAsync(h->d_nactive, 0, (size_t)window * 4 * sizeof(int), s));
+            for (int t = 0; t < window; ++t) {
+                h->big_movers = 1;                      // the broad search gates itself on the pair's motion (k_nn_scan: gate)
+                if ((st = nn_pass(h, (ticks == 0 && t == 0) ? 0 : 1, s)) != MRS_OK) return st;
+                launch_linearize(grid, s, h->d_pts[0], h->d_offs[0], h->d_cov[0],
+                                   h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->d_corr, h->d_partial, h->max_blocks);
+                hipLaunchKernelGGL(k_lm_update, dim3(h->n_pairs), dim3(64), 0, s, h->d_state, h->d_partial, h->d_nblocks,
+                                   h->max_blocks, h->prm, h->d_nactive + 4 * t);
+            }
+            MRS_HIP_TRY(hipGetLastError());
+            MRS_HIP_TRY(hipMemcpyAsync(h_win, h->d_nactive, (size_t)window * 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+            MRS_HIP_TRY(hipStreamSynchronize(s));
+            for (int t = 0; t < window; ++t) nn_ticks += h_win[4 * t + 3];
+            for (int i = 0; i < 3; ++i) next[i] = h_win[4 * (window - 1) + i];
+            ticks += window;
+        }
+    }
     while (next[0] + next[1] > 0 && ticks < max_ticks) {
         MRS_HIP_TRY(hipMemsetAsync(h->d_nactive, 0, 4 * sizeof(int), s));
         if (h->prm.voxel_res > 0.0) {

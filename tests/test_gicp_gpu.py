@@ -157,6 +157,44 @@ def test_pygicp_drop_in(dev, oracle):
     assert _pose_err(T, Ttrue)[0] < 0.05
 
 
+def test_windowed_lm_schedule_equals_the_per_tick_schedule_bit_for_bit(dev):
+    """Round 6: batches of <= 8 pairs (one registration at a time is how the nodes call fast_gicp, main_RING.py:81-104,
+    global_manager.cpp:2016-2021) run the LM schedule in windows of 4 ticks with no host round trip in between and compute the two clouds'
+    covariances side by side on two streams.  Same kernels on the same device-side state: transforms, iteration counts, convergence flags,
+    Hessians and the number of nearest-neighbour passes must equal the per-tick schedule (development switch MRS_GICP_WINDOW=0) bit for bit --
+    one pair, three pairs that converge at different ticks, forced iterations, and a window that is not a divisor of the tick count."""
+    import os
+    from mr_slam_amd import gicp
+    pairs = [_pair(21 + i, 9000 + 2500 * i, (0.01 * i, -0.02, 0.05 + 0.02 * i), (0.4 + 0.2 * i, -0.3, 0.05)) for i in range(3)]
+
+    def run(n, env, **prm):
+        old = {k: os.environ.get(k) for k in ("MRS_DEV", "MRS_GICP_WINDOW", "MRS_GICP_SERIAL_COV")}
+        os.environ.update(env)
+        try:
+            b = gicp.GicpBatch(n)
+            b.set_params(max_correspondence_distance=5.0, **prm)
+            b.set_sources([p[0] for p in pairs[:n]]); b.set_targets([p[1] for p in pairs[:n]])
+            T, conv, its = b.align()
+            return T.copy(), conv.copy(), its.copy(), b.nn_passes, b.hessian.copy()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    per_tick = {"MRS_DEV": "1", "MRS_GICP_WINDOW": "0", "MRS_GICP_SERIAL_COV": "1"}
+    for n, prm in ((1, {}), (3, {}), (2, {"force_iterations": 5}), (1, {"k_correspondences": 15})):
+        want = run(n, per_tick, **prm)
+        for env in ({}, {"MRS_DEV": "1", "MRS_GICP_WINDOW": "3"}, {"MRS_DEV": "1", "MRS_GICP_WINDOW": "16"}):
+            got = run(n, env, **prm)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]), (n, prm, env)
+            assert got[3] == want[3], (got[3], want[3])
+            if want[4] is not None:
+                assert np.array_equal(got[4], want[4])
+        if not prm:
+            assert want[1].all() and _pose_err(want[0][0], pairs[0][2])[0] < 0.05
+
+
 def test_force_iterations_and_failure_modes(dev):
     from mr_slam_amd import gicp, _lib
     src, tgt, _ = _pair(8, 5000)
