@@ -169,6 +169,78 @@ def ring_descriptors_fused(xyz, offsets, num_ring=NUM_RING, num_sector=NUM_SECTO
     return img, sino, norm
 
 
+class DeviceMirror:
+    """Device twins of HOST tensors, by identity -- what lets the UNCHANGED candidate loop of the nodes
+        for idx in range(len(pc_candidates)): dist, angle = fast_corr(TIRING_current, TIRING_candidates[idx])      (main_RING.py:133-134)
+    run through the drop-in without re-uploading two 115 KB host tensors per candidate (round 5: 4.4 k pairs/s, all of it PCIe round trips).
+    The reference keeps its descriptors as CPU tensors in Python lists (generate_RING returns `.cpu()` copies, util.py:200); the mirror maps
+    id(tensor) -> (tensor._version, weak reference, device value).  A hit needs the same object at the same version: an in-place torch
+    operation on a cached tensor bumps `_version` and the twin is rebuilt at the next use; a collected tensor frees its slot through the weak
+    reference's callback (and an id re-used by a new tensor can therefore never alias an old entry).  Writes that bypass torch's version
+    counter (through a `.numpy()` view) are not seen -- the nodes never write to a stored descriptor.  `max_bytes` bounds the device memory
+    held (oldest entries go first).  Thread-safe (the nodes' three callbacks share the lists)."""
+
+    def __init__(self, max_bytes=8 << 30):
+        self._d = {}
+        self._lock = threading.Lock()
+        self.max_bytes = int(max_bytes)
+        self.bytes = 0
+        self.hits = self.misses = 0
+
+    def __len__(self):
+        return len(self._d)
+
+    def _evict(self, key, ref=None):
+        with self._lock:
+            ent = self._d.get(key)
+            if ent is not None and (ref is None or ent[1] is ref):
+                del self._d[key]
+                self.bytes -= ent[3]
+
+    def put(self, t, value):
+        """register `value` (device tensor or tuple of them) as the twin of host tensor `t` at its current version"""
+        import weakref
+        key = id(t)
+        nbytes = sum(v.numel() * v.element_size() for v in (value if isinstance(value, tuple) else (value,)) if isinstance(v, torch.Tensor))
+        ref = weakref.ref(t, lambda r, k=key: self._evict(k, r))
+        with self._lock:
+            old = self._d.pop(key, None)
+            if old is not None:
+                self.bytes -= old[3]
+            while self._d and self.bytes + nbytes > self.max_bytes:
+                k0 = next(iter(self._d))               # insertion order: the oldest entry
+                self.bytes -= self._d.pop(k0)[3]
+            self._d[key] = (t._version, ref, value, nbytes)
+            self.bytes += nbytes
+        return value
+
+    def get(self, t, build):
+        """the device twin of host tensor `t`; `build(t)` makes it on a miss"""
+        ent = self._d.get(id(t))
+        if ent is not None and ent[0] == t._version and ent[1]() is t:
+            self.hits += 1
+            return ent[2]
+        self.misses += 1
+        return self.put(t, build(t))
+
+    def clear(self):
+        with self._lock:
+            self._d.clear()
+            self.bytes = 0
+
+
+_mirror = DeviceMirror()
+
+
+def device_mirror():
+    """the process-wide mirror behind fast_corr / fast_corr_RINGplusplus (tests, memory accounting)"""
+    return _mirror
+
+
+def _cacheable(x):
+    return isinstance(x, torch.Tensor) and not x.is_cuda and not x.requires_grad
+
+
 def generate_RING(pc, device="cuda:0"):
     """util.py:174-200 for one pre-processed cloud [n,3]: returns (pc_bev [1,R,S] numpy,
     pc_RING [1,A,D] cpu tensor, pc_TIRING complex64 [1,A,D] cpu tensor)."""
@@ -180,7 +252,11 @@ def generate_RING(pc, device="cuda:0"):
         # THIS call's output, not on the plan-wide counter, which other callers and threads of the cached plan share
         raise ValueError("std evaluated to zero after conversion to torch.float32, leading to division by zero.")
     tiring = fft_angle(norm)
-    return img.cpu().numpy(), sino.cpu(), tiring.cpu()
+    host = tiring.cpu()
+    # the device copy this call already holds becomes the host tensor's twin (Hermitian by construction: the FFT of a real sinogram): fast_corr
+    # never uploads it
+    _mirror.put(host, ("half", tiring[:, :61].contiguous()[None]) if tuple(tiring.shape) == (1, 120, 120) else ("full", tiring))
+    return img.cpu().numpy(), sino.cpu(), host
 
 
 def corr_sweep(query, db, want_corr=False):
@@ -213,34 +289,70 @@ def corr_pairs(a, b, out=None):
     return dist, ang
 
 
+def _tiring_twin(x, device):
+    """TIRING spectrum (complex64 [C,A,D], host or device) -> its device form for fast_corr: ("half", [1,1,61,120]) when it is ONE channel of the
+    reference's 120 x 120 geometry and the spectrum is Hermitian along the angle axis -- every TIRING is: it is the FFT of a real sinogram
+    (util.py:198), so rows 61..119 repeat rows 59..1 conjugated and the pair kernel on half spectra (11 us; the database format) gives
+    fast_corr's numbers -- else ("full", [C,A,D]) for the general kernel (143 us).  The symmetry is CHECKED, once per tensor."""
+    t = torch.as_tensor(x).to(device).to(torch.complex64).contiguous()
+    if t.dim() == 3 and tuple(t.shape) == (1, 120, 120):       # one channel: fast_corr has no channel factor (util.py:369), the RING++ pair kernel has
+        tol = 1e-5 * float(t.abs().max())
+        if float((t[:, 61:] - t[:, 1:60].flip(1).conj()).abs().max()) <= tol and float(t[:, (0, 60)].imag.abs().max()) <= tol:
+            return ("half", t[:, :61].contiguous()[None])
+    return ("full", t)
+
+
+def _full_of(tw):
+    if tw[0] == "full":
+        return tw[1]
+    h = tw[1][0]
+    return torch.cat([h, h[:, 1:60].flip(1).conj()], 1).contiguous()
+
+
 def fast_corr(a, b, device="cuda:0", want_corr=False):
     """util.py:362-374 on TIRING spectra a, b (complex64 [C,A,D], host or device).
-    Returns (dist, angle) as numpy scalars like the reference."""
-    a = torch.as_tensor(a).to(device).to(torch.complex64).contiguous()
-    b = torch.as_tensor(b).to(device).to(torch.complex64).contiguous()
-    Cc, A, D = a.shape
-    d = _dev(a)
-    dist = torch.empty(1, dtype=torch.float32, device=a.device)
-    ang = torch.empty(1, dtype=torch.int32, device=a.device)
-    corr = torch.empty(A, dtype=torch.float32, device=a.device) if want_corr else None
-    _lib.check(_lib.load().mrs_ring_corr_spectra(_lib.ctx(d), _lib.ptr(torch.view_as_real(a)),
-                                                 _lib.ptr(torch.view_as_real(b)), 1, Cc, A, D, _lib.ptr(dist),
-                                                 _lib.ptr(ang), _lib.ptr(corr) if want_corr else None,
+    Returns (dist, angle) as numpy scalars like the reference.  Host TENSORS keep a device twin (DeviceMirror): the node's loop over its stored
+    descriptors costs one small launch and one 8-byte read-back per candidate, no upload after a tensor's first visit."""
+    ta = _mirror.get(a, lambda t: _tiring_twin(t, device)) if _cacheable(a) else _tiring_twin(a, device)
+    tb = _mirror.get(b, lambda t: _tiring_twin(t, device)) if _cacheable(b) else _tiring_twin(b, device)
+    dv = ta[1].device
+    out = torch.empty(2, dtype=torch.float32, device=dv)               # (dist, angle bits): one read-back instead of two
+    if ta[0] == "half" and tb[0] == "half" and ta[1].shape == tb[1].shape and not want_corr:
+        corr_pairs_fft(ta[1][0], tb[1][0], out=(out[0:1], out[1:2].view(torch.int32)))
+        h = out.cpu().numpy()
+        return h[0], h[1:2].view(np.int32)[0]
+    fa, fb = _full_of(ta), _full_of(tb)
+    Cc, A, D = fa.shape
+    d = _dev(fa)
+    corr = torch.empty(A, dtype=torch.float32, device=dv) if want_corr else None
+    _lib.check(_lib.load().mrs_ring_corr_spectra(_lib.ctx(d), _lib.ptr(torch.view_as_real(fa)),
+                                                 _lib.ptr(torch.view_as_real(fb)), 1, Cc, A, D, C.c_void_p(out.data_ptr()),
+                                                 C.c_void_p(out.data_ptr() + 4), _lib.ptr(corr) if want_corr else None,
                                                  _lib.current_stream(d)))
-    out = (dist.cpu().numpy()[0], ang.cpu().numpy()[0])
-    return out + (corr.cpu().numpy(),) if want_corr else out
+    h = out.cpu().numpy()
+    res = (h[0], h[1:2].view(np.int32)[0])
+    return res + (corr.cpu().numpy(),) if want_corr else res
+
+
+def _ringpp_spec(t, device):
+    """RING++ TIRING magnitudes float32 [C,120,120] -> half spectrum of the jointly normalised channels (what fast_corr_RINGplusplus recomputes
+    for both arguments at every comparison, util.py:339-343)"""
+    return half_spectrum(normalize(t.to(device=device, dtype=torch.float32).contiguous()[None]))
 
 
 def fast_corr_RINGplusplus(a, b, device="cuda:0"):
-    """util.py:337-358 on RING++ TIRING magnitudes a, b (float32 [C,A,D])."""
+    """util.py:337-358 on RING++ TIRING magnitudes a, b (float32 [C,A,D]).  Host tensors keep their normalised half spectrum on the device
+    (DeviceMirror): per candidate of the node's loop (main_RINGplusplus.py:131-134) one pair launch, nothing uploaded or re-normalised."""
+    if tuple(torch.as_tensor(a).shape[-2:]) == (120, 120):      # FFT-domain kernel (specialised for the reference geometry)
+        sa = _mirror.get(a, lambda t: _ringpp_spec(t, device)) if _cacheable(a) else _ringpp_spec(torch.as_tensor(a), device)
+        sb = _mirror.get(b, lambda t: _ringpp_spec(t, device)) if _cacheable(b) else _ringpp_spec(torch.as_tensor(b), device)
+        out = torch.empty(2, dtype=torch.float32, device=sa.device)
+        corr_pairs_fft(sa, sb, out=(out[0:1], out[1:2].view(torch.int32)))
+        h = out.cpu().numpy()
+        return h[0], h[1:2].view(np.int32)[0]
     a = torch.as_tensor(a, dtype=torch.float32).to(device).contiguous()
     b = torch.as_tensor(b, dtype=torch.float32).to(device).contiguous()
-    an = normalize(a[None])
-    bn = normalize(b[None])
-    if a.shape[-2:] == (120, 120):      # FFT-domain kernel (specialised for the reference geometry)
-        dist, ang = corr_pairs_fft(half_spectrum(an), half_spectrum(bn))
-        return dist.cpu().numpy()[0], ang.cpu().numpy()[0]
-    dist, ang = corr_sweep(an, bn)
+    dist, ang = corr_sweep(normalize(a[None]), normalize(b[None]))
     return dist.cpu().numpy()[0, 0], ang.cpu().numpy()[0, 0]
 
 
@@ -351,7 +463,10 @@ def generate_RINGplusplus(pc, device="cuda:0"):
     pc_RING [6,A,D] cpu, pc_TIRING [6,A,D] cpu)."""
     pts = torch.from_numpy(np.ascontiguousarray(np.asarray(pc, dtype=np.float32)[:, 0:3])).to(device)
     fb, sino, tiring = ringpp_descriptors(pts, np.array([0, pts.shape[0]], np.int64))
-    return fb[0], sino[0].cpu(), tiring[0].cpu()
+    host = tiring[0].cpu()
+    if tuple(host.shape[-2:]) == (120, 120):
+        _mirror.put(host, _ringpp_spec(tiring[0], device))     # fast_corr_RINGplusplus' device form of this descriptor, made once, here
+    return fb[0], sino[0].cpu(), host
 
 
 def half_spectrum(norm):

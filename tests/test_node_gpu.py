@@ -429,3 +429,64 @@ def test_query_multi_equals_single_queries_bit_for_bit():
         _, _, _, alld, alla = dbp.query(tiring[60 + i], 9.0, want_all=True)
         assert np.array_equal(D[i], alld) and np.array_equal(A[i], alla)
     assert node.LoopDatabase("ring").query_multi(full[:2])[0].shape == (2, 0)
+
+
+def test_unchanged_candidate_loop_uses_device_twins_of_the_host_tensors():
+    """the node's loop AS WRITTEN (main_RING.py:133-134, fast_corr per stored CPU tensor) through the drop-in keeps a device
+    twin per host tensor (ring.DeviceMirror): same numbers as before, no upload after a tensor's first visit, an in-place change to a cached
+    tensor is seen, and a dropped tensor frees its slot."""
+    import gc
+    import torch
+    from mr_slam_amd import ring, synth
+    m = ring.device_mirror()
+    m.clear()
+    scans = [synth.lidar_scan(300 + i, 20000) for i in range(4)]
+    descs = [ring.generate_RING(s) for s in scans]               # (bev, RING cpu, TIRING cpu): the twin is seeded by generate_RING itself
+    assert len(m) == 4 and m.misses == 0
+    TIRING = [d[2] for d in descs]
+    cur = TIRING[3]
+    h0 = m.hits
+    got = [ring.fast_corr(cur, TIRING[i]) for i in range(3)]
+    got0 = got[0]
+    assert m.misses == 0 and m.hits == h0 + 6                     # nothing uploaded
+    for i in range(3):                                            # the same numbers as the uncached path (numpy arguments are never cached)
+        wd, wa = ring.fast_corr(cur.numpy(), TIRING[i].numpy())
+        assert got[i][0] == wd and got[i][1] == wa and isinstance(got[i][0], np.float32)
+    # a host tensor the mirror has never seen (e.g. loaded from disk) is uploaded once
+    fresh = TIRING[0].clone()
+    ring.fast_corr(cur, fresh); ring.fast_corr(cur, fresh)
+    assert m.misses == 1 and len(m) == 5
+    # in-place change of a cached tensor: torch bumps its version, the twin is rebuilt
+    d_before = ring.fast_corr(cur, fresh)[0]
+    fresh.mul_(0.5)
+    d_after, _ = ring.fast_corr(cur, fresh)
+    assert m.misses == 2 and d_after == ring.fast_corr(cur.numpy(), fresh.numpy())[0] and d_after != d_before
+    # a dropped tensor frees its slot (and its device memory)
+    b0 = m.bytes
+    del fresh
+    gc.collect()
+    assert len(m) == 4 and m.bytes < b0
+    # RING++: the normalised half spectrum is the twin
+    C = 6
+    g = torch.Generator().manual_seed(5)
+    A, B = torch.rand((C, 120, 120), generator=g) * 3, torch.rand((C, 120, 120), generator=g) * 3
+    want = ring.fast_corr_RINGplusplus(A.numpy(), B.numpy())
+    mm = m.misses
+    for _ in range(3):
+        got = ring.fast_corr_RINGplusplus(A, B)
+        assert got[0] == want[0] and got[1] == want[1]
+    assert m.misses == mm + 2
+    # the memory bound evicts the oldest entries
+    small = ring.DeviceMirror(max_bytes=3 * 120 * 120 * 8)
+    ts = [torch.zeros((1, 120, 120), dtype=torch.complex64) for _ in range(5)]
+    for t in ts:
+        small.get(t, lambda x: x.cuda())
+    assert len(small) == 3 and small.bytes == 3 * 120 * 120 * 8
+    # a spectrum that is NOT Hermitian along the angle axis takes the general kernel, cached or not, and want_corr returns the curve
+    nh = torch.randn((1, 120, 120), dtype=torch.complex64, generator=g)
+    assert ring._tiring_twin(nh, "cuda:0")[0] == "full" and ring._tiring_twin(TIRING[0], "cuda:0")[0] == "half"
+    r1, r2 = ring.fast_corr(nh, TIRING[0]), ring.fast_corr(nh.numpy(), TIRING[0].numpy())
+    assert r1[0] == r2[0] and r1[1] == r2[1]
+    d3, a3, curve = ring.fast_corr(cur, TIRING[0], want_corr=True)
+    assert curve.shape == (120,) and int(a3) == int(got0[1]) and abs(float(d3) - float(got0[0])) < 1e-5
+    m.clear()
