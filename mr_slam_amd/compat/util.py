@@ -6,11 +6,32 @@ import numpy as np
 import torch
 
 from .. import preprocess as _pre
-from ..node import calculate_row_shift, euler2rot, getSE3          # noqa: F401  (util.py:51-82, 378-385)
 from ..ring import (fast_corr, fast_corr_RINGplusplus, forward_row_fft, generate_RING, generate_RINGplusplus,   # noqa: F401
                     rotate_bev, solve_translation, solve_translation_bev)
 
 device = torch.device("cuda:0")                                    # util.py:23 (there is no CPU path behind these names)
+
+
+def euler2rot(roll, pitch, yaw):
+    """util.py:51-75: R = Rz(yaw) Ry(pitch) Rx(roll)"""
+    cr, sr, cp, sp, cy, sy = np.cos(roll), np.sin(roll), np.cos(pitch), np.sin(pitch), np.cos(yaw), np.sin(yaw)
+    Rx = np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]])
+    Ry = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]])
+    Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def getSE3(x, y, yaw):
+    """util.py:78-82: planar pose as a homogeneous 4 x 4"""
+    T = np.eye(4)
+    T[:3, :3] = euler2rot(0, 0, yaw)
+    T[0, 3], T[1, 3] = x, y
+    return T
+
+
+def calculate_row_shift(shift, num_ring=120):
+    """util.py:378-385 (the node passes cfg.num_ring = 120 implicitly)"""
+    return -shift if shift < num_ring // 2 else shift - num_ring
 
 
 def load_pc_infer(pc):

@@ -9,14 +9,14 @@ writes one slot, and the whole candidate loop is ONE sweep launch that returns t
 Two ways in, both leave the node's callbacks, message handling and ICP untouched:
 
   * `detect_loop_icp = node.bind_detect_loop_icp(globals(), "ring")` after the node's own definition (one line):
-    same signature, same prints, same `loopinfo.txt` lines and published messages; the candidate lists stay plain Python lists -- their
-    device twins are kept in step by identity (entries appended since the last call are uploaded, nothing is re-uploaded);
+    the node's OWN function keeps running (its glue, prints, `loopinfo.txt` lines and messages are its own code), only the names through which
+    it scores the candidates are answered by one sweep of the list's device twin; the candidate lists stay plain Python lists -- their
+    twins are kept in step by identity (entries appended since the last call are uploaded, nothing is re-uploaded);
+  * no edit at all: `compat.install()` alone -- `fast_corr` keeps device twins of the host tensors it is handed (ring.DeviceMirror);
   * `TIRING1 = node.DescriptorList("ring")`: a `list` whose `append` also writes the device slot (no per-call bookkeeping at all).
 """
 import ctypes as C
 import threading
-import time
-import weakref
 
 import numpy as np
 import torch
@@ -244,211 +244,107 @@ def _disco_twin(sigs, ffts, device=0):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------------
-# helpers the nodes define themselves (main_RING.py:60-104, util.py:51-82, 253-260, 378-385); used when the twin is bound without a node
-def euler2rot(roll, pitch, yaw):
-    R_x = np.array([[1, 0, 0], [0, np.cos(roll), -np.sin(roll)], [0, np.sin(roll), np.cos(roll)]])
-    R_y = np.array([[np.cos(pitch), 0, np.sin(pitch)], [0, 1, 0], [-np.sin(pitch), 0, np.cos(pitch)]])
-    R_z = np.array([[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1]])
-    return np.dot(R_z, np.dot(R_y, R_x))
+# Binding the twin to a node.  Rounds 1-5 restated the ~55 lines of host glue that follow the candidate loop (top-1 pick, the two rotation
+# hypotheses, BEV -> lidar frame, ICP gate, loopinfo.txt line, Loops message: main_RING.py:147-236) with the reference's own names; a fix in
+# the node's glue would have silently diverged from that copy.  Now the NODE'S OWN detect_loop_icp runs, unchanged, from its own
+# code object; only the names through which it reaches the candidates are bound to the twin for the duration of the call:
+#   ring   : `fast_corr`               answers entry idx of a table filled by ONE sweep of the device-resident list before the function starts;
+#   ringpp : `fast_corr_RINGplusplus`  likewise;
+#   disco  : `KDTree` / `phase_corr`   answer from the two-launch query (nearest signature + phase correlation of the winner).
+# Everything else -- cfg, f, pub, Loop, Loops, get_pose_msg_from_homo_matrix, fast_gicp, solve_translation, every print -- is looked up in the
+# node's LIVE globals at the moment it is used (names the node defines after the binding line, like `f` and `pub` in its __main__ block, resolve
+# too).  The node's Python loop over the candidates remains (~0.25 us per entry: a table read and a comparison); LoopDatabase.query is the
+# form without it.
+import types
 
 
-def getSE3(x, y, yaw):
-    R = np.eye(4)
-    R[:3, :3] = euler2rot(0, 0, yaw)
-    R[:3, 3] = np.array([x, y, 0])
-    return R
+class _Overlay(dict):
+    """globals of the re-bound function: the few substituted names live here, every other lookup falls through to the node's own globals"""
+
+    def __init__(self, base):
+        super().__init__()
+        self._base = base
+
+    def __missing__(self, key):
+        return self._base[key]
 
 
-def calculate_row_shift(shift, num_ring=120):
-    return -shift if shift < num_ring // 2 else shift - num_ring
-
-
-def fast_gicp(source, target, max_correspondence_distance=1.0, init_pose=np.eye(4)):
-    """main_RING.py:81-104 on the drop-in pygicp"""
-    from .compat import pygicp
-    source = pygicp.downsample(source, 0.2)
-    target = pygicp.downsample(target, 0.2)
-    gicp = pygicp.FastGICP()
-    gicp.set_input_target(target)
-    gicp.set_input_source(source)
-    gicp.set_num_threads(4)
-    gicp.set_max_correspondence_distance(max_correspondence_distance)
-    gicp.align(initial_guess=init_pose)
-    fitness = gicp.get_fitness_score(1.0)
-    return fitness, gicp.get_final_transformation()
-
-
-class _Cfg:
-    """RING_ros/config.py values the loop reads"""
-    num_ring = 120
-    num_sector = 120
-    dist_threshold = 0.48
-    icp_max_distance = 5.0
-    icp_fitness_score = 0.22
-
-
-class LoopResult:
-    """What one detect_loop_icp call decided (the reference prints / publishes it; returned as well for callers that want it)"""
-    __slots__ = ("idxs", "dists", "angles", "idx_matched", "dist", "init_pose", "fitness", "transform", "accepted", "id0", "id1")
-
-    def __init__(self):
-        for k in self.__slots__:
-            setattr(self, k, None)
-        self.accepted = False
-
-
-def bind_detect_loop_icp(ns=None, kind="ring", device="cuda:0", **overrides):
-    """-> detect_loop_icp with the reference's signature for `kind` ("ring": main_RING.py:126, "ringpp": main_RINGplusplus.py:126,
-    "disco": disco_ros/main.py:276).  `ns`: the node's globals() -- cfg, f (loopinfo file), pub, Loop, Loops, robotid_to_key,
-    get_pose_msg_from_homo_matrix, fast_gicp, getSE3 are taken from it when present, so messages, file and ICP are the node's own; the
-    candidate loop, the translation solve and (RING++) the BEV rotation / correlation run on the device.  Keyword overrides replace any of them."""
-    ns = dict(ns or {})
-    ns.update(overrides)
-    from . import preprocess, ring
-    cfg = ns.get("cfg", _Cfg)
-    out = ns.get("print", print)
-    _getSE3 = ns.get("getSE3", getSE3)
-    _fast_gicp = ns.get("fast_gicp", fast_gicp)
-    _key = ns.get("robotid_to_key", preprocess.robotid_to_key)
+def bind_detect_loop_icp(ns, kind="ring", device="cuda:0", **overrides):
+    """-> detect_loop_icp with the node's own signature and behaviour for `kind` ("ring": main_RING.py:126, "ringpp":
+    main_RINGplusplus.py:126, "disco": disco_ros/main.py:276).  `ns`: the node's globals() (it must hold the node's detect_loop_icp, or pass
+    detect_loop_icp=...); keyword overrides replace further names the function uses."""
+    fn = overrides.pop("detect_loop_icp", None) or ns["detect_loop_icp"]
+    ov = _Overlay(fn.__globals__)                            # == ns when the node passes globals()
+    ov.update(overrides)
+    import inspect
+    sig = inspect.signature(fn)
+    tls = threading.local()                                  # the table of the call in flight: the node's callbacks run on concurrent threads
     dev_index = torch.device(device).index or 0
 
-    def publish(res, robotid_current, idx_current, robotid_candidate, idx_matched, loop_transform, tag=""):
-        """main_RING.py:206-236: invert, pose message, loopinfo.txt line, Loops message"""
-        f, pub, Loop, Loops = ns.get("f"), ns.get("pub"), ns.get("Loop"), ns.get("Loops")
-        pose_of = ns.get("get_pose_msg_from_homo_matrix")
-        res.id0 = _key(robotid_current) + idx_current + 1
-        res.id1 = _key(robotid_candidate) + idx_matched + 1
-        loop_transform = np.linalg.inv(loop_transform)
-        res.transform = loop_transform
-        if pose_of is not None:
-            pose = pose_of(loop_transform)
-            line = [robotid_current, idx_current, robotid_candidate, idx_matched, pose.position.x, pose.position.y, pose.position.z,
-                    pose.orientation.x, pose.orientation.y, pose.orientation.z, pose.orientation.w]
-            if f is not None:
-                f.write(' '.join(str(i) for i in line))
-                f.write("\n")
-            if Loop is not None and Loops is not None and pub is not None:
-                Loop_msgs = Loops()
-                Loop_msg = Loop()
-                Loop_msg.id0, Loop_msg.id1, Loop_msg.pose = res.id0, res.id1, pose
-                Loop_msgs.Loops.append(Loop_msg)
-                pub.publish(Loop_msgs)
-        out(tag + "Loop detected between id ", res.id0, " and id ", res.id1)
+    def rebind():
+        return types.FunctionType(fn.__code__, ov, fn.__name__, fn.__defaults__, fn.__closure__)
 
-    def finish(res, robotid_current, idx_current, pc_current, robotid_candidate, pc_matched, trans_x, trans_y, rot_yaw):
-        """main_RING.py:189-238 from the (x, y, yaw) estimate on"""
-        trans_x_bev, trans_y_bev = -trans_y, trans_x
-        trans_x_lidar, trans_y_lidar = -trans_x_bev, -trans_y_bev
-        init_pose = np.linalg.inv(_getSE3(trans_x_lidar, trans_y_lidar, rot_yaw))
-        res.init_pose = init_pose
-        out("Loop detected.")
-        out("Estimated translation: x: {}, y: {}, rotation: {}".format(trans_x_lidar, trans_y_lidar, rot_yaw))
-        times = time.time()
-        icp_fitness_score, loop_transform = _fast_gicp(pc_current, pc_matched, max_correspondence_distance=cfg.icp_max_distance, init_pose=init_pose)
-        timee = time.time()
-        res.fitness = icp_fitness_score
-        out("ICP fitness score:", icp_fitness_score)
-        out("ICP processed time:", timee - times, 's')
-        if icp_fitness_score < cfg.icp_fitness_score and robotid_current != robotid_candidate:
-            out("\033[32mICP fitness score is less than threshold, accept the loop.\033[0m")
-            res.accepted = True
-            publish(res, robotid_current, idx_current, robotid_candidate, res.idx_matched, loop_transform)
-        else:
-            out("\033[31mICP fitness score is larger than threshold, reject the loop.\033[0m")
-        return res
+    if kind in ("ring", "ringpp"):
+        name = "fast_corr" if kind == "ring" else "fast_corr_RINGplusplus"
+        own = ov[name] if name in overrides else None
 
-    def detect_ring(robotid_current, idx_current, pc_current, RING_current, TIRING_current,
-                    robotid_candidate, pc_candidates, RING_candidates, TIRING_candidates):
-        res = LoopResult()
-        db = twin_of(TIRING_candidates, "ring", device=dev_index)
-        assert len(db) >= len(pc_candidates)
-        RING_idxs, RING_dists, RING_angles = db.query(TIRING_current, cfg.dist_threshold)
-        keep = RING_idxs < len(pc_candidates)              # `for idx in range(len(pc_candidates))`
-        RING_idxs, RING_dists, RING_angles = RING_idxs[keep], RING_dists[keep], RING_angles[keep]
-        res.idxs, res.dists, res.angles = RING_idxs, RING_dists, RING_angles
-        if len(RING_dists) == 0:
-            out("No loop detected.")
-            return res
-        idx_top1 = np.argsort(RING_dists)[0]
-        dist = RING_dists[idx_top1]
-        out("Top {} RING distance: ".format(1), dist)
-        angle_matched = int(RING_angles[idx_top1])
-        angle_matched_extra = angle_matched - cfg.num_ring // 2
-        angle_matched_rad = angle_matched * 2 * np.pi / cfg.num_ring
-        angle_matched_extra_rad = angle_matched_extra * 2 * np.pi / cfg.num_ring
-        row_shift = calculate_row_shift(angle_matched, cfg.num_ring)
-        row_shift_extra = calculate_row_shift(angle_matched_extra, cfg.num_ring)
-        idx_matched = int(RING_idxs[idx_top1])
-        res.idx_matched, res.dist = idx_matched, dist
-        pc_matched = pc_candidates[idx_matched]
-        RING_matched = torch.as_tensor(RING_candidates[idx_matched])
-        RING_matched_shifted = torch.roll(RING_matched, row_shift, dims=1)
-        RING_matched_shifted_extra = torch.roll(RING_matched, row_shift_extra, dims=1)
-        x, y, error = ring.solve_translation(RING_current, RING_matched_shifted, angle_matched_rad, device)
-        x_extra, y_extra, error_extra = ring.solve_translation(RING_current, RING_matched_shifted_extra, angle_matched_extra_rad, device)
-        if error < error_extra:
-            trans_x, trans_y, rot_yaw = x / cfg.num_sector * 140., y / cfg.num_ring * 140., angle_matched_rad
-        else:
-            trans_x, trans_y, rot_yaw = x_extra / cfg.num_sector * 140., y_extra / cfg.num_ring * 140., angle_matched_extra_rad
-        return finish(res, robotid_current, idx_current, pc_current, robotid_candidate, pc_matched, trans_x, trans_y, rot_yaw)
+        def from_table(a, b):
+            t = tls.table
+            i = t[0]
+            t[0] = i + 1
+            if i < len(t[1]) and b is t[3][i] and a is t[4]:
+                return t[1][i], t[2][i]
+            return (own or fn.__globals__[name])(a, b)       # not the loop's pattern: the node's own function answers
+        ov[name] = from_table
+        node_fn = rebind()
 
-    def detect_ringpp(robotid_current, idx_current, pc_current, bev_current, TIRING_current,
-                      robotid_candidate, pc_candidates, bev_candidates, TIRING_candidates):
-        res = LoopResult()
-        channels = int(torch.as_tensor(TIRING_current).shape[0])
-        db = twin_of(TIRING_candidates, "ringpp", channels=channels, device=dev_index)
-        idxs, dists, angles = db.query(TIRING_current, cfg.dist_threshold)
-        keep = idxs < len(pc_candidates)
-        idxs, dists, angles = idxs[keep], dists[keep], angles[keep]
-        res.idxs, res.dists, res.angles = idxs, dists, angles
-        if len(dists) == 0:
-            out("No loop detected.")
-            return res
-        idx_top1 = np.argsort(dists)[0]
-        dist = dists[idx_top1]
-        out("Top {} TIRING distance: ".format(1), dist)
-        angle_matched = int(angles[idx_top1])
-        angle_matched_extra = angle_matched - cfg.num_ring // 2
-        angle_matched_rad = angle_matched * 2 * np.pi / cfg.num_ring
-        angle_matched_extra_rad = angle_matched_extra * 2 * np.pi / cfg.num_ring
-        idx_matched = int(idxs[idx_top1])
-        res.idx_matched, res.dist = idx_matched, dist
-        pc_matched = pc_candidates[idx_matched]
-        bev_matched = torch.as_tensor(bev_candidates[idx_matched]).to(device)
-        bev_cur = torch.as_tensor(bev_current).to(device)
-        bev_current_rotated = ring.rotate_bev(bev_cur, angle_matched_rad)
-        bev_current_rotated_extra = ring.rotate_bev(bev_cur, angle_matched_extra_rad)
-        x, y, error = ring.solve_translation_bev(bev_current_rotated, bev_matched)
-        x_extra, y_extra, error_extra = ring.solve_translation_bev(bev_current_rotated_extra, bev_matched)
-        if error < error_extra:
-            trans_x, trans_y, rot_yaw = x / cfg.num_sector * 140., y / cfg.num_ring * 140., angle_matched_rad
-        else:
-            trans_x, trans_y, rot_yaw = x_extra / cfg.num_sector * 140., y_extra / cfg.num_ring * 140., angle_matched_extra_rad
-        return finish(res, robotid_current, idx_current, pc_current, robotid_candidate, pc_matched, trans_x, trans_y, rot_yaw)
+        def detect_loop_icp(*args, **kwargs):
+            a = list(sig.bind(*args, **kwargs).arguments.values())      # (..., TIRING_current = a[4], ..., pc_candidates = a[6], ..., TIRING_candidates = a[8])
+            TIRING_current, pc_candidates, TIRING_candidates = a[4], a[6], a[8]
+            alld = alla = ()
+            if len(pc_candidates):
+                channels = int(torch.as_tensor(TIRING_current).shape[0]) if kind == "ringpp" else None
+                db = twin_of(TIRING_candidates, kind, channels=channels, device=dev_index)
+                _, _, _, alld, alla = db.query(TIRING_current, -1.0, want_all=True)       # every entry's score, one sweep
+                alla = alla.astype(np.int64)                # the reference's angle is an int64 (util.py:372)
+            tls.table = [0, alld, alla, TIRING_candidates, TIRING_current]
+            try:
+                return node_fn(*args, **kwargs)
+            finally:
+                tls.table = None
+        detect_loop_icp.__signature__ = sig
+        detect_loop_icp.__wrapped__ = fn
+        return detect_loop_icp
 
-    def detect_disco(robotid_current, idx_current, pc_current, DiSCO_current, fft_current,
-                     robotid_candidate, pc_candidates, DiSCO_candidates, FFT_candidates):
-        res = LoopResult()
-        if len(DiSCO_candidates) <= 1:
-            return res
-        db = _disco_twin(DiSCO_candidates, FFT_candidates, dev_index)
-        idx_top1_pc, d2, yaw_bin = db.query(np.asarray(DiSCO_current, np.float32).reshape(-1), torch.as_tensor(fft_current).reshape(40, 120))
-        num_sector = getattr(cfg, "num_sector", 120)
-        yaw_pc = (yaw_bin - num_sector // 2) / float(num_sector) * 360.
-        pred_angle_rad = yaw_pc * np.pi / 180.
-        init_pose_pc = _getSE3(0, 0, pred_angle_rad)
-        res.idx_matched, res.dist, res.init_pose = idx_top1_pc, d2, init_pose_pc
-        res.idxs, res.angles = np.array([idx_top1_pc]), np.array([yaw_bin])
-        pc_matched_pc = pc_candidates[idx_top1_pc]
-        fitness_pc, loop_transform = _fast_gicp(pc_current, pc_matched_pc, max_correspondence_distance=cfg.icp_max_distance, init_pose=init_pose_pc)
-        res.fitness = fitness_pc
-        out("fitness: ", fitness_pc)
-        if fitness_pc < cfg.icp_fitness_score and robotid_current != robotid_candidate:
-            out("ICP fitness score is less than threshold, accept the loop.")
-            res.accepted = True
-            publish(res, robotid_current, idx_current, robotid_candidate, idx_top1_pc, loop_transform, tag="DiSCO: ")
-        else:
-            out("DiSCO: ICP fitness score is larger than threshold, reject the loop.")
-        return res
+    assert kind == "disco", kind
 
-    return {"ring": detect_ring, "ringpp": detect_ringpp, "disco": detect_disco}[kind]
+    class _TwinTree:
+        """`KDTree(np.array(DiSCO_candidates)).query(DiSCO_current.reshape(1, -1), k=1)` (main.py:284-285) from the query made before the call"""
+
+        def __init__(self, data, *a, **k):
+            pass
+
+        def query(self, x, k=1, **kw):
+            idx, d2, _ = tls.q
+            return np.array([[np.sqrt(max(d2, 0.0))]]), np.array([[idx]])
+
+    def phase_from_query(FFT_candidate, fft_current, *a, **k):
+        return np.array(tls.q[2]), None                       # main.py:260-272 returns (angle % num_sector as a 0-d array, corr)
+    ov["KDTree"] = _TwinTree
+    ov["phase_corr"] = phase_from_query
+    node_fn = rebind()
+
+    def detect_loop_icp(*args, **kwargs):
+        a = list(sig.bind(*args, **kwargs).arguments.values())          # (..., DiSCO_current = a[3], fft_current = a[4], ..., DiSCO_candidates = a[7], FFT_candidates = a[8])
+        DiSCO_current, fft_current, DiSCO_candidates, FFT_candidates = a[3], a[4], a[7], a[8]
+        if len(DiSCO_candidates) > 1:
+            db = _disco_twin(DiSCO_candidates, FFT_candidates, dev_index)
+            num_sector = getattr(ov["cfg"], "num_sector", 120)
+            tls.q = db.query(np.asarray(DiSCO_current, np.float32).reshape(-1), torch.as_tensor(fft_current).reshape(40, 120), num_sector)
+        try:
+            return node_fn(*args, **kwargs)
+        finally:
+            tls.q = None
+    detect_loop_icp.__signature__ = sig
+    detect_loop_icp.__wrapped__ = fn
+    return detect_loop_icp

@@ -53,16 +53,19 @@ def test_helpers_equal_the_reference_util():
     with ref_import.reference_modules("oracle") as ref:
         u = ref.util
         for s in range(-60, 120):
-            assert node.calculate_row_shift(s) == u.calculate_row_shift(s)
+            assert mirror.calculate_row_shift(s) == u.calculate_row_shift(s)
         for x, y, yaw in ((0.0, 0.0, 0.0), (1.5, -2.25, 0.7), (-3.0, 4.0, -2.9)):
-            assert np.array_equal(node.getSE3(x, y, yaw), u.getSE3(x, y, yaw))
+            assert np.array_equal(mirror.getSE3(x, y, yaw), u.getSE3(x, y, yaw))
         rng = np.random.default_rng(0)
         pc = rng.uniform(-90, 90, (5000, 3))
         assert np.array_equal(mirror.load_pc_infer(pc), u.load_pc_infer(pc))
         assert mirror.robotid_to_key(2) == u.robotid_to_key(2)
 
 
-def test_bind_detect_loop_icp_signatures_match_the_reference():
+def test_bind_detect_loop_icp_runs_the_nodes_own_function_with_its_signature():
+    """bind_detect_loop_icp re-binds the NODE'S OWN detect_loop_icp (its code object, its live globals): same signature, names the node defines
+    after the binding line resolve, keyword overrides win, and a call that does not follow the loop's pattern falls back to the node's own
+    fast_corr.  (Empty candidate lists: no device work, so this runs without a GPU.)"""
     import inspect
     from mr_slam_amd import node
     want = {"ring": ["robotid_current", "idx_current", "pc_current", "RING_current", "TIRING_current", "robotid_candidate", "pc_candidates",
@@ -72,8 +75,17 @@ def test_bind_detect_loop_icp_signatures_match_the_reference():
             "disco": ["robotid_current", "idx_current", "pc_current", "DiSCO_current", "fft_current", "robotid_candidate", "pc_candidates",
                       "DiSCO_candidates", "FFT_candidates"]}
     for kind, names in want.items():
-        fn = node.bind_detect_loop_icp({}, kind)
-        assert list(inspect.signature(fn).parameters) == names
+        ns = {}
+        exec("def detect_loop_icp(" + ", ".join(names) + "):\n"
+             "    seen.append((len(pc_candidates), later, helper(3)))\n"
+             "    return 'node'\n", ns)
+        ns["seen"] = []
+        ns["helper"] = lambda x: x + 1
+        fn = node.bind_detect_loop_icp(ns, kind, helper=lambda x: x * 10)
+        assert list(inspect.signature(fn).parameters) == names and fn.__wrapped__ is ns["detect_loop_icp"]
+        ns["later"] = "defined after the binding line"          # like `f` / `pub` in the node's __main__ block
+        assert fn(0, 1, None, None, None, 2, [], [], []) == "node"
+        assert ns["seen"] == [(0, "defined after the binding line", 30)]
     if ref_import.available():
         for kind, rel in (("ring", os.path.join(ref_import.RING_ROS, "main_RING.py")), ("ringpp", os.path.join(ref_import.RING_ROS, "main_RINGplusplus.py")),
                           ("disco", os.path.join(ref_import.DISCO_ROS, "main.py"))):
