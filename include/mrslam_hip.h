@@ -548,6 +548,17 @@ int mrs_exchange_allgather(mrs_exchange* x, const void* d_local, int64_t n_local
  * packs what it was asked for, one grouped send / receive per peer pair moves exactly those rows.  entry_bytes % 16 == 0.  Collective; blocking. */
 int mrs_exchange_fetch_rows(mrs_exchange* x, const void* d_local_db, int64_t rows_per_rank, int64_t entry_bytes, const int64_t* d_global_rows,
                             int32_t n_rows, void* d_out, mrs_stream stream);
+/* The same with the request phase done ahead of time (candidate rows are known long before the entries are needed: they come out of a coarse
+ * search).  mrs_exchange_fetch_plan_create is a COLLECTIVE (every rank calls it, with its own d_global_rows [n_rows]; one all-gather of the
+ * requests + one host synchronisation); mrs_exchange_fetch_planned then only enqueues work on `stream` (gather -> one grouped send / receive
+ * per remote peer -> scatter to request order into d_out [n_rows][entry_bytes]): no host synchronisation, so it can be issued launches ahead
+ * on a communication stream.  Fetches of ONE plan share the plan's staging buffers and must follow each other in stream order. */
+typedef struct mrs_fetch_plan mrs_fetch_plan;
+int mrs_exchange_fetch_plan_create(mrs_exchange* x, int64_t rows_per_rank, const int64_t* d_global_rows, int32_t n_rows, mrs_stream stream,
+                                   mrs_fetch_plan** out);
+int mrs_exchange_fetch_planned(mrs_fetch_plan* plan, const void* d_local_db, int64_t entry_bytes, void* d_out, mrs_stream stream);
+int mrs_exchange_fetch_plan_counts(const mrs_fetch_plan* plan, int64_t* rows_sent_to_peers, int64_t* rows_received_from_peers);
+int mrs_exchange_fetch_plan_destroy(mrs_fetch_plan* plan);
 
 /* ------------------------------------------------------------------------------------
  * Loop database: the per-robot descriptor lists of the LoopDetection nodes, resident on the device

@@ -161,69 +161,164 @@ int mrs_exchange_allgather(mrs_exchange* x, const void* d_local, int64_t n_local
     return MRS_OK;
 }
 
-int mrs_exchange_fetch_rows(mrs_exchange* x, const void* d_local_db, int64_t rows_per_rank, int64_t entry_bytes, const int64_t* d_global_rows,
-                            int32_t n_rows, void* d_out, mrs_stream stream)
+// ---- row fetch with the request phase done ahead of time -----------------------------------------------------------------------------
+// Candidate rows are usually known long before the entries are needed (they come out of a coarse search; bench.py knows them before a step
+// starts), so the request exchange, its host synchronisation and the index tables are paid ONCE, in mrs_exchange_fetch_plan_create; a fetch
+// is then gather -> one grouped send / receive per remote peer -> scatter, all stream-ordered, no host synchronisation: it can be issued
+// launches ahead on a communication stream and waited for with an event.
+struct mrs_fetch_plan {
+    mrs_exchange* x = nullptr;
+    int n_rows = 0;
+    int64_t rows_per_rank = 0;
+    std::vector<int64_t> send_off, recv_off;      // [W + 1] prefix counts per peer
+    int64_t* d_sidx = nullptr;                     // local rows I send, grouped by peer, in the peer's request order
+    int64_t* d_rpos = nullptr;                     // position in the caller's output of every row I receive, grouped by owner
+    void* sendbuf = nullptr;
+    void* recvbuf = nullptr;
+    int64_t buf_entry_bytes = 0;                   // sendbuf / recvbuf are sized for entries of this many bytes
+};
+
+extern "C++" {
+namespace {
+void free_plan(mrs_fetch_plan* p)
 {
-    MRS_REQUIRE(x && d_local_db && d_global_rows && d_out, "null pointer");
+    if (!p) return;
+    if (p->d_sidx) (void)hipFree(p->d_sidx);
+    if (p->d_rpos) (void)hipFree(p->d_rpos);
+    if (p->sendbuf) (void)hipFree(p->sendbuf);
+    if (p->recvbuf) (void)hipFree(p->recvbuf);
+    delete p;
+}
+}  // namespace
+}
+
+int mrs_exchange_fetch_plan_create(mrs_exchange* x, int64_t rows_per_rank, const int64_t* d_global_rows, int32_t n_rows, mrs_stream stream,
+                                   mrs_fetch_plan** out)
+{
+    MRS_REQUIRE(x && d_global_rows && out, "null pointer");
+    *out = nullptr;
     MRS_REQUIRE(rows_per_rank > 0 && n_rows > 0, "sizes must be positive");
-    MRS_REQUIRE(entry_bytes > 0 && entry_bytes % 16 == 0, "entry_bytes must be a positive multiple of 16");
     MRS_HIP_TRY(hipSetDevice(x->ctx->device));
     hipStream_t s = (hipStream_t)stream;
     const int W = x->n_ranks, me = x->rank;
-    const int64_t units = entry_bytes / 16;
-    // 1. everybody's requests to everybody (n_rows int64 per rank: a few KB)
-    mrs::Scratch req_all;
-    int st = req_all.alloc((size_t)W * n_rows * sizeof(int64_t), s);
-    if (st != MRS_OK) return st;
-    MRS_NCCL_TRY(rccl().AllGather(d_global_rows, req_all.p, (size_t)n_rows * sizeof(int64_t), ncclChar, x->comm, s));
+    // everybody's requests to everybody (n_rows int64 per rank: a few KB)
     std::vector<int64_t> req((size_t)W * n_rows);
-    MRS_HIP_TRY(hipMemcpyAsync(req.data(), req_all.p, req.size() * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    MRS_HIP_TRY(hipStreamSynchronize(s));
+    {
+        mrs::Scratch req_all;
+        int st = req_all.alloc((size_t)W * n_rows * sizeof(int64_t), s);
+        if (st != MRS_OK) return st;
+        MRS_NCCL_TRY(rccl().AllGather(d_global_rows, req_all.p, (size_t)n_rows * sizeof(int64_t), ncclChar, x->comm, s));
+        MRS_HIP_TRY(hipMemcpyAsync(req.data(), req_all.p, req.size() * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        MRS_HIP_TRY(hipStreamSynchronize(s));
+    }
     for (int64_t r : req) MRS_REQUIRE(r >= 0 && r < rows_per_rank * W, "requested row outside the database");
-    // 2. what I send to every peer (local row indices, in the peer's request order) and where what I receive goes (positions in d_out)
+    mrs_fetch_plan* p = new mrs_fetch_plan();
+    p->x = x; p->n_rows = n_rows; p->rows_per_rank = rows_per_rank;
+    // what I send to every peer (local row indices, in the peer's request order) and where what I receive goes (positions in the output)
     std::vector<int64_t> send_idx, recv_pos;
-    std::vector<int64_t> send_off(W + 1, 0), recv_off(W + 1, 0);
-    for (int p = 0; p < W; ++p) {
+    p->send_off.assign(W + 1, 0); p->recv_off.assign(W + 1, 0);
+    for (int q = 0; q < W; ++q) {
         for (int k = 0; k < n_rows; ++k)
-            if (req[(size_t)p * n_rows + k] / rows_per_rank == me) send_idx.push_back(req[(size_t)p * n_rows + k] - (int64_t)me * rows_per_rank);
-        send_off[p + 1] = (int64_t)send_idx.size();
+            if (req[(size_t)q * n_rows + k] / rows_per_rank == me) send_idx.push_back(req[(size_t)q * n_rows + k] - (int64_t)me * rows_per_rank);
+        p->send_off[q + 1] = (int64_t)send_idx.size();
     }
     for (int o = 0; o < W; ++o) {
         for (int k = 0; k < n_rows; ++k)
             if (req[(size_t)me * n_rows + k] / rows_per_rank == o) recv_pos.push_back(k);
-        recv_off[o + 1] = (int64_t)recv_pos.size();
+        p->recv_off[o + 1] = (int64_t)recv_pos.size();
     }
-    mrs::Scratch d_sidx, d_rpos, sendbuf, recvbuf;
-    if ((st = d_sidx.alloc(std::max<size_t>(send_idx.size(), 1) * sizeof(int64_t), s)) != MRS_OK) return st;
-    if ((st = d_rpos.alloc(std::max<size_t>(recv_pos.size(), 1) * sizeof(int64_t), s)) != MRS_OK) return st;
-    if ((st = sendbuf.alloc(std::max<size_t>(send_idx.size(), 1) * entry_bytes, s)) != MRS_OK) return st;
-    if ((st = recvbuf.alloc((size_t)n_rows * entry_bytes, s)) != MRS_OK) return st;
-    if (!send_idx.empty()) MRS_HIP_TRY(hipMemcpyAsync(d_sidx.p, send_idx.data(), send_idx.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
-    MRS_HIP_TRY(hipMemcpyAsync(d_rpos.p, recv_pos.data(), recv_pos.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
-    if (!send_idx.empty())
-        hipLaunchKernelGGL(k_gather_rows16, dim3((unsigned)send_idx.size()), dim3(256), 0, s, static_cast<const uint4*>(d_local_db), d_sidx.as<int64_t>(), units,
-                           sendbuf.as<uint4>());
-    // 3. the rows travel: one send and one receive per remote peer, grouped; my own rows are a device copy
-    char* sb = sendbuf.as<char>();
-    char* rb = recvbuf.as<char>();
+    hipError_t e = hipMalloc(&p->d_sidx, std::max<size_t>(send_idx.size(), 1) * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc(&p->d_rpos, (size_t)n_rows * sizeof(int64_t));
+    if (e == hipSuccess && !send_idx.empty()) e = hipMemcpy(p->d_sidx, send_idx.data(), send_idx.size() * sizeof(int64_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p->d_rpos, recv_pos.data(), recv_pos.size() * sizeof(int64_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        free_plan(p);
+        mrs::set_error("fetch plan tables: %s", hipGetErrorString(e));
+        return MRS_ERR_HIP;
+    }
+    *out = p;
+    return MRS_OK;
+}
+
+int mrs_exchange_fetch_plan_destroy(mrs_fetch_plan* p)
+{
+    if (p) {
+        (void)hipSetDevice(p->x->ctx->device);
+        (void)hipDeviceSynchronize();              // a fetch of this plan may still be in flight on some stream
+    }
+    free_plan(p);
+    return MRS_OK;
+}
+
+int mrs_exchange_fetch_plan_counts(const mrs_fetch_plan* p, int64_t* rows_sent_to_peers, int64_t* rows_received_from_peers)
+{
+    MRS_REQUIRE(p, "null plan");
+    const int W = p->x->n_ranks, me = p->x->rank;
+    if (rows_sent_to_peers) *rows_sent_to_peers = p->send_off[W] - (p->send_off[me + 1] - p->send_off[me]);
+    if (rows_received_from_peers) *rows_received_from_peers = p->recv_off[W] - (p->recv_off[me + 1] - p->recv_off[me]);
+    return MRS_OK;
+}
+
+int mrs_exchange_fetch_planned(mrs_fetch_plan* p, const void* d_local_db, int64_t entry_bytes, void* d_out, mrs_stream stream)
+{
+    MRS_REQUIRE(p && d_local_db && d_out, "null pointer");
+    MRS_REQUIRE(entry_bytes > 0 && entry_bytes % 16 == 0, "entry_bytes must be a positive multiple of 16");
+    mrs_exchange* x = p->x;
+    MRS_HIP_TRY(hipSetDevice(x->ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int W = x->n_ranks, me = x->rank;
+    const int64_t units = entry_bytes / 16;
+    const int64_t n_send = p->send_off[W];
+    if (p->buf_entry_bytes < entry_bytes) {        // first use (or larger entries): the plan owns its staging buffers; fetches of ONE plan must
+        MRS_HIP_TRY(hipStreamSynchronize(s));      // follow each other in stream order (they share them)
+        if (p->sendbuf) (void)hipFree(p->sendbuf);
+        if (p->recvbuf) (void)hipFree(p->recvbuf);
+        p->sendbuf = p->recvbuf = nullptr;
+        p->buf_entry_bytes = 0;
+        MRS_HIP_TRY(hipMalloc(&p->sendbuf, (size_t)std::max<int64_t>(n_send, 1) * entry_bytes));
+        MRS_HIP_TRY(hipMalloc(&p->recvbuf, (size_t)p->n_rows * entry_bytes));
+        p->buf_entry_bytes = entry_bytes;
+    }
+    if (n_send > 0)
+        hipLaunchKernelGGL(k_gather_rows16, dim3((unsigned)n_send), dim3(256), 0, s, static_cast<const uint4*>(d_local_db), p->d_sidx, units,
+                           static_cast<uint4*>(p->sendbuf));
+    char* sb = static_cast<char*>(p->sendbuf);
+    char* rb = static_cast<char*>(p->recvbuf);
     if (W > 1) {
         MRS_NCCL_TRY(rccl().GroupStart());
-        for (int p = 0; p < W; ++p) {
-            if (p == me) continue;
-            const int64_t ns = send_off[p + 1] - send_off[p], nr = recv_off[p + 1] - recv_off[p];
-            if (ns > 0) MRS_NCCL_TRY(rccl().Send(sb + send_off[p] * entry_bytes, (size_t)(ns * entry_bytes), ncclChar, p, x->comm, s));
-            if (nr > 0) MRS_NCCL_TRY(rccl().Recv(rb + recv_off[p] * entry_bytes, (size_t)(nr * entry_bytes), ncclChar, p, x->comm, s));
+        ncclResult_t bad = ncclSuccess;
+        for (int q = 0; q < W && bad == ncclSuccess; ++q) {
+            if (q == me) continue;
+            const int64_t ns = p->send_off[q + 1] - p->send_off[q], nr = p->recv_off[q + 1] - p->recv_off[q];
+            if (ns > 0) bad = rccl().Send(sb + p->send_off[q] * entry_bytes, (size_t)(ns * entry_bytes), ncclChar, q, x->comm, s);
+            if (nr > 0 && bad == ncclSuccess) bad = rccl().Recv(rb + p->recv_off[q] * entry_bytes, (size_t)(nr * entry_bytes), ncclChar, q, x->comm, s);
         }
-        MRS_NCCL_TRY(rccl().GroupEnd());
+        const ncclResult_t end = rccl().GroupEnd();    // ALWAYS closed: a group left open would wedge every later collective of the communicator
+        if (bad != ncclSuccess || end != ncclSuccess) {
+            mrs::set_error("row fetch send / receive failed: %s", rccl().GetErrorString ? rccl().GetErrorString(bad != ncclSuccess ? bad : end) : "?");
+            return MRS_ERR_HIP;
+        }
     }
-    const int64_t mine = send_off[me + 1] - send_off[me];
+    const int64_t mine = p->send_off[me + 1] - p->send_off[me];
     if (mine > 0)
-        MRS_HIP_TRY(hipMemcpyAsync(rb + recv_off[me] * entry_bytes, sb + send_off[me] * entry_bytes, (size_t)(mine * entry_bytes), hipMemcpyDeviceToDevice, s));
-    // 4. back to request order
-    hipLaunchKernelGGL(k_scatter_rows16, dim3((unsigned)n_rows), dim3(256), 0, s, recvbuf.as<uint4>(), d_rpos.as<int64_t>(), units, static_cast<uint4*>(d_out));
+        MRS_HIP_TRY(hipMemcpyAsync(rb + p->recv_off[me] * entry_bytes, sb + p->send_off[me] * entry_bytes, (size_t)(mine * entry_bytes), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_scatter_rows16, dim3((unsigned)p->n_rows), dim3(256), 0, s, static_cast<const uint4*>(p->recvbuf), p->d_rpos, units, static_cast<uint4*>(d_out));
     MRS_HIP_TRY(hipGetLastError());
-    MRS_HIP_TRY(hipStreamSynchronize(s));      // the index tables are host temporaries; the scratch buffers return to the cache
     return MRS_OK;
+}
+
+int mrs_exchange_fetch_rows(mrs_exchange* x, const void* d_local_db, int64_t rows_per_rank, int64_t entry_bytes, const int64_t* d_global_rows,
+                            int32_t n_rows, void* d_out, mrs_stream stream)
+{
+    MRS_REQUIRE(x && d_local_db && d_global_rows && d_out, "null pointer");
+    MRS_REQUIRE(entry_bytes > 0 && entry_bytes % 16 == 0, "entry_bytes must be a positive multiple of 16");
+    mrs_fetch_plan* p = nullptr;
+    int st = mrs_exchange_fetch_plan_create(x, rows_per_rank, d_global_rows, n_rows, stream, &p);
+    if (st != MRS_OK) return st;
+    st = mrs_exchange_fetch_planned(p, d_local_db, entry_bytes, d_out, stream);
+    if (st == MRS_OK && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) { mrs::set_error("row fetch: stream synchronisation failed"); st = MRS_ERR_HIP; }
+    free_plan(p);
+    return st;
 }
 
 }  // extern "C"

@@ -72,7 +72,7 @@ def _rank(group=None):
     return dist.get_rank(group) if (dist.is_available() and dist.is_initialized()) else 0
 
 
-def sharded_topk_sweep(queries, local_db, sweep_fn, k, group=None, shard_rows=None, packed=False):
+def sharded_topk_sweep(queries, local_db, sweep_fn, k, group=None, shard_rows=None, packed=False, exchange=None):
     """The low-traffic alternative to replicating the database: the database stays sharded, the
     queries are the same on every rank (all-gather them first if they are not), every rank scores them against ITS rows
     and only the k best (dist, angle, global row) per query travel.  Rows are numbered in rank order (rank r owns
@@ -80,7 +80,8 @@ def sharded_topk_sweep(queries, local_db, sweep_fn, k, group=None, shard_rows=No
     on every rank; ties resolve to the smaller global row, like a single-rank sweep followed by a stable sort.
     shard_rows (rows per rank, the same list on every rank) skips the exchange of the shard sizes and its host
     synchronisation: every shape is then static and the call only enqueues work (timed loops).  packed=True sends the three
-    result arrays as ONE collective (an int64 view of (dist bits, angle) + the row)."""
+    result arrays as ONE collective (an int64 view of (dist bits, angle) + the row); exchange (an Exchange; needs packed and shard_rows): that
+    collective goes through the C ABI (mrs_exchange_allgather) on the current stream instead of torch.distributed."""
     world, rank = _world(group), _rank(group)
     Q = queries.shape[0]
     dev = queries.device
@@ -115,7 +116,10 @@ def sharded_topk_sweep(queries, local_db, sweep_fn, k, group=None, shard_rows=No
         b32[..., 1] = pd.contiguous().view(torch.int32)
         buf[..., 1] = pr
         gb = torch.empty((world * Q, k, 2), dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(gb, buf, group=group)
+        if exchange is not None:
+            exchange.allgather_into(gb, buf)
+        else:
+            dist.all_gather_into_tensor(gb, buf, group=group)
         gb = gb.view(world, Q, k, 2).permute(1, 0, 2, 3).reshape(Q, world * k, 2).contiguous()
         g32 = gb.view(torch.int32)                                           # [Q, world * k, 4]
         pa = g32[..., 0].contiguous()
@@ -365,6 +369,22 @@ class Exchange:
                                                       _lib.ptr(self._bytes(out)), _lib.current_stream(self.device)))
         return out
 
+    def allgather_into(self, out, local, stream=None):
+        """ONE ncclAllGather of `local` (contiguous, the same size on every rank) into `out` (world x local, rank order), enqueued on `stream`
+        (a torch stream; default: the current one): stream-ordered, nothing blocks the host"""
+        _lib = self._lib_mod
+        assert local.is_cuda and out.is_cuda and local.is_contiguous() and out.is_contiguous()
+        nbytes = local.numel() * local.element_size()
+        assert out.numel() * out.element_size() == self.world * nbytes
+        st = self._C.c_void_p(stream.cuda_stream) if stream is not None else _lib.current_stream(self.device)
+        _lib.check(_lib.load().mrs_exchange_allgather(self._h, self._C.c_void_p(local.data_ptr()), self._C.c_int64(1), self._C.c_int64(nbytes),
+                                                      self._C.c_void_p(out.data_ptr()), st))
+        return out
+
+    def fetch_plan(self, global_rows, rows_per_rank):
+        """-> PlannedFetch: the request phase of fetch_rows done now (collective: every rank calls it), fetches are then stream-ordered"""
+        return PlannedFetch(self, global_rows, rows_per_rank)
+
     def fetch_rows(self, local_db, global_rows):
         _lib = self._lib_mod
         db = local_db.contiguous()
@@ -375,3 +395,64 @@ class Exchange:
         _lib.check(_lib.load().mrs_exchange_fetch_rows(self._h, _lib.ptr(self._bytes(db)), self._C.c_int64(db.shape[0]), self._C.c_int64(entry),
                                                        _lib.ptr(rows), int(rows.numel()), _lib.ptr(self._bytes(out)), _lib.current_stream(self.device)))
         return out
+
+
+class PlannedFetch:
+    """RowFetchPlan's counterpart behind the C ABI (mrs_exchange_fetch_plan_*): the candidate rows a rank will ask for are registered once
+    (one all-gather of the requests, one host synchronisation), every fetch() afterwards is gather -> grouped RCCL send / receive -> scatter,
+    enqueued on a stream without touching the host.  Same interface as RowFetchPlan.fetch(async_op=True): (work, finish)."""
+
+    class _Work:
+        def __init__(self, event):
+            self.event = event
+
+        def wait(self):
+            torch.cuda.current_stream().wait_event(self.event)       # stream-side wait, like a torch.distributed Work on a CUDA stream
+
+    def __init__(self, exchange, global_rows, rows_per_rank):
+        import ctypes as C
+        self.x, self._C = exchange, C
+        _lib = exchange._lib_mod
+        rows = global_rows.to(torch.int64).reshape(-1).contiguous()
+        assert rows.is_cuda and rows.numel() > 0
+        self.n, self.rows_per_rank = int(rows.numel()), int(rows_per_rank)
+        self._h = C.c_void_p()
+        _lib.check(_lib.load().mrs_exchange_fetch_plan_create(exchange._h, C.c_int64(self.rows_per_rank), _lib.ptr(rows), self.n,
+                                                              _lib.current_stream(exchange.device), C.byref(self._h)))
+        sent, recv = C.c_int64(0), C.c_int64(0)
+        _lib.check(_lib.load().mrs_exchange_fetch_plan_counts(self._h, C.byref(sent), C.byref(recv)))
+        self.rows_from_peers, self.rows_to_peers = int(recv.value), int(sent.value)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self.x._lib_mod.load().mrs_exchange_fetch_plan_destroy(self._h)
+        except Exception:
+            pass
+
+    def bytes_in(self, row_bytes, rank_local_too=False):
+        return row_bytes * (self.n if rank_local_too else self.rows_from_peers)
+
+    def fetch(self, local_db, async_op=False, stream=None):
+        """rows in request order; async_op: (work, finish) -- the fetch runs on `stream` (a torch stream the caller keeps for communication;
+        it first waits for what the current stream has enqueued so far), work.wait() makes the then-current stream wait for it"""
+        _lib = self.x._lib_mod
+        db = local_db.contiguous()
+        assert db.is_cuda and db.shape[0] == self.rows_per_rank
+        real = torch.view_as_real(db) if db.is_complex() else db
+        entry = real[0].numel() * real.element_size()
+        out = torch.empty((self.n,) + tuple(db.shape[1:]), dtype=db.dtype, device=db.device)
+        oreal = torch.view_as_real(out) if out.is_complex() else out
+        cur = torch.cuda.current_stream()
+        st = stream if stream is not None else cur
+        if st is not cur:
+            ready = torch.cuda.Event(); ready.record(cur)
+            st.wait_event(ready)
+        _lib.check(_lib.load().mrs_exchange_fetch_planned(self._h, _lib.ptr(real), self._C.c_int64(entry), _lib.ptr(oreal), self._C.c_void_p(st.cuda_stream)))
+        if not async_op:
+            if st is not cur:
+                done = torch.cuda.Event(); done.record(st); cur.wait_event(done)
+            return out
+        done = torch.cuda.Event(); done.record(st)
+        self._keep = (db, out)
+        return PlannedFetch._Work(done), (lambda: out)

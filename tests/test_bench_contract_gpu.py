@@ -162,6 +162,24 @@ def test_bench_collective_path_on_one_gpu():
     assert x["rescore"]["calls"] == 4 and x["rescore"]["rounds"] >= 4 and x["designs"]["sharded_topk_ms"] > 0
 
 
+def test_bench_exchange_through_the_c_abi_on_one_gpu():
+    """--exchange-impl cabi: the step functions' data-path exchanges (descriptor all-gather, planned candidate-row fetch, per-launch query
+    gather, packed top-1 results) go through the product's own mrs_exchange_* (RCCL resolved at run time, the library's own communicator)
+    on a communication stream instead of torch.distributed; world size 1 here (one GPU), both designs, checked by --verify-exchange."""
+    for port, extra, design in ((29551, (), "fetch"), (29552, ("--exchange", "allgather"), "allgather"), (29553, ("--exchange", "allgather", "--replica", "f32"), "allgather")):
+        d = _run({"MRS_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)},
+                 ("--exchange-impl", "cabi", "--verify-exchange", "--no-extra-legs", "--no-cpu-baseline", "--gicp-pairs", "0", *extra))
+        x = d["exchange"]
+        assert x["impl"] == "cabi" and x["design"] == design and "mrs_exchange" in x["impl_note"] and d["config"]["exchange_impl"] == "cabi"
+        assert x["verify"]["ok"] and x["verify"]["checked"] == 32, x["verify"]
+        c = d["_compact"]
+        assert c["exchange"] == {"process_group": x["process_group"], "impl": "cabi", "verify_ok": True} and c["config"]["exchange_impl"] == "cabi"
+    # the same flags on torch.distributed give the same verified answers (and say so)
+    d = _run({"MRS_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29554"},
+             ("--verify-exchange", "--no-extra-legs", "--no-cpu-baseline", "--gicp-pairs", "0"))
+    assert d["exchange"]["impl"] == "torch" and d["exchange"]["verify"]["ok"] and d["_compact"]["exchange"]["impl"] == "torch"
+
+
 def _two_ranks(port, extra):
     env = dict(os.environ)
     env.update({"MRS_BENCH_BACKEND": "gloo", "MRS_BENCH_SHARE_GPU": "1"})

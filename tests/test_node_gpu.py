@@ -347,6 +347,23 @@ def test_exchange_through_the_c_abi_on_one_rank():
     assert torch.equal(torch.view_as_real(got), torch.view_as_real(spec[rows]))
     with pytest.raises(Exception):
         x.fetch_rows(spec, torch.tensor([48], device="cuda:0"))                # outside the database
+    # the planned form (round 6): the request phase once, every fetch stream-ordered on a communication stream; two fetches of one plan
+    # against different databases, back to back
+    plan = x.fetch_plan(rows, 48)
+    assert plan.n == 6 and plan.rows_from_peers == 0 and plan.bytes_in(58560) == 0
+    comm = torch.cuda.Stream()
+    spec2 = spec.flip(0).contiguous()
+    w1, f1 = plan.fetch(spec, async_op=True, stream=comm)
+    w1.wait(); out1 = f1().clone()
+    w2, f2 = plan.fetch(spec2, async_op=True, stream=comm)
+    w2.wait(); out2 = f2()
+    torch.cuda.synchronize()
+    assert torch.equal(torch.view_as_real(out1), torch.view_as_real(spec[rows])) and torch.equal(torch.view_as_real(out2), torch.view_as_real(spec2[rows]))
+    assert torch.equal(torch.view_as_real(plan.fetch(spec)), torch.view_as_real(spec[rows]))
+    buf = torch.empty((1, 48, 61, 120, 2), dtype=torch.float32, device="cuda:0")
+    x.allgather_into(buf, torch.view_as_real(spec).contiguous(), stream=comm)
+    torch.cuda.synchronize()
+    assert torch.equal(buf[0], torch.view_as_real(spec))
 
 
 def test_one_twin_queried_from_two_threads_while_a_third_appends():
