@@ -616,16 +616,24 @@ def node_shape_leg(device, spec_pool, n_db=10_000, n_loop=1000):
     TIRING = [host[i % n_pool] for i in range(n_db)]
     cur = host[3 % n_pool]
     out = {"db_entries": n_db}
-    # (i) the unchanged loop
-    t0 = time.perf_counter()
-    hits = 0
-    for idx in range(n_loop):
-        dist, angle = ring.fast_corr(cur, TIRING[idx])
-        if dist < 0.48:
-            hits += 1
-    t = time.perf_counter() - t0
-    out["reference_loop_through_dropin"] = {"pairs_per_s": n_loop / t, "ms_per_pair": 1e3 * t / n_loop, "entries_timed": n_loop,
-                                            "what": "for idx in range(len(candidates)): fast_corr(TIRING_current, TIRING_candidates[idx]) on host tensors"}
+    # (i) the unchanged loop.  Through the drop-in, fast_corr keeps a device twin of every HOST tensor it is handed (ring.DeviceMirror; generate_RING
+    # seeds it, so a node's own descriptors never upload): `first_visit` pays one 115 KB upload per tensor the mirror has not seen (descriptors
+    # that came from elsewhere), the steady state is what every later callback sees -- the node's lists persist and are swept at every callback
+    ring.device_mirror().clear()
+    rates = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        hits = 0
+        for idx in range(n_loop):
+            dist, angle = ring.fast_corr(cur, TIRING[idx])
+            if dist < 0.48:
+                hits += 1
+        rates.append(n_loop / (time.perf_counter() - t0))
+    out["reference_loop_through_dropin"] = {"pairs_per_s": max(rates[1:]), "ms_per_pair": 1e3 / max(rates[1:]), "entries_timed": n_loop,
+                                            "first_visit_pairs_per_s": rates[0], "distinct_host_tensors": min(n_pool, n_loop),
+                                            "what": "for idx in range(len(candidates)): fast_corr(TIRING_current, TIRING_candidates[idx]) on host tensors, "
+                                                    "unchanged; device twins of the host tensors (no upload after a tensor's first visit)"}
+    ring.device_mirror().clear()
     # (ii) the twin
     db = node.LoopDatabase("ring", capacity=1024)
     t0 = time.perf_counter()
@@ -733,6 +741,7 @@ def build_legs(device, chunks):
         v, c, f, kept = [float(np.mean([x[i] for x in tm])) for i in range(4)]
         res[batched] = {"scans_per_s": R / (v + c + f), "ms": {"voxel_down_sample_per_scan": 1e3 * v / R, "crop_scale_batch": 1e3 * c, "fused_descriptors": 1e3 * f},
                         "points_after_voxel_0.2": kept / R}
+    out["ingest_from_host"] = host_fed_leg(device, raws, raw_offs)
     out["ingest"] = {"scans_per_s": res[True]["scans_per_s"], "batch": R, "raw_points_per_scan": 130_000,
                      "points_after_voxel_0.2": res[True]["points_after_voxel_0.2"], "ms": res[True]["ms"],
                      "per_scan_calls": res[False],
@@ -741,6 +750,63 @@ def build_legs(device, chunks):
                              "synchronisation per scan, the ROS callback's shape) -> load_pc_infer -> BEV + Radon + normalise; reported next to "
                              "`value`, never instead of it"}
     return out
+
+
+def host_fed_leg(device, raws, raw_offs, n_batches=12):
+    """What the callbacks really hand over (main_RING.py:251-260): HOST arrays, float32 [n, 4] per scan.  Batches of R scans lie in PINNED host
+    memory; a copy stream brings batch b + 1 to one of two device buffers (hipMemcpyAsync) while the compute stream runs voxel_down_sample(0.2)
+    -> load_pc_infer -> fused BEV + Radon + normalise on batch b.  Reported next to a pure copy of the same batches on the same box: the wire is
+    the bound of a host-fed node, not HBM (every headline leg reads scans that are already resident)."""
+    from mr_slam_amd import preprocess
+    R = len(raws)
+    host = torch.cat(raws).cpu().pin_memory()                       # one batch worth of scans, [sum n, 4] float32, pinned
+    nbytes = host.numel() * 4
+    offs = raw_offs
+    dev = [torch.empty_like(host, device=device) for _ in range(2)]
+    copy = torch.cuda.Stream(device=device)
+    comp = torch.cuda.current_stream()
+
+    def run(process, nb):
+        ready = [torch.cuda.Event() for _ in range(2)]
+        freed = [torch.cuda.Event() for _ in range(2)]
+        for e in freed:
+            e.record(comp)
+        last = None
+
+        def issue(b):
+            with torch.cuda.stream(copy):
+                copy.wait_event(freed[b % 2])                       # the buffer's previous batch has been consumed
+                dev[b % 2].copy_(host, non_blocking=True)
+                ready[b % 2].record(copy)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        issue(0)
+        for b in range(nb):
+            if b + 1 < nb:
+                issue(b + 1)                                        # in flight while batch b is processed (the batched voxel grid synchronises the host once)
+            comp.wait_event(ready[b % 2])
+            if process:
+                cat, doffs = preprocess.voxel_down_sample_batch(dev[b % 2], offs, 0.2)
+                soa, so = preprocess.load_pc_infer_batch(cat, doffs.cpu().numpy())
+                last = ring.ring_descriptors_fused(soa, so, raw=False, normalized=True)
+            freed[b % 2].record(comp)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, last
+    run(True, 2)
+    t_copy, _ = run(False, n_batches)
+    t_all, last = run(True, n_batches)
+    # the last batch's descriptors against the same scans processed from a resident copy (bits)
+    cat, doffs = preprocess.voxel_down_sample_batch(torch.cat(raws), offs, 0.2)
+    soa, so = preprocess.load_pc_infer_batch(cat, doffs.cpu().numpy())
+    want = ring.ring_descriptors_fused(soa, so, raw=False, normalized=True)
+    same = bool(torch.equal(last[-1], want[-1]))
+    copy_gbs = n_batches * nbytes / t_copy / 1e9
+    return {"scans_per_s": n_batches * R / t_all, "batches": n_batches, "scans_per_batch": R, "bytes_per_scan": nbytes / R,
+            "host_to_device_gbs": n_batches * nbytes / t_all / 1e9, "pinned_copy_only_gbs": copy_gbs, "pinned_copy_only_scans_per_s": n_batches * R / t_copy,
+            "frac_of_pinned_copy": t_copy / t_all, "last_batch_bit_identical_to_resident_input": same,
+            "note": "pinned host float32 [n, 4] clouds (130 k points, 2.08 MB per scan) -> hipMemcpyAsync on a copy stream, double-buffered against "
+                    "voxel grid 0.2 m + load_pc_infer + fused BEV / Radon / normalise on the compute stream; frac_of_pinned_copy = copy-only time / "
+                    "pipeline time for the same batches"}
 
 
 def pipeline_shard_leg(device, spec_pool, gicp_res):

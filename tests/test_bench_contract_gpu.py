@@ -103,6 +103,9 @@ def test_bench_line_contract():
     assert set(r["fused_grid_ms_per_launch"]) == {"persistent", "per_pair"} and r["valu_roofline"] is None or r["valu_roofline"]["floor_ms_bounds"][0] > 0
     b3 = d["builds"]
     assert b3["disco_build"]["scans_per_s"] > 0 and b3["ringpp_build"]["scans_per_s"] > 0 and b3["ingest"]["scans_per_s"] > b3["ingest"]["per_scan_calls"]["scans_per_s"] * 0.5
+    hf = b3["ingest_from_host"]          # round 6: pinned host clouds -> copy stream -> voxel grid + crop + descriptors, double-buffered
+    assert hf["last_batch_bit_identical_to_resident_input"] is True and hf["scans_per_s"] > 0 and 0 < hf["frac_of_pinned_copy"] <= 1.05
+    assert hf["pinned_copy_only_gbs"] > 1.0 and cr["host_fed_scans_per_s"] > 0
     # --verify (default 8): outputs of the timed loop's last fused launch against the oracle, after the timed region
     v = d["verify"]
     assert v["ok"] and v["checked"] == 8 and v["bev_mismatches"] == 0 and v["sinogram_mismatches"] == 0 and v["angle_mismatches"] == 0, v
