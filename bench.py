@@ -1664,7 +1664,6 @@ def main():
                 # fixed-size rounds that only end when every rank reports none left); the rest differ from exact by < 2e-3 < margin
                 undecided = {"replica_margin": rescorer.margin, "threshold": rescorer.threshold, "requested": rescorer.stats["requested"],
                              "rounds": rescorer.stats["rounds"], "left_undecided": rescorer.stats["still_ambiguous"],
-                             "left_after_last_round_allreduce_max": rescorer.stats["left_after_last_round"],
                              "note": "measured on the last call: left_undecided = ambiguous entries of its output that were not replaced by an owner's exact "
                                      "score; the loop ends only when an all-reduce(MAX) of the per-rank remaining counts is 0"}
             line["exchange"] = {"design": EXCH, "impl": args.exchange_impl,

@@ -253,9 +253,9 @@ class OwnerRescorer:
 
     def __init__(self, threshold, margin=2e-3, slots=64, group=None):
         self.threshold, self.margin, self.slots, self.group = float(threshold), float(margin), int(slots), group
-        # left_after_last_round: the all-reduced (MAX over ranks) count of ambiguous candidates still waiting when the last call's loop ended;
-        # still_ambiguous: entries of the last call's OUTPUT whose replica score was ambiguous and that were NOT replaced by an exact one (measured)
-        self.stats = {"calls": 0, "requested": 0, "rounds": 0, "flipped": 0, "left_after_last_round": None, "still_ambiguous": None}
+        # still_ambiguous: entries of the last call's OUTPUT whose replica score was ambiguous and that were NOT replaced by an exact one (measured;
+        # the loop below only ends when an all-reduce(MAX) of the per-rank remaining counts is 0)
+        self.stats = {"calls": 0, "requested": 0, "rounds": 0, "flipped": 0, "still_ambiguous": None}
 
     def ambiguous(self, dist_replica):
         return torch.nonzero((dist_replica - self.threshold).abs() < self.margin).reshape(-1)
@@ -316,7 +316,6 @@ class OwnerRescorer:
                 replaced[take] = True
             self.stats["rounds"] = self.stats.get("rounds", 0) + 1
             if int(left.item()) == 0:
-                self.stats["left_after_last_round"] = int(left.item())
                 break
         self.stats["still_ambiguous"] = int((~replaced[all_amb]).sum()) if all_amb.numel() else 0
         return out_d, out_a

@@ -36,7 +36,7 @@ def valu_cycles(mean):
     return sum(mean[k] * c for k, c in CLASS_CYCLES.items()) + max(mean["SQ_INSTS_VALU"] - known, 0.0) * REST_CYCLES
 
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
 KEYS = {"k_cart_lds": "k_cart_lds", "k_polar_lds": "k_polar_lds", "k_radon2": "k_radon2", "k_bev_radon2": "k_bev_radon2", "k_bev_radon3": "k_bev_radon3",
@@ -57,7 +57,8 @@ for f in files:
             t = re.search(r"k_ring_sweep_dma<([^>]*)>", r["Kernel_Name"])
             a = [x.strip() for x in t.group(1).split(",")] if t else []
             if len(a) >= 8:
-                k += "<%s%s>" % ("tiled" if a[5] in ("true", "1") else "rows", ", 6 channels" if a[7] in ("true", "1") else "")
+                k += "<%s%s, %s waves%s>" % ("tiled" if a[5] in ("true", "1") else "rows", ", 6 channels" if a[7] in ("true", "1") else "", a[0],
+                                             "" if a[2] != "0" else ", several queries")      # NT = 0 (default cache policy) is the several-queries form
         if k == "k_knn_cov":                       # k = 15 covariances (16 slots) and the k = 30 point-feature selection (32 slots) are different kernels
             t = re.search(r"k_knn_cov<\s*(\d+)", r["Kernel_Name"])
             if t:

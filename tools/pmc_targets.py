@@ -29,12 +29,14 @@ for _ in range(3):      # the single-launch form of the three kernels above (k_b
 del gout
 spec = ring.half_spectrum(norm)
 db = spec[torch.arange(10000, device=dev) % B].contiguous()
-for nq in (1, 4):                   # 1 query: the LDS-DMA kernel on row-layout entries (k_ring_sweep_dma<..., TILED = false>); 4: k_ring_corr_fft
+for nq in (1, 4):                   # the LDS-DMA kernel on row-layout entries (k_ring_sweep_dma<..., TILED = false>): 1 query, and 4 (round 6)
     for _ in range(3):
         ring.corr_sweep_fft(spec[:nq].contiguous(), db)
 tiled = ring.spec_to_tiled(db)      # the database's resident format (mrs_loopdb): k_ring_sweep_dma<..., TILED = true>
 for _ in range(3):
     ring.corr_sweep_fft_tiled(spec[:1].contiguous(), tiled)
+for _ in range(3):                  # round 6: four queries per sweep on the same pipeline (12 waves, default cache policy: its own instantiation)
+    ring.corr_sweep_fft_tiled_q(spec[:4].contiguous(), tiled)
 del tiled
 db6 = torch.stack([db[:2000].roll(k, 0) for k in range(6)], 1).contiguous()      # RING++: 2 000 entries x 6 channels, tiled: k_ring_sweep_dma<MC> + k_ring_mc_finish
 tiled6 = ring.spec_to_tiled(db6)

@@ -14,13 +14,15 @@ from mr_slam_amd.compat import pygicp  # noqa: E402
 
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    reuse = len(sys.argv) > 2 and sys.argv[2] == "reuse"           # one registration object fed new clouds (the Mapping node's shape) instead of a new one each time
     srcs, tgts = bench._gicp_pairs(1, 0)
     s, t = pygicp.downsample(srcs[0].astype(np.float64), 0.2), pygicp.downsample(tgts[0].astype(np.float64), 0.2)
     tm = {k: [] for k in ("ctor", "set_target", "set_source", "align", "fitness", "total")}
     T = None
     for r in range(reps + 3):
         t0 = time.perf_counter()
-        g = pygicp.FastGICP()
+        if not reuse or r == 0:
+            g = pygicp.FastGICP()
         t1 = time.perf_counter()
         g.set_input_target(t)
         t2 = time.perf_counter()

@@ -4,13 +4,13 @@
 # Every step runs under its own `timeout`: one --pmc pass of round 3 hung for 37 minutes (profiler, not the kernels: the same pass took 8 s before).
 # PMC passes carry no tracing flags (gpurun refuses --pmc together with trace domains).  The raw counter CSVs of a pass hold every torch
 # kernel of the scan synthesis and exceed what gpurun copies back: only the rows of this library's kernels are kept (pmc_<group>.csv).
-TAG=${1:-r04}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 if [ -z "$PMC_ONLY" ]; then
-(cd $R && timeout 400 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err)
+(cd $R && timeout 400 python bench.py --detail-file $OUT/bench_detail.json > $OUT/bench_default.json 2> $OUT/bench_default.err)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs --verify 0 > $OUT/stats.log 2>&1
 for f in $(find $OUT/stats -name '*kernel_stats.csv'); do cp $f $OUT/kernel_stats.csv; done; rm -rf $OUT/stats
 fi
