@@ -25,6 +25,7 @@ import json
 import os
 import sys
 import time
+import types
 
 import numpy as np
 import torch
@@ -1032,6 +1033,308 @@ def self_launch(n):
     return subprocess.call(cmd)
 
 
+def after_timed_region(S):
+    """Everything between the clock stopping and the result line, on every rank: per-launch kernel times from the recorded events, the GICP leg,
+    the exchange check (--verify-exchange), the two database designs side by side (N > 1), the side stream's own time.  S: main()'s locals."""
+    # per launch of B scans; entries that cover several launches (descriptor kernel, grouped correlation, a group's sweeps) carry their count.
+    # With --sweep-stream side the sweep figure is stream time on the side stream (it includes waiting for compute units the other stream holds)
+    kern_ms = {k: float(sum(t[0].elapsed_time(t[1]) for t in v) / sum((t[2] if len(t) > 2 else 1) for t in v)) for k, v in S.ev.items() if v}
+
+    extra = {}
+    gicp_res = None
+    if S.args.gicp_pairs > 0:
+        S.fence()
+        gicp_res = gicp_leg(S.local_rank, S.rank, S.args.gicp_pairs, S.args.gicp_iters)
+        if S.dist_on:   # whole-job GICP rate: all ranks' iterations / slowest rank's time
+            t = torch.tensor([gicp_res["align_s"]], dtype=torch.float64, device=S.device)    # the cold-start forced protocol
+            S.dist.all_reduce(t, op=S.dist.ReduceOp.MAX)
+            gicp_res["iters_per_s"] = S.world * S.args.gicp_pairs * S.args.gicp_iters / float(t.item())
+            gicp_res["pairs"] = S.world * S.args.gicp_pairs
+
+    verify = None
+    if S.dist_on and S.args.verify_exchange:
+        # the last launch scored its new descriptors against what the exchange delivered (fp16 replicas / fetched fp32 rows) of the
+        # descriptors every rank built DEPTH launches earlier: gather those exact fp32 entries and score the same pairs against them
+        S.fence()
+        c = S.CH - 1
+        exact_db = shard.allgather_ragged(torch.view_as_real(S.spec32[S.db_slot(c)]).contiguous())
+        exact_db = torch.view_as_complex(exact_db.contiguous())
+        d_ex, a_ex = ring.corr_pairs_fft(S.spec32[c].contiguous(), exact_db[S.cand_idx[c].long()].contiguous())
+        err = (d_ex - S.out_dist[c]).abs()
+        verify = {"checked": int(err.numel()), "max_abs_dist_error": float(err.max()),
+                  "angle_mismatches": int((a_ex != S.out_ang[c]).sum()), "remote_candidates": int((S.cand_idx[c] // S.B != S.rank).sum())}
+        if S.EXCH == "fetch":
+            # the fetched rows are the owners' entries bit for bit, and the sharded top-1 sweep equals a sweep over the gathered database
+            verify["fetched_rows_bit_identical"] = bool(torch.equal(torch.view_as_real(S.last_fetched[0]),
+                                                                    torch.view_as_real(exact_db[S.cand_idx[c].long()])))
+            d_full, _ = ring.corr_sweep_fft(S.spec32[c, :1].contiguous(), exact_db)
+            v_full, r_full = torch.min(d_full, 1)
+            verify["sweep_value_equal"] = bool(float(v_full[0]) == float(S.sweep_val[c]))
+            verify["sweep_row_equal"] = bool(int(r_full[0]) == int(S.sweep_row[c]))
+        tol = 2e-3 if (S.EXCH == "allgather" and not S.REP32) else 1e-6          # fp16 replicas differ from the exact entries by < 2e-3 (re-scored near the threshold)
+        verify["ok"] = bool(verify["max_abs_dist_error"] < tol and (S.EXCH == "allgather" and not S.REP32 or verify["angle_mismatches"] == 0) and
+                            all(verify.get(k, True) for k in ("fetched_rows_bit_identical", "sweep_value_equal", "sweep_row_equal")))
+
+    topk_cmp = None
+    if S.dist_on:
+        # the two database designs of SURVEY.md 8(e) side by side: (a) replicate (all-gather the descriptors, every rank sweeps
+        # everything: what the step does) vs (b) keep the database sharded, all-gather the QUERIES, exchange top-k rows only
+        q_local = S.spec32[0, :4].contiguous()
+        S.fence()
+
+        def design_a():
+            full = shard.allgather_ragged(torch.view_as_real(S.spec32[0]).to(torch.float16))
+            d, a = ring.corr_sweep_fft(q_local, full)
+            return torch.topk(d, 4, dim=1, largest=False)
+
+        def design_b():
+            q_all = shard.allgather_ragged(torch.view_as_real(q_local).contiguous())
+            return shard.sharded_topk_sweep(torch.view_as_complex(q_all), S.spec32[0], ring.corr_sweep_fft, 4)
+        ms_a, ms_b = ev_ms(design_a, reps=3, warm=1), ev_ms(design_b, reps=3, warm=1)
+        topk_cmp = {"replicate_db_ms": ms_a, "sharded_topk_ms": ms_b, "queries_per_rank": 4, "db_rows_per_rank": S.B,
+                    "replicate_bytes_in_per_rank": (S.world - 1) * S.B * 29280, "sharded_bytes_in_per_rank": (S.world - 1) * 4 * (58560 + 4 * 16)}
+
+    side_stream = None
+    if S.SIDE_SWEEP and "sweep" in kern_ms:
+        # on the side stream the interval between a batch's events is STREAM time: it contains the wait for compute units the descriptor
+        # kernel holds, so it is not a kernel duration and must not be added to the others.  The sweep's own duration is measured stand-alone
+        # right here (same entries), the stream time is reported apart
+        S.fence()
+        side_stream = {"sweeps_stream_time_ms_per_launch": kern_ms.pop("sweep"),
+                       "note": "time between the events around a batch of sweeps on the side stream / launches in the batch: includes waiting for "
+                               "compute units held by the descriptor kernel on the compute stream; kernel_ms.sweep_standalone is the sweep's own duration"}
+        kern_ms["sweep_standalone"] = ev_ms(lambda: torch.min(ring.corr_sweep_fft(S.spec32[S.wslot(0), :1], S.spec32[S.db_slot(0)])[0], 1))
+
+    return {"gicp_res": gicp_res, "kern_ms": kern_ms, "side_stream": side_stream, "topk_cmp": topk_cmp, "verify": verify}
+
+
+def result_line(S):
+    """Rank 0: the full result (every block; emit() writes it to the detail file and prints the compact contract line).  S: main()'s locals + what
+    after_timed_region returned."""
+    pmc = load_pmc()
+    cells = 120 * 120
+    bev_bytes = S.B * (12 * N_POINTS + 4 * cells)          # SURVEY 8(d): 12 B/point + 4 B/cell
+    if S.FUSE:
+        # the rasteriser no longer runs on its own in the timed region: its stand-alone roofline is measured right here (same
+        # scans, same box), the timed region's dominant kernel is the fused one (12 B/point in, one normalised sinogram out)
+        xyz0, offs0 = S.chunks[0]
+        S.kern_ms["bev_standalone"] = ev_ms(lambda: bev.cart_bev(xyz0, offs0, 1, 1, 120, 120, 1, out=S.img.view(S.B, -1)))
+        S.kern_ms["radon_standalone"] = ev_ms(lambda: S.plan.forward(S.img.view(S.B, 120, 120), raw=False, normalized=True))
+        fused_bytes = S.B * (12 * N_POINTS + 4 * cells)
+        achieved = fused_bytes / (S.kern_ms["bev_radon"] * 1e-3) / 1e9
+    else:
+        achieved = bev_bytes / (S.kern_ms["bev"] * 1e-3) / 1e9
+    line = {
+        "metric": "loop-candidate pairs/sec (BEV+Radon+corr), 120k-pt scans",
+        "value": S.world * S.B * S.CH * S.args.steps / S.elapsed,
+        "unit": "pairs/s",
+        "n_gpus": S.world,
+        "steps": S.args.steps,
+        "warmup": S.args.warmup,
+        "ms_per_step": 1e3 * S.elapsed / S.args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1] batched: 120k-pt synthetic lidar scans -> Cartesian BEV 120x120x1 -> Radon "
+                               "120x120 -> normalise -> half spectrum -> FFT-domain rotation correlation vs 1 candidate of the "
+                               "database (+ 1 query per launch swept over the database)",
+                   "pairs_per_rank_per_step": S.B * S.CH, "pairs_per_launch": S.B, "launches_per_step": S.CH,
+                   "database_rows_swept_per_launch": S.NDB,      # grows with the world size: the replicated database is world x B rows
+                   "resident_scan_bytes_per_rank": S.B * S.CH * 12 * N_POINTS, "points_per_scan": N_POINTS,
+                   "parallelism": f"scan-sharded x{S.world}" + ("" if not S.dist_on else
+                                                              " + RCCL all-gather of fp16 descriptor replicas, candidates and sweeps read the "
+                                                              "replicated database, owner re-scoring" if S.EXCH == "allgather" else
+                                                              " + database kept sharded: RCCL all-to-all of the candidate rows asked for (exact "
+                                                              "fp32, pre-planned), per-launch query all-gathered for a sharded top-1 sweep"),
+                   "exchange": S.EXCH, "exchange_impl": (S.args.exchange_impl if S.dist_on else None), "fused_grid": S.fused_grid if S.FUSE else None},
+        "timed_region_s": S.elapsed,
+        "setup_s": S.setup_s,
+        "kernel_ms": S.kern_ms,
+        "side_stream": S.side_stream,
+        "roofline": {"kernel": "k_cart_lds (BEV scatter)", "bound": "hbm", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": pmc.get("k_cart_lds", {}).get("hbm_bytes"), "algorithmic_bytes_per_launch": bev_bytes,
+                     "traffic_source": PMC_NAME + " (rocprofv3 --pmc passes of tools/pmc_targets.py)" if pmc.get("k_cart_lds") else None},
+        "gicp": S.gicp_res,
+    }
+    if S.FUSE:
+        # one kernel with an HBM-bound half (rasteriser) and a VALU-bound half (Radon march) per workgroup, overlapped across
+        # compute units: its time is bounded below by max(HBM time of the points, VALU time of the rays), not by either alone
+        r = pmc.get("k_bev_radon3") or pmc.get("k_bev_radon2", {})
+        if r.get("hbm_bytes"):        # the PMC pass profiles the kernel at 16 x 1024 scans per launch: per 1024 scans like everything else here
+            per = (r.get("launch_scans") or 1024) / 1024.0
+            r = dict(r, hbm_bytes=r["hbm_bytes"] / per, valu_pipe_cycles_est=(r.get("valu_pipe_cycles_est") or 0) / per or None,
+                     counters={k: v / per for k, v in (r.get("counters") or {}).items()})
+        sa = bev_bytes / (S.kern_ms["bev_standalone"] * 1e-3) / 1e9
+        line["config"]["fused_launches"] = S.FUSE
+        line["config"]["corr_launches_grouped"] = S.FUSE if S.GROUP_CORR else 1
+        line["config"]["sweep_stream"] = "side" if (S.SIDE_SWEEP or S.EXCH == "fetch") else "main"
+        line["config"]["sweeps_per_launch"] = S.FUSE if S.SWEEP_BATCH else 1
+        if S.SIDE_SWEEP:
+            line["config"]["sweep_join"] = S.args.sweep_join
+        if S.args.fused_wgs > 0:
+            line["config"]["fused_persistent_workgroups"] = S.args.fused_wgs
+        line["config"]["database_slots"] = "two sets, alternating per step" if S.RING_DB else "one set + copies of the previous step's last entries"
+        line["roofline"] = {"kernel": f"k_bev_radon3 (BEV scatter + Radon + normalise, {S.FUSE} x {S.B} scans per launch)", "bound": "hbm",
+                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                            "traffic": r.get("hbm_bytes"), "algorithmic_bytes_per_launch": bev_bytes,
+                            "traffic_source": PMC_NAME if r else None,
+                            "valu_issue_frac": r.get("valu_issue_frac"), "lds_busy_frac": r.get("lds_busy_frac"),
+                            "valu_roofline": valu_roofline(r, S.kern_ms["bev_radon"]),
+                            "note": "per 1024 scans; the kernel also carries the VALU-bound Radon march (1.47 M two-tap samples per image), "
+                                    "so the HBM fraction of the fused kernel is below the stand-alone rasteriser's by construction",
+                            "ms_vs_separate_kernels": {"fused": S.kern_ms["bev_radon"], "bev_standalone": S.kern_ms["bev_standalone"],
+                                                       "radon_standalone": S.kern_ms["radon_standalone"]}}
+        line["roofline_bev_scatter"] = {"kernel": "k_cart_lds (BEV scatter, stand-alone launch outside the timed region)", "bound": "hbm",
+                                        "achieved": sa, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sa / HBM_PEAK_GBS,
+                                        "ms": S.kern_ms["bev_standalone"], "traffic": pmc.get("k_cart_lds", {}).get("hbm_bytes"),
+                                        "algorithmic_bytes_per_launch": bev_bytes}
+    if S.gicp_res:
+        # north_star's own targets as flat scalars of `roofline` (the driver's record keeps scalars of this block)
+        gr = S.gicp_res["roofline"]
+        line["roofline"].update({
+            "gicp_iters_per_s": S.gicp_res["iters_per_s"], "gicp_iters_per_s_warm": S.gicp_res["warm"]["iters_per_s"],
+            "gicp_iters_per_s_cold5": S.gicp_res["cold"]["iters_per_s"],
+            "gicp_natural_pairs_per_s": S.gicp_res["natural"]["pairs_per_s"], "gicp_pairs_per_s_incl_covariances": S.gicp_res["pairs_per_s_incl_covariances"],
+            "gicp_pairs_per_s_incl_covariances_shared_submaps": S.gicp_res["shared_submaps"]["pairs_per_s_incl_covariances"],
+            "gicp_searched_fraction_natural": S.gicp_res["natural"]["searched_fraction"],
+            "gicp_linearize_ms": gr["k_linearize"]["ms"], "gicp_linearize_gbs": gr["k_linearize"]["achieved"], "gicp_linearize_frac": gr["k_linearize"]["frac"],
+            "gicp_linearize_error_only_frac": gr["k_linearize_error_only"]["frac"],
+            "gicp_nn_round3_all_ms": S.gicp_res["kernel_ms"]["search_round3_all"], "gicp_nn_round4_all_ms": S.gicp_res["kernel_ms"]["search_round4_all"],
+            "gicp_nn_certify_ms": S.gicp_res["kernel_ms"]["certify"], "gicp_nn_certify_frac": gr["k_nn_certify (unchanged pose)"]["frac"],
+            "gicp_nn_certified_pass_1mm_ms": S.gicp_res["kernel_ms"]["certify_plus_worklist_1mm"],
+            "gicp_knn_select_ms": S.gicp_res["kernel_ms"]["knn_select"], "gicp_cov_from_knn_ms": S.gicp_res["kernel_ms"]["cov_from_knn"],
+            "gicp_pairs": S.gicp_res["pairs"]})
+        line["roofline"]["gicp"] = gr
+    if S.FUSE:
+        line["roofline"]["bev_scatter_frac"] = line["roofline_bev_scatter"]["frac"]
+        line["roofline"]["bev_scatter_gbs"] = line["roofline_bev_scatter"]["achieved"]
+    if S.dist_on:
+        # bytes a rank receives per launch under either design, and the inbound rate each would need at the measured step time
+        ag_launch = (S.world - 1) * S.B * (58560 if S.REP32 else 29280)
+        if S.EXCH == "fetch":
+            fetch_launch = float(np.mean([pl.bytes_in(58560) for pl in S.fetch_plans]))
+        else:
+            fetch_launch = (S.world - 1) / S.world * S.B * 58560                    # expected for uniformly drawn candidates
+        sweep_launch = (S.world - 1) * (58560 + S.world * 16)                     # the other ranks' queries + their packed top-1 answers
+        step_s = 1e-3 * line["ms_per_step"]
+        undecided = None
+        if S.rescorer is not None:
+            # proof that no loop decision rests on a replica score: after re-scoring, every (query, candidate) whose REPLICA distance was
+            # within the margin of the acceptance threshold carries the owner's exact value (rescore.requested of them, in rescore.rounds
+            # fixed-size rounds that only end when every rank reports none left); the rest differ from exact by < 2e-3 < margin
+            undecided = {"replica_margin": S.rescorer.margin, "threshold": S.rescorer.threshold, "requested": S.rescorer.stats["requested"],
+                         "rounds": S.rescorer.stats["rounds"], "left_undecided": S.rescorer.stats["still_ambiguous"],
+                         "note": "measured on the last call: left_undecided = ambiguous entries of its output that were not replaced by an owner's exact "
+                                 "score; the loop ends only when an all-reduce(MAX) of the per-rank remaining counts is 0"}
+        line["exchange"] = {"design": S.EXCH, "impl": S.args.exchange_impl,
+                            "impl_note": ("data-path collectives through the C ABI (mrs_exchange_allgather / mrs_exchange_fetch_planned, the library's own RCCL "
+                                          "communicator of %d ranks) on a communication stream" % S.xch.world) if S.CABI else "torch.distributed collectives",
+                            "process_group": {"backend": S.dist.get_backend(), "world_size": S.dist.get_world_size(), "gpus_flag": S.args.gpus,
+                                              "devices_visible": torch.cuda.device_count()},
+                            "replica": (S.args.replica if S.EXCH == "allgather" else None),
+                            "decisions_on_replica_scores": (None if S.EXCH != "allgather" or S.rescorer is None else S.rescorer.stats["still_ambiguous"]),
+                            "rescore_proof": undecided,
+                            "allgather": {"format": ("exact fp32 half spectra, 58 560 B per descriptor" if S.REP32 else
+                                                     "fp16 half spectra, 29 280 B per descriptor") + ", every descriptor to every rank",
+                                          "bytes_in_per_rank_per_launch": ag_launch,
+                                          "inbound_gbs_needed_at_this_rate": (ag_launch * S.CH / step_s / 1e9) if S.world > 1 else None},
+                            "fetch": {"format": "exact fp32 half spectra, 58 560 B per candidate row actually asked for (pre-planned all-to-all) + one "
+                                                "query per rank and launch all-gathered for the sharded top-1 sweep",
+                                      "bytes_in_per_rank_per_launch": fetch_launch + sweep_launch,
+                                      "rows_bytes_in_per_rank_per_launch": fetch_launch, "sweep_bytes_in_per_rank_per_launch": sweep_launch,
+                                      "inbound_gbs_needed_at_this_rate": ((fetch_launch + sweep_launch) * S.CH / step_s / 1e9) if S.world > 1 else None,
+                                      "launches_ahead": S.FETCH_AHEAD if S.EXCH == "fetch" else None},
+                            "compute_stream_wait_ms_per_launch": S.kern_ms.get("wait"),
+                            "compute_stream_wait_ms_per_step": S.kern_ms.get("wait", 0.0) * S.CH,
+                            "rescore": S.rescorer.stats if S.rescorer else None, "designs": S.topk_cmp, "verify": S.verify}
+    if not S.args.no_extra_legs:
+        # polar BEV (the rasteriser north_star names), DiSCO layout 40 x 120 x 20, same scans
+        xyz0, offs0 = S.chunks[0]
+        pcells = 40 * 120 * 20
+        ms = ev_ms(lambda: bev.polar_bev(xyz0, offs0, 1, 1, 40, 120, 20))
+        pbytes = S.B * (12 * N_POINTS + 4 * pcells)
+        line["roofline_polar"] = {"kernel": "k_polar_lds (polar BEV scatter, 40x120x20)", "bound": "hbm", "achieved": pbytes / ms / 1e6,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": pbytes / ms / 1e6 / HBM_PEAK_GBS, "ms": ms,
+                                  "traffic": pmc.get("k_polar_lds", {}).get("hbm_bytes"), "algorithmic_bytes_per_launch": pbytes}
+        samples = 1.47e6 * S.B                       # two-tap samples per launch (120 angles x 120 rays x ~102 steps)
+        radon_ms = S.kern_ms.get("radon", S.kern_ms.get("radon_standalone"))
+        r = pmc.get("k_radon2", {})
+        line["roofline_radon"] = {"kernel": "k_radon2 (two images per workgroup)", "bound": "valu+lds (not HBM: 115 KB per image)",
+                                  "ms": radon_ms, "samples_per_s": samples / (radon_ms * 1e-3),
+                                  "valu_issue_frac": r.get("valu_issue_frac"), "lds_busy_frac": r.get("lds_busy_frac"),
+                                  "lds_bank_conflict_frac_of_lds": r.get("lds_bank_conflict_frac"),
+                                  "hbm_bytes": r.get("hbm_bytes"), "source": PMC_NAME if r else None}
+        # SURVEY 8(d): the same box's device-to-device copy rate next to the nominal peak (a copy moves 2 bytes per byte copied)
+        src_buf = S.chunks[0][0]
+        dst_buf = torch.empty_like(src_buf)
+        ms = ev_ms(lambda: dst_buf.copy_(src_buf), reps=5, warm=2)
+        copy_gbs = 2 * src_buf.numel() * 4 / ms / 1e6
+        ms_fill = ev_ms(lambda: dst_buf.zero_(), reps=5, warm=2)
+        fill_gbs = src_buf.numel() * 4 / ms_fill / 1e6
+        del dst_buf
+        # the polar rasteriser writes 21 % of its bytes (384 KB of cells per scan); this memory system streams writes slower than reads, so its
+        # bound is the mix of the two stream rates measured on this box: the read-mostly Cartesian rasteriser's rate for the points, a fill's
+        # rate for the cells
+        rp = line["roofline_polar"]
+        read_gbs = line.get("roofline_bev_scatter", {}).get("achieved")
+        if read_gbs:
+            rd, wr = S.B * 12 * N_POINTS, S.B * 4 * pcells
+            mix = (rd + wr) / (rd / read_gbs + wr / fill_gbs)
+            rp.update({"read_stream_gbs": read_gbs, "write_stream_gbs": fill_gbs, "write_share": wr / (rd + wr), "mix_bound_gbs": mix,
+                       "frac_of_mix_bound": rp["achieved"] / mix})
+            line["roofline"]["polar_frac_of_rw_mix_bound"] = rp["achieved"] / mix
+        line["roofline"]["measured_fill_gbs"] = fill_gbs
+        line["roofline"]["polar_frac_of_measured_copy"] = rp["achieved"] / copy_gbs
+        line["roofline"]["polar_frac"] = line["roofline_polar"]["frac"]
+        line["roofline"]["polar_gbs"] = line["roofline_polar"]["achieved"]
+        line["roofline"]["measured_copy_gbs"] = copy_gbs
+        line["roofline"]["frac_of_measured_copy"] = achieved / copy_gbs
+        line["roofline_polar"]["frac_of_measured_copy"] = line["roofline_polar"]["achieved"] / copy_gbs
+        line["sweeps"] = sweep_legs(S.device, S.spec32[:S.CH].reshape(-1, 61, 120))
+        line["node_shape"] = node_shape_leg(S.device, S.spec32[:S.CH].reshape(-1, 61, 120))
+        line["pipeline_shard"] = pipeline_shard_leg(S.device, S.spec32[:S.CH].reshape(-1, 61, 120), S.gicp_res)
+        line["builds"] = build_legs(S.device, S.chunks)
+        line["dropin_latency"] = dropin_latency_leg(host_scans(S.chunks[0][0], 1)[0])
+    if S.FUSE and not S.dist_on and S.args.verify > 0:
+        # the outputs of the timed loop's last fused launch are still in norm_group / out_dist / out_ang
+        last = ((S.CH - 1) // S.FUSE) * S.FUSE
+        line["verify"] = verify_timed_outputs(S.args.verify, make_shard.whole, S.norm_group[:(S.CH - last) * S.B], last, S.out_dist, S.out_ang, S.cand_idx,
+                                              lambda c: c - S.DEPTH if c >= S.DEPTH else S.CH - S.DEPTH + c)
+        # the per-launch sweeps of the timed loop (possibly issued on the side stream) against fresh ones over the same entries
+        bad = 0
+        for c in np.random.default_rng(1).choice(S.CH, size=min(S.args.verify, S.CH), replace=False):
+            d_f, _ = ring.corr_sweep_fft(S.spec32[S.wslot(int(c)), :1], S.spec32[S.db_slot(int(c))])
+            v_f, r_f = torch.min(d_f, 1)
+            bad += int(float(v_f[0]) != float(S.sweep_val[int(c)]) or int(r_f[0]) != int(S.sweep_row[int(c)]))
+        line["verify"]["sweep_mismatches"] = bad
+        line["verify"]["ok"] = bool(line["verify"]["ok"] and bad == 0)
+    if S.FUSE and not S.args.no_extra_legs:
+        # the other workgroup shape of the fused kernel on the same scans (N > 1 runs per_pair so that RCCL's kernels get in): measured, not assumed
+        other = "per_pair" if S.fused_grid == "persistent" else "persistent"
+        ng = min(S.FUSE, S.CH)
+        S.set_fused_grid(other)
+        ms_other = ev_ms(lambda: ring.ring_descriptors_fused(make_shard.whole[:ng].view(-1), S.group_offs[:ng * S.B + 1], raw=False, normalized=True,
+                                                             out_norm=S.norm_group[:ng * S.B]), reps=3, warm=1) / ng
+        S.set_fused_grid(S.fused_grid)
+        line["roofline"]["fused_grid_ms_per_launch"] = {S.fused_grid: S.kern_ms["bev_radon"], other: ms_other}
+        # the kernel's two phase floors in the same run (measurement option of the plan: the same kernel without its ray march / without its
+        # rasteriser) and how far the kernel is from a compute unit that overlapped them perfectly
+        fl = {}
+        for name, skip in (("full", 0), ("hbm_only_no_march", 2), ("march_only_no_rasteriser", 1)):
+            S.plan.set_option(S.plan.OPT_FUSED_SKIP, skip)
+            fl[name] = ev_ms(lambda: ring.ring_descriptors_fused(make_shard.whole[:ng].view(-1), S.group_offs[:ng * S.B + 1], raw=False, normalized=True,
+                                                                 out_norm=S.norm_group[:ng * S.B]), reps=3, warm=1) / ng
+        S.plan.set_option(S.plan.OPT_FUSED_SKIP, 0)
+        line["roofline"]["fused_phase_floors_ms_per_launch"] = fl
+        line["roofline"]["frac_of_max_hbm_only_march_only"] = max(fl["hbm_only_no_march"], fl["march_only_no_rasteriser"]) / fl["full"]
+    if S.world == 1 and not S.args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(host_scans(S.chunks[0][0], min(S.args.cpu_sample, S.B)))
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1478,299 +1781,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per launch of B scans; entries that cover several launches (descriptor kernel, grouped correlation, a group's sweeps) carry their count.
-    # With --sweep-stream side the sweep figure is stream time on the side stream (it includes waiting for compute units the other stream holds)
-    kern_ms = {k: float(sum(t[0].elapsed_time(t[1]) for t in v) / sum((t[2] if len(t) > 2 else 1) for t in v)) for k, v in ev.items() if v}
-
-    extra = {}
-    gicp_res = None
-    if args.gicp_pairs > 0:
-        fence()
-        gicp_res = gicp_leg(local_rank, rank, args.gicp_pairs, args.gicp_iters)
-        if dist_on:   # whole-job GICP rate: all ranks' iterations / slowest rank's time
-            t = torch.tensor([gicp_res["align_s"]], dtype=torch.float64, device=device)    # the cold-start forced protocol
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            gicp_res["iters_per_s"] = world * args.gicp_pairs * args.gicp_iters / float(t.item())
-            gicp_res["pairs"] = world * args.gicp_pairs
-
-    verify = None
-    if dist_on and args.verify_exchange:
-        # the last launch scored its new descriptors against what the exchange delivered (fp16 replicas / fetched fp32 rows) of the
-        # descriptors every rank built DEPTH launches earlier: gather those exact fp32 entries and score the same pairs against them
-        fence()
-        c = CH - 1
-        exact_db = shard.allgather_ragged(torch.view_as_real(spec32[db_slot(c)]).contiguous())
-        exact_db = torch.view_as_complex(exact_db.contiguous())
-        d_ex, a_ex = ring.corr_pairs_fft(spec32[c].contiguous(), exact_db[cand_idx[c].long()].contiguous())
-        err = (d_ex - out_dist[c]).abs()
-        verify = {"checked": int(err.numel()), "max_abs_dist_error": float(err.max()),
-                  "angle_mismatches": int((a_ex != out_ang[c]).sum()), "remote_candidates": int((cand_idx[c] // B != rank).sum())}
-        if EXCH == "fetch":
-            # the fetched rows are the owners' entries bit for bit, and the sharded top-1 sweep equals a sweep over the gathered database
-            verify["fetched_rows_bit_identical"] = bool(torch.equal(torch.view_as_real(last_fetched[0]),
-                                                                    torch.view_as_real(exact_db[cand_idx[c].long()])))
-            d_full, _ = ring.corr_sweep_fft(spec32[c, :1].contiguous(), exact_db)
-            v_full, r_full = torch.min(d_full, 1)
-            verify["sweep_value_equal"] = bool(float(v_full[0]) == float(sweep_val[c]))
-            verify["sweep_row_equal"] = bool(int(r_full[0]) == int(sweep_row[c]))
-        tol = 2e-3 if (EXCH == "allgather" and not REP32) else 1e-6          # fp16 replicas differ from the exact entries by < 2e-3 (re-scored near the threshold)
-        verify["ok"] = bool(verify["max_abs_dist_error"] < tol and (EXCH == "allgather" and not REP32 or verify["angle_mismatches"] == 0) and
-                            all(verify.get(k, True) for k in ("fetched_rows_bit_identical", "sweep_value_equal", "sweep_row_equal")))
-
-    topk_cmp = None
-    if dist_on:
-        # the two database designs of SURVEY.md 8(e) side by side: (a) replicate (all-gather the descriptors, every rank sweeps
-        # everything: what the step does) vs (b) keep the database sharded, all-gather the QUERIES, exchange top-k rows only
-        q_local = spec32[0, :4].contiguous()
-        fence()
-
-        def design_a():
-            full = shard.allgather_ragged(torch.view_as_real(spec32[0]).to(torch.float16))
-            d, a = ring.corr_sweep_fft(q_local, full)
-            return torch.topk(d, 4, dim=1, largest=False)
-
-        def design_b():
-            q_all = shard.allgather_ragged(torch.view_as_real(q_local).contiguous())
-            return shard.sharded_topk_sweep(torch.view_as_complex(q_all), spec32[0], ring.corr_sweep_fft, 4)
-        ms_a, ms_b = ev_ms(design_a, reps=3, warm=1), ev_ms(design_b, reps=3, warm=1)
-        topk_cmp = {"replicate_db_ms": ms_a, "sharded_topk_ms": ms_b, "queries_per_rank": 4, "db_rows_per_rank": B,
-                    "replicate_bytes_in_per_rank": (world - 1) * B * 29280, "sharded_bytes_in_per_rank": (world - 1) * 4 * (58560 + 4 * 16)}
-
-    side_stream = None
-    if SIDE_SWEEP and "sweep" in kern_ms:
-        # on the side stream the interval between a batch's events is STREAM time: it contains the wait for compute units the descriptor
-        # kernel holds, so it is not a kernel duration and must not be added to the others.  The sweep's own duration is measured stand-alone
-        # right here (same entries), the stream time is reported apart
-        fence()
-        side_stream = {"sweeps_stream_time_ms_per_launch": kern_ms.pop("sweep"),
-                       "note": "time between the events around a batch of sweeps on the side stream / launches in the batch: includes waiting for "
-                               "compute units held by the descriptor kernel on the compute stream; kernel_ms.sweep_standalone is the sweep's own duration"}
-        kern_ms["sweep_standalone"] = ev_ms(lambda: torch.min(ring.corr_sweep_fft(spec32[wslot(0), :1], spec32[db_slot(0)])[0], 1))
-
-    if rank == 0:
-        pmc = load_pmc()
-        cells = 120 * 120
-        bev_bytes = B * (12 * N_POINTS + 4 * cells)          # 12 B/point + 4 B/cell
-        if FUSE:
-            # the rasteriser no longer runs on its own in the timed region: its stand-alone roofline is measured right here (same
-            # scans, same box), the timed region's dominant kernel is the fused one (12 B/point in, one normalised sinogram out)
-            xyz0, offs0 = chunks[0]
-            kern_ms["bev_standalone"] = ev_ms(lambda: bev.cart_bev(xyz0, offs0, 1, 1, 120, 120, 1, out=img.view(B, -1)))
-            kern_ms["radon_standalone"] = ev_ms(lambda: plan.forward(img.view(B, 120, 120), raw=False, normalized=True))
-            fused_bytes = B * (12 * N_POINTS + 4 * cells)
-            achieved = fused_bytes / (kern_ms["bev_radon"] * 1e-3) / 1e9
-        else:
-            achieved = bev_bytes / (kern_ms["bev"] * 1e-3) / 1e9
-        line = {
-            "metric": "loop-candidate pairs/sec (BEV+Radon+corr), 120k-pt scans",
-            "value": world * B * CH * args.steps / elapsed,
-            "unit": "pairs/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1] batched: 120k-pt synthetic lidar scans -> Cartesian BEV 120x120x1 -> Radon "
-                                   "120x120 -> normalise -> half spectrum -> FFT-domain rotation correlation vs 1 candidate of the "
-                                   "database (+ 1 query per launch swept over the database)",
-                       "pairs_per_rank_per_step": B * CH, "pairs_per_launch": B, "launches_per_step": CH,
-                       "database_rows_swept_per_launch": NDB,      # grows with the world size: the replicated database is world x B rows
-                       "resident_scan_bytes_per_rank": B * CH * 12 * N_POINTS, "points_per_scan": N_POINTS,
-                       "parallelism": f"scan-sharded x{world}" + ("" if not dist_on else
-                                                                  " + RCCL all-gather of fp16 descriptor replicas, candidates and sweeps read the "
-                                                                  "replicated database, owner re-scoring" if EXCH == "allgather" else
-                                                                  " + database kept sharded: RCCL all-to-all of the candidate rows asked for (exact "
-                                                                  "fp32, pre-planned), per-launch query all-gathered for a sharded top-1 sweep"),
-                       "exchange": EXCH, "exchange_impl": (args.exchange_impl if dist_on else None), "fused_grid": fused_grid if FUSE else None},
-            "timed_region_s": elapsed,
-            "setup_s": setup_s,
-            "kernel_ms": kern_ms,
-            "side_stream": side_stream,
-            "roofline": {"kernel": "k_cart_lds (BEV scatter)", "bound": "hbm", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc.get("k_cart_lds", {}).get("hbm_bytes"), "algorithmic_bytes_per_launch": bev_bytes,
-                         "traffic_source": PMC_NAME + " (rocprofv3 --pmc passes of tools/pmc_targets.py)" if pmc.get("k_cart_lds") else None},
-            "gicp": gicp_res,
-        }
-        if FUSE:
-            # one kernel with an HBM-bound half (rasteriser) and a VALU-bound half (Radon march) per workgroup, overlapped across
-            # compute units: its time is bounded below by max(HBM time of the points, VALU time of the rays), not by either alone
-            r = pmc.get("k_bev_radon3") or pmc.get("k_bev_radon2", {})
-            if r.get("hbm_bytes"):        # the PMC pass profiles the kernel at 16 x 1024 scans per launch: per 1024 scans like everything else here
-                per = (r.get("launch_scans") or 1024) / 1024.0
-                r = dict(r, hbm_bytes=r["hbm_bytes"] / per, valu_pipe_cycles_est=(r.get("valu_pipe_cycles_est") or 0) / per or None,
-                         counters={k: v / per for k, v in (r.get("counters") or {}).items()})
-            sa = bev_bytes / (kern_ms["bev_standalone"] * 1e-3) / 1e9
-            line["config"]["fused_launches"] = FUSE
-            line["config"]["corr_launches_grouped"] = FUSE if GROUP_CORR else 1
-            line["config"]["sweep_stream"] = "side" if (SIDE_SWEEP or EXCH == "fetch") else "main"
-            line["config"]["sweeps_per_launch"] = FUSE if SWEEP_BATCH else 1
-            if SIDE_SWEEP:
-                line["config"]["sweep_join"] = args.sweep_join
-            if args.fused_wgs > 0:
-                line["config"]["fused_persistent_workgroups"] = args.fused_wgs
-            line["config"]["database_slots"] = "two sets, alternating per step" if RING_DB else "one set + copies of the previous step's last entries"
-            line["roofline"] = {"kernel": f"k_bev_radon3 (BEV scatter + Radon + normalise, {FUSE} x {B} scans per launch)", "bound": "hbm",
-                                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                "traffic": r.get("hbm_bytes"), "algorithmic_bytes_per_launch": bev_bytes,
-                                "traffic_source": PMC_NAME if r else None,
-                                "valu_issue_frac": r.get("valu_issue_frac"), "lds_busy_frac": r.get("lds_busy_frac"),
-                                "valu_roofline": valu_roofline(r, kern_ms["bev_radon"]),
-                                "note": "per 1024 scans; the kernel also carries the VALU-bound Radon march (1.47 M two-tap samples per image), "
-                                        "so the HBM fraction of the fused kernel is below the stand-alone rasteriser's by construction",
-                                "ms_vs_separate_kernels": {"fused": kern_ms["bev_radon"], "bev_standalone": kern_ms["bev_standalone"],
-                                                           "radon_standalone": kern_ms["radon_standalone"]}}
-            line["roofline_bev_scatter"] = {"kernel": "k_cart_lds (BEV scatter, stand-alone launch outside the timed region)", "bound": "hbm",
-                                            "achieved": sa, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sa / HBM_PEAK_GBS,
-                                            "ms": kern_ms["bev_standalone"], "traffic": pmc.get("k_cart_lds", {}).get("hbm_bytes"),
-                                            "algorithmic_bytes_per_launch": bev_bytes}
-        if gicp_res:
-            # north_star's own targets as flat scalars of `roofline` (the driver's record keeps scalars of this block)
-            gr = gicp_res["roofline"]
-            line["roofline"].update({
-                "gicp_iters_per_s": gicp_res["iters_per_s"], "gicp_iters_per_s_warm": gicp_res["warm"]["iters_per_s"],
-                "gicp_iters_per_s_cold5": gicp_res["cold"]["iters_per_s"],
-                "gicp_natural_pairs_per_s": gicp_res["natural"]["pairs_per_s"], "gicp_pairs_per_s_incl_covariances": gicp_res["pairs_per_s_incl_covariances"],
-                "gicp_pairs_per_s_incl_covariances_shared_submaps": gicp_res["shared_submaps"]["pairs_per_s_incl_covariances"],
-                "gicp_searched_fraction_natural": gicp_res["natural"]["searched_fraction"],
-                "gicp_linearize_ms": gr["k_linearize"]["ms"], "gicp_linearize_gbs": gr["k_linearize"]["achieved"], "gicp_linearize_frac": gr["k_linearize"]["frac"],
-                "gicp_linearize_error_only_frac": gr["k_linearize_error_only"]["frac"],
-                "gicp_nn_round3_all_ms": gicp_res["kernel_ms"]["search_round3_all"], "gicp_nn_round4_all_ms": gicp_res["kernel_ms"]["search_round4_all"],
-                "gicp_nn_certify_ms": gicp_res["kernel_ms"]["certify"], "gicp_nn_certify_frac": gr["k_nn_certify (unchanged pose)"]["frac"],
-                "gicp_nn_certified_pass_1mm_ms": gicp_res["kernel_ms"]["certify_plus_worklist_1mm"],
-                "gicp_knn_select_ms": gicp_res["kernel_ms"]["knn_select"], "gicp_cov_from_knn_ms": gicp_res["kernel_ms"]["cov_from_knn"],
-                "gicp_pairs": gicp_res["pairs"]})
-            line["roofline"]["gicp"] = gr
-        if FUSE:
-            line["roofline"]["bev_scatter_frac"] = line["roofline_bev_scatter"]["frac"]
-            line["roofline"]["bev_scatter_gbs"] = line["roofline_bev_scatter"]["achieved"]
-        if dist_on:
-            # bytes a rank receives per launch under either design, and the inbound rate each would need at the measured step time
-            ag_launch = (world - 1) * B * (58560 if REP32 else 29280)
-            if EXCH == "fetch":
-                fetch_launch = float(np.mean([pl.bytes_in(58560) for pl in fetch_plans]))
-            else:
-                fetch_launch = (world - 1) / world * B * 58560                    # expected for uniformly drawn candidates
-            sweep_launch = (world - 1) * (58560 + world * 16)                     # the other ranks' queries + their packed top-1 answers
-            step_s = 1e-3 * line["ms_per_step"]
-            undecided = None
-            if rescorer is not None:
-                # proof that no loop decision rests on a replica score: after re-scoring, every (query, candidate) whose REPLICA distance was
-                # within the margin of the acceptance threshold carries the owner's exact value (rescore.requested of them, in rescore.rounds
-                # fixed-size rounds that only end when every rank reports none left); the rest differ from exact by < 2e-3 < margin
-                undecided = {"replica_margin": rescorer.margin, "threshold": rescorer.threshold, "requested": rescorer.stats["requested"],
-                             "rounds": rescorer.stats["rounds"], "left_undecided": rescorer.stats["still_ambiguous"],
-                             "note": "measured on the last call: left_undecided = ambiguous entries of its output that were not replaced by an owner's exact "
-                                     "score; the loop ends only when an all-reduce(MAX) of the per-rank remaining counts is 0"}
-            line["exchange"] = {"design": EXCH, "impl": args.exchange_impl,
-                                "impl_note": ("data-path collectives through the C ABI (mrs_exchange_allgather / mrs_exchange_fetch_planned, the library's own RCCL "
-                                              "communicator of %d ranks) on a communication stream" % xch.world) if CABI else "torch.distributed collectives",
-                                "process_group": {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "gpus_flag": args.gpus,
-                                                  "devices_visible": torch.cuda.device_count()},
-                                "replica": (args.replica if EXCH == "allgather" else None),
-                                "decisions_on_replica_scores": (None if EXCH != "allgather" or rescorer is None else rescorer.stats["still_ambiguous"]),
-                                "rescore_proof": undecided,
-                                "allgather": {"format": ("exact fp32 half spectra, 58 560 B per descriptor" if REP32 else
-                                                         "fp16 half spectra, 29 280 B per descriptor") + ", every descriptor to every rank",
-                                              "bytes_in_per_rank_per_launch": ag_launch,
-                                              "inbound_gbs_needed_at_this_rate": (ag_launch * CH / step_s / 1e9) if world > 1 else None},
-                                "fetch": {"format": "exact fp32 half spectra, 58 560 B per candidate row actually asked for (pre-planned all-to-all) + one "
-                                                    "query per rank and launch all-gathered for the sharded top-1 sweep",
-                                          "bytes_in_per_rank_per_launch": fetch_launch + sweep_launch,
-                                          "rows_bytes_in_per_rank_per_launch": fetch_launch, "sweep_bytes_in_per_rank_per_launch": sweep_launch,
-                                          "inbound_gbs_needed_at_this_rate": ((fetch_launch + sweep_launch) * CH / step_s / 1e9) if world > 1 else None,
-                                          "launches_ahead": FETCH_AHEAD if EXCH == "fetch" else None},
-                                "compute_stream_wait_ms_per_launch": kern_ms.get("wait"),
-                                "compute_stream_wait_ms_per_step": kern_ms.get("wait", 0.0) * CH,
-                                "rescore": rescorer.stats if rescorer else None, "designs": topk_cmp, "verify": verify}
-        if not args.no_extra_legs:
-            # polar BEV (the rasteriser north_star names), DiSCO layout 40 x 120 x 20, same scans
-            xyz0, offs0 = chunks[0]
-            pcells = 40 * 120 * 20
-            ms = ev_ms(lambda: bev.polar_bev(xyz0, offs0, 1, 1, 40, 120, 20))
-            pbytes = B * (12 * N_POINTS + 4 * pcells)
-            line["roofline_polar"] = {"kernel": "k_polar_lds (polar BEV scatter, 40x120x20)", "bound": "hbm", "achieved": pbytes / ms / 1e6,
-                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": pbytes / ms / 1e6 / HBM_PEAK_GBS, "ms": ms,
-                                      "traffic": pmc.get("k_polar_lds", {}).get("hbm_bytes"), "algorithmic_bytes_per_launch": pbytes}
-            samples = 1.47e6 * B                       # two-tap samples per launch (120 angles x 120 rays x ~102 steps)
-            radon_ms = kern_ms.get("radon", kern_ms.get("radon_standalone"))
-            r = pmc.get("k_radon2", {})
-            line["roofline_radon"] = {"kernel": "k_radon2 (two images per workgroup)", "bound": "valu+lds (not HBM: 115 KB per image)",
-                                      "ms": radon_ms, "samples_per_s": samples / (radon_ms * 1e-3),
-                                      "valu_issue_frac": r.get("valu_issue_frac"), "lds_busy_frac": r.get("lds_busy_frac"),
-                                      "lds_bank_conflict_frac_of_lds": r.get("lds_bank_conflict_frac"),
-                                      "hbm_bytes": r.get("hbm_bytes"), "source": PMC_NAME if r else None}
-            # the same box's device-to-device copy rate next to the nominal peak (a copy moves 2 bytes per byte copied)
-            src_buf = chunks[0][0]
-            dst_buf = torch.empty_like(src_buf)
-            ms = ev_ms(lambda: dst_buf.copy_(src_buf), reps=5, warm=2)
-            copy_gbs = 2 * src_buf.numel() * 4 / ms / 1e6
-            ms_fill = ev_ms(lambda: dst_buf.zero_(), reps=5, warm=2)
-            fill_gbs = src_buf.numel() * 4 / ms_fill / 1e6
-            del dst_buf
-            # the polar rasteriser writes 21 % of its bytes (384 KB of cells per scan); this memory system streams writes slower than reads, so its
-            # bound is the mix of the two stream rates measured on this box: the read-mostly Cartesian rasteriser's rate for the points, a fill's
-            # rate for the cells
-            rp = line["roofline_polar"]
-            read_gbs = line.get("roofline_bev_scatter", {}).get("achieved")
-            if read_gbs:
-                rd, wr = B * 12 * N_POINTS, B * 4 * pcells
-                mix = (rd + wr) / (rd / read_gbs + wr / fill_gbs)
-                rp.update({"read_stream_gbs": read_gbs, "write_stream_gbs": fill_gbs, "write_share": wr / (rd + wr), "mix_bound_gbs": mix,
-                           "frac_of_mix_bound": rp["achieved"] / mix})
-                line["roofline"]["polar_frac_of_rw_mix_bound"] = rp["achieved"] / mix
-            line["roofline"]["measured_fill_gbs"] = fill_gbs
-            line["roofline"]["polar_frac_of_measured_copy"] = rp["achieved"] / copy_gbs
-            line["roofline"]["polar_frac"] = line["roofline_polar"]["frac"]
-            line["roofline"]["polar_gbs"] = line["roofline_polar"]["achieved"]
-            line["roofline"]["measured_copy_gbs"] = copy_gbs
-            line["roofline"]["frac_of_measured_copy"] = achieved / copy_gbs
-            line["roofline_polar"]["frac_of_measured_copy"] = line["roofline_polar"]["achieved"] / copy_gbs
-            line["sweeps"] = sweep_legs(device, spec32[:CH].reshape(-1, 61, 120))
-            line["node_shape"] = node_shape_leg(device, spec32[:CH].reshape(-1, 61, 120))
-            line["pipeline_shard"] = pipeline_shard_leg(device, spec32[:CH].reshape(-1, 61, 120), gicp_res)
-            line["builds"] = build_legs(device, chunks)
-            line["dropin_latency"] = dropin_latency_leg(host_scans(chunks[0][0], 1)[0])
-        if FUSE and not dist_on and args.verify > 0:
-            # the outputs of the timed loop's last fused launch are still in norm_group / out_dist / out_ang
-            last = ((CH - 1) // FUSE) * FUSE
-            line["verify"] = verify_timed_outputs(args.verify, make_shard.whole, norm_group[:(CH - last) * B], last, out_dist, out_ang, cand_idx,
-                                                  lambda c: c - DEPTH if c >= DEPTH else CH - DEPTH + c)
-            # the per-launch sweeps of the timed loop (possibly issued on the side stream) against fresh ones over the same entries
-            bad = 0
-            for c in np.random.default_rng(1).choice(CH, size=min(args.verify, CH), replace=False):
-                d_f, _ = ring.corr_sweep_fft(spec32[wslot(int(c)), :1], spec32[db_slot(int(c))])
-                v_f, r_f = torch.min(d_f, 1)
-                bad += int(float(v_f[0]) != float(sweep_val[int(c)]) or int(r_f[0]) != int(sweep_row[int(c)]))
-            line["verify"]["sweep_mismatches"] = bad
-            line["verify"]["ok"] = bool(line["verify"]["ok"] and bad == 0)
-        if FUSE and not args.no_extra_legs:
-            # the other workgroup shape of the fused kernel on the same scans (N > 1 runs per_pair so that RCCL's kernels get in): measured, not assumed
-            other = "per_pair" if fused_grid == "persistent" else "persistent"
-            ng = min(FUSE, CH)
-            set_fused_grid(other)
-            ms_other = ev_ms(lambda: ring.ring_descriptors_fused(make_shard.whole[:ng].view(-1), group_offs[:ng * B + 1], raw=False, normalized=True,
-                                                                 out_norm=norm_group[:ng * B]), reps=3, warm=1) / ng
-            set_fused_grid(fused_grid)
-            line["roofline"]["fused_grid_ms_per_launch"] = {fused_grid: kern_ms["bev_radon"], other: ms_other}
-            # the kernel's two phase floors in the same run (measurement option of the plan: the same kernel without its ray march / without its
-            # rasteriser) and how far the kernel is from a compute unit that overlapped them perfectly
-            fl = {}
-            for name, skip in (("full", 0), ("hbm_only_no_march", 2), ("march_only_no_rasteriser", 1)):
-                plan.set_option(plan.OPT_FUSED_SKIP, skip)
-                fl[name] = ev_ms(lambda: ring.ring_descriptors_fused(make_shard.whole[:ng].view(-1), group_offs[:ng * B + 1], raw=False, normalized=True,
-                                                                     out_norm=norm_group[:ng * B]), reps=3, warm=1) / ng
-            plan.set_option(plan.OPT_FUSED_SKIP, 0)
-            line["roofline"]["fused_phase_floors_ms_per_launch"] = fl
-            line["roofline"]["frac_of_max_hbm_only_march_only"] = max(fl["hbm_only_no_march"], fl["march_only_no_rasteriser"]) / fl["full"]
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(host_scans(chunks[0][0], min(args.cpu_sample, B)))
-    else:
-        line = None
+    S = types.SimpleNamespace(**locals())
+    S.__dict__.update(after_timed_region(S))
+    line = result_line(S) if rank == 0 else None
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
