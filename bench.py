@@ -561,9 +561,9 @@ def sweep_legs(device, spec_pool, n_db=10_000):
     # the entry leaves HBM once (profiles/r06_sweep_mq.md); hbm_frac = database bytes streamed ONCE per launch / time
     for nq in (4, 8):
         q = spec_pool[:nq].contiguous()
-        out[f"ring_q{nq}"] = entry(nq, ev_ms(lambda: ring.corr_sweep_fft_tiled_q(q, tiled)), TILED, layout="dma-tiled (mrs_loopdb_query_multi)")
+        out[f"ring_q{nq}"] = entry(nq, ev_ms(lambda: ring.corr_sweep_fft_tiled_q(q, tiled), reps=10, warm=3), TILED, layout="dma-tiled (mrs_loopdb_query_multi)")
     q = spec_pool[:4].contiguous()
-    out["ring_q4_row_layout"] = entry(4, ev_ms(lambda: ring.corr_sweep_fft(q, db)), 58560)
+    out["ring_q4_row_layout"] = entry(4, ev_ms(lambda: ring.corr_sweep_fft(q, db), reps=10, warm=3), 58560)
     del tiled
     db6 = torch.stack([db.roll(k, 0) for k in range(6)], 1).contiguous()   # RING++: [n_db][6][61][120] = 351 360 B each
     tiled6 = ring.spec_to_tiled(db6)
