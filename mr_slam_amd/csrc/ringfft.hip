@@ -1070,15 +1070,6 @@ static int sweep_dma_queries(mrs_ctx* ctx, hipStream_t s, const float2* q, int n
             if (st != MRS_OK) return st;
             continue;
         }
-        if (tiled && p.nq == 2 && !mrs::dev_env("MRS_SWEEP_MQ_VARIANT")) {
-            // two queries over tiled entries: the pair of workgroups moves at the pace of the one that misses (213 us per 10 000 entries), two
-            // one-query sweeps at the HBM rate take 2 x 96 us
-            FftCorrP p1 = p;
-            p1.nq = 1;
-            for (int i = 0; i < 2; ++i)
-                MRS_HIP_TRY(sweep_dma_launch(kSweepDmaTiledDefault, num_cu, s, qq + (size_t)i * qentry, db, p1, dd + (size_t)i * p.ndb, aa + (size_t)i * p.ndb, true));
-            continue;
-        }
         int variant = p.nq > 1 ? kSweepDmaMultiDefault : (tiled ? kSweepDmaTiledDefault : kSweepDmaDefault);
         if (const char* v = mrs::dev_env(p.nq > 1 ? "MRS_SWEEP_MQ_VARIANT" : "MRS_SWEEP_VARIANT")) variant = atoi(v) > 0 ? atoi(v) : variant;
         MRS_HIP_TRY(sweep_dma_launch(variant, num_cu, s, qq, db, p, dd, aa, tiled));
