@@ -227,6 +227,7 @@ class DeviceMirror:
         with self._lock:
             self._d.clear()
             self.bytes = 0
+            self.hits = self.misses = 0
 
 
 _mirror = DeviceMirror()
