@@ -1463,6 +1463,9 @@ def main():
     EXCH = args.exchange if dist_on else None
     CABI = bool(dist_on and args.exchange_impl == "cabi")
     xch = comm_stream = None
+    if CABI and world > 1 and os.environ.get("MRS_BENCH_SHARE_GPU") == "1":
+        sys.exit("bench.py: --exchange-impl cabi needs one GPU per rank (RCCL refuses two ranks on one device); the shared-GPU gloo mode is for "
+                 "--exchange-impl torch only")
     if CABI:
         # the product's own exchange: one RCCL communicator made by the library (its unique id travels through the process group once)
         xch = shard.Exchange(device=local_rank)
