@@ -1029,12 +1029,14 @@ template <int WAVES, bool PREN>
 __global__ __launch_bounds__(kNNThreads) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_linearize(
     const float4* __restrict__ src_all, const int64_t* __restrict__ src_offs, const double* __restrict__ src_cov,
     const float4* __restrict__ tgt_all, const int64_t* __restrict__ tgt_offs, const double* __restrict__ tgt_cov,
-    const LmState* __restrict__ st, const int* __restrict__ corr, double* __restrict__ partial, int max_blocks)
+    const LmState* __restrict__ st, const int* __restrict__ corr, double* __restrict__ partial, int max_blocks, int trial_only)
 {
     __shared__ double red[kNNThreads / 64][kTerms];
     const int pair = blockIdx.y;
     const LmState& S = st[pair];
     if (!S.active) return;
+    if (trial_only && S.phase == 0) return;     // a tick enqueued WITHOUT its search kernels (mrs_gicp_batch_align, one pair): a pair that needs a
+                                                // linearisation sits this tick out (k_lm_update leaves its state alone) and takes the next, full one
     const int64_t so = src_offs[pair], to = tgt_offs[pair];
     const int n = (int)(src_offs[pair + 1] - so);
     const float4* src = src_all + so;
@@ -1880,22 +1882,32 @@ __device__ void propose(LmState& S)
 //   outer iteration linearises again: phase 0) or reject (lambda *= nu, next candidate, stay in phase 1)
 // n_next[0] counts the pairs that need a linearisation next tick, n_next[1] the pairs in an LM trial, n_next[2] those of [0] that moved
 // farther than prm.motion_switch in the step just accepted.
-__global__ void k_lm_update(LmState* __restrict__ st, const double* __restrict__ partial, const int* __restrict__ nblocks,
-                            int max_blocks, GicpParams prm, int* __restrict__ n_next)
+constexpr int kLmThreads = 256;     // four waves share the 28 terms of the final sum (rounds 1-5: one wave, 28 dependent reductions in a row)
+__global__ __launch_bounds__(kLmThreads) void k_lm_update(LmState* __restrict__ st, const double* __restrict__ partial, const int* __restrict__ nblocks,
+                            int max_blocks, GicpParams prm, int* __restrict__ n_next, int trial_only)
 {
     const int pair = blockIdx.x;
     LmState& S = st[pair];
     if (!S.active) return;
+    if (trial_only && S.phase == 0) {                   // see k_linearize: the pair waits for the next full tick; it still counts as "to linearise"
+        if (threadIdx.x == 0) {
+            atomicAdd(&n_next[0], 1);
+            if (pair_motion(S) > prm.motion_switch) atomicAdd(&n_next[2], 1);
+        }
+        return;
+    }
     __shared__ double sum[kTerms];
     {   // fixed-order (deterministic) final sum of the per-workgroup partials: lane l adds blocks l, l + 64, ...
-        // in ascending order, then one wave butterfly per term
+        // in ascending order, then one wave butterfly per term; wave w takes the terms t0 + w, t0 + w + 4, ... (the order INSIDE a term is
+        // what fixes its bits, and that is unchanged)
         const double* p = partial + (size_t)pair * max_blocks * kTerms;
         const int nb = nblocks[pair];
-        for (int t = S.phase == 1 ? kTerms - 1 : 0; t < kTerms; ++t) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (int t = (S.phase == 1 ? kTerms - 1 : 0) + wave; t < kTerms; t += kLmThreads / 64) {
             double v = 0;
-            for (int b = threadIdx.x; b < nb; b += 64) v += p[(size_t)b * kTerms + t];
+            for (int b = lane; b < nb; b += 64) v += p[(size_t)b * kTerms + t];
             v = wave_sum_d(v);
-            if (threadIdx.x == 0) sum[t] = v;
+            if (lane == 0) sum[t] = v;
         }
     }
     __syncthreads();
@@ -2978,15 +2990,22 @@ int mrs_gicp_batch_align(mrs_gicp_batch* h, const double* h_guess, double* h_fin
     if (small && window > 1 && h->prm.voxel_res <= 0.0) {
         static_assert(kLmWindowMax * 4 <= mrs::kSidePinnedInts, "the slot's pinned buffer holds a window's counters");
         int* const h_win = side.sl.pinned;
-        while (next[0] + next[1] > 0 && ticks < max_ticks) {
+        const bool alternate = h->n_pairs == 1 && !mrs::dev_env("MRS_GICP_FULL_TICKS");
+        const long max_ticks_w = alternate ? 2 * max_ticks : max_ticks;      // a sat-out tick does no work: the bound counts work ticks
+        while (next[0] + next[1] > 0 && ticks < max_ticks_w) {
             MRS_HIP_TRY(hipMemsetAsync(h->d_nactive, 0, (size_t)window * 4 * sizeof(int), s));
             for (int t = 0; t < window; ++t) {
+                // ONE pair alternates between a linearisation and (at least) one LM trial: every second tick is enqueued without its four
+                // search kernels (an empty launch still costs ~5 us on the stream: 20 us per trial tick, ~160 us per registration).  If the
+                // pair needs a linearisation on such a tick after all (it only does after a rejected trial shifted the rhythm) it sits the
+                // tick out -- k_linearize / k_lm_update leave it alone -- and takes the next one: same transitions, same bits.
+                const int trial_only = (alternate && ((ticks + t) & 1)) ? 1 : 0;
                 h->big_movers = 1;                      // the broad search gates itself on the pair's motion (k_nn_scan: gate)
-                if ((st = nn_pass(h, (ticks == 0 && t == 0) ? 0 : 1, s)) != MRS_OK) return st;
+                if (!trial_only && (st = nn_pass(h, (ticks == 0 && t == 0) ? 0 : 1, s)) != MRS_OK) return st;
                 launch_linearize(grid, s, h->d_pts[0], h->d_offs[0], h->d_cov[0],
-                                   h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->d_corr, h->d_partial, h->max_blocks);
-                hipLaunchKernelGGL(k_lm_update, dim3(h->n_pairs), dim3(64), 0, s, h->d_state, h->d_partial, h->d_nblocks,
-                                   h->max_blocks, h->prm, h->d_nactive + 4 * t);
+                                   h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->d_corr, h->d_partial, h->max_blocks, trial_only);
+                hipLaunchKernelGGL(k_lm_update, dim3(h->n_pairs), dim3(kLmThreads), 0, s, h->d_state, h->d_partial, h->d_nblocks,
+                                   h->max_blocks, h->prm, h->d_nactive + 4 * t, trial_only);
             }
             MRS_HIP_TRY(hipGetLastError());
             MRS_HIP_TRY(hipMemcpyAsync(h_win, h->d_nactive, (size_t)window * 4 * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -3007,11 +3026,11 @@ int mrs_gicp_batch_align(mrs_gicp_batch* h, const double* h_guess, double* h_fin
                 if ((st = nn_pass(h, nn_ticks == 0 ? 0 : 1, s)) != MRS_OK) return st;
             }
             launch_linearize(grid, s, h->d_pts[0], h->d_offs[0], h->d_cov[0],
-                               h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->d_corr, h->d_partial, h->max_blocks);
+                               h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->d_corr, h->d_partial, h->max_blocks, 0);
         }
         if (next[0] > 0) ++nn_ticks;
-        hipLaunchKernelGGL(k_lm_update, dim3(h->n_pairs), dim3(64), 0, s, h->d_state, h->d_partial, h->d_nblocks,
-                           h->max_blocks, h->prm, h->d_nactive);
+        hipLaunchKernelGGL(k_lm_update, dim3(h->n_pairs), dim3(kLmThreads), 0, s, h->d_state, h->d_partial, h->d_nblocks,
+                           h->max_blocks, h->prm, h->d_nactive, 0);
         MRS_HIP_TRY(hipGetLastError());
         MRS_HIP_TRY(hipMemcpyAsync(next, h->d_nactive, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
         MRS_HIP_TRY(hipStreamSynchronize(s));
@@ -3067,7 +3086,7 @@ int mrs_gicp_batch_linearize(mrs_gicp_batch* h, const double* h_poses, double* h
         if ((st = nn_pass(h, 2, s)) != MRS_OK) return st;
         launch_linearize(dim3(h->max_blocks, h->n_pairs), s, h->d_pts[0], h->d_offs[0],
                            h->d_cov[0], h->d_pts[1], h->d_offs[1], h->d_cov[1], h->d_state, h->d_corr, h->d_partial,
-                           h->max_blocks);
+                           h->max_blocks, 0);
     }
     if (d_corr)
         hipLaunchKernelGGL(k_corr_to_original, dim3(64, h->n_pairs), dim3(256), 0, s, h->d_pts[0], h->d_offs[0], h->d_pts[1],
@@ -3188,7 +3207,7 @@ int mrs_gicp_batch_profile(mrs_gicp_batch* h, const double* h_poses, int32_t rep
     if ((st = dump_trace(3)) != MRS_OK) return fail(st);
     if ((st = timed(out_ms[0], [&]() {
              launch_linearize(lin_grid, s, h->d_pts[0], h->d_offs[0], h->d_cov[0], h->d_pts[1], h->d_offs[1], h->d_cov[1],
-                                h->d_state, h->d_corr, h->d_partial, h->max_blocks);
+                                h->d_state, h->d_corr, h->d_partial, h->max_blocks, 0);
          })) != MRS_OK) return fail(st);
     {   // correspondences at the poses
         std::vector<int> corr(h->n_seed);
@@ -3204,7 +3223,7 @@ int mrs_gicp_batch_profile(mrs_gicp_batch* h, const double* h_poses, int32_t rep
     if ((st = upload(1, 0.0)) != MRS_OK) return fail(st);
     if ((st = timed(out_ms[1], [&]() {
              launch_linearize(lin_grid, s, h->d_pts[0], h->d_offs[0], h->d_cov[0], h->d_pts[1], h->d_offs[1], h->d_cov[1],
-                                h->d_state, h->d_corr, h->d_partial, h->max_blocks);
+                                h->d_state, h->d_corr, h->d_partial, h->max_blocks, 0);
          })) != MRS_OK) return fail(st);
     // a pass after a 1 mm step: certify + search the work lists (the certificates are those of the unmoved poses: t_prev stays)
     if ((st = upload(0, 1e-3)) != MRS_OK) return fail(st);
