@@ -182,7 +182,7 @@ class DeviceMirror:
 
     def __init__(self, max_bytes=8 << 30):
         self._d = {}
-        self._lock = threading.Lock()
+        self._lock = threading.RLock()           # re-entrant: a weak-reference callback (garbage collection) may fire on the thread that holds it
         self.max_bytes = int(max_bytes)
         self.bytes = 0
         self.hits = self.misses = 0
