@@ -2477,7 +2477,12 @@ static int prepare_side(mrs_gicp_batch* h, int32_t which, const int64_t* h_offse
     if (h->d_seed) MRS_HIP_TRY(hipMemsetAsync(h->d_seed, 0xff, h->n_seed * sizeof(int), s));  // -1: no warm start across clouds
     MRS_HIP_TRY(hipMemcpyAsync(h->d_offs[which], h_offsets, (h->n_pairs + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
     MRS_HIP_TRY(hipMemcpyAsync(h->d_tile_base[which], tile_base.data(), h->n_pairs * sizeof(int), hipMemcpyHostToDevice, s));
-    MRS_HIP_TRY(hipStreamSynchronize(s));   // tile_base and h_offsets are temporaries
+    // per-cloud bounding boxes armed for k_cloud_bbox (ordered ints: min = +max, max = -max)
+    std::vector<int> box_init((size_t)h->n_pairs * 6);
+    for (int i = 0; i < h->n_pairs; ++i)
+        for (int a = 0; a < 3; ++a) { box_init[6 * i + a] = INT32_MAX; box_init[6 * i + 3 + a] = INT32_MIN; }
+    MRS_HIP_TRY(hipMemcpyAsync(h->d_bbox[which], box_init.data(), box_init.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    MRS_HIP_TRY(hipStreamSynchronize(s));   // tile_base, box_init and h_offsets are temporaries
     return MRS_OK;
 }
 
@@ -2598,13 +2603,7 @@ int mrs_gicp_batch_set_clouds(mrs_gicp_batch* h, int32_t which, const float* d_p
     if ((st = keys_out.alloc((size_t)total * 8, s)) != MRS_OK) return st;
     if ((st = vals_in.alloc((size_t)total * 4, s)) != MRS_OK) return st;
     if ((st = vals_out.alloc((size_t)total * 4, s)) != MRS_OK) return st;
-    {
-        std::vector<int> init((size_t)h->n_pairs * 6);
-        for (int i = 0; i < h->n_pairs; ++i)
-            for (int a = 0; a < 3; ++a) { init[6 * i + a] = INT32_MAX; init[6 * i + 3 + a] = INT32_MIN; }
-        MRS_HIP_TRY(hipMemcpyAsync(bbox_p, init.data(), init.size() * sizeof(int), hipMemcpyHostToDevice, s));
-        MRS_HIP_TRY(hipStreamSynchronize(s));  // `init`, `tile_base`, h_offsets are temporaries
-    }
+    // (the boxes were armed by prepare_side, in the same host synchronisation as the offsets: one round trip less per cloud)
     const dim3 pg((unsigned)std::min<int64_t>((longest + 255) / 256, 1024), h->n_pairs);
     hipLaunchKernelGGL(k_cloud_bbox, dim3(std::min(pg.x, 64u), pg.y), dim3(256), 0, s, d_points, stride_floats, h->d_offs[which],
                        bbox_p);
@@ -2941,6 +2940,10 @@ int mrs_gicp_batch_align(mrs_gicp_batch* h, const double* h_guess, double* h_fin
     MRS_HIP_TRY(hipSetDevice(h->ctx->device));
     hipStream_t s = (hipStream_t)stream;
     int st;
+    // device-side state first: its (blocking) upload of the per-pair block counts would otherwise wait for the covariance kernels enqueued below
+    // and keep the host from enqueuing the first ticks behind them
+    st = ensure_state(h);
+    if (st != MRS_OK) return st;
     const bool small = h->n_pairs <= kLmWindowPairs;
     // a second stream, two events and a pinned buffer from the context's pool for the duration of this call (small batches only)
     struct Side {
@@ -2962,8 +2965,6 @@ int mrs_gicp_batch_align(mrs_gicp_batch* h, const double* h_guess, double* h_fin
     }
     for (int w = 0; w < 2; ++w)
         if (!h->cov_valid[w]) { st = mrs_gicp_batch_compute_covariances(h, w, nullptr, stream); if (st != MRS_OK) return st; }
-    st = ensure_state(h);
-    if (st != MRS_OK) return st;
     if (h->prm.voxel_res > 0.0) {
         st = build_voxel_map(h, s);
         if (st != MRS_OK) return st;

@@ -22,6 +22,19 @@ def default_params():
     return p
 
 
+_tls = __import__("threading").local()
+
+
+def _staging(points):
+    """thread-local pinned float32 [>= points, 3] staging tensor, grown geometrically"""
+    buf = getattr(_tls, "buf", None)
+    if buf is None or buf.shape[0] < points:
+        cap = max(1 << 16, 1 << int(points - 1).bit_length())
+        buf = torch.empty((cap, 3), dtype=torch.float32).pin_memory()
+        _tls.buf = buf
+    return buf
+
+
 class GicpBatch:
     """n_pairs independent (source, target) registrations advanced together on one GPU."""
 
@@ -61,10 +74,19 @@ class GicpBatch:
             pts, offs = clouds
             offs = np.ascontiguousarray(offs, dtype=np.int64)
         else:
-            arrs = [np.ascontiguousarray(np.asarray(c, dtype=np.float32)[:, :3]) for c in clouds]
-            offs = np.zeros(len(arrs) + 1, np.int64)
-            offs[1:] = np.cumsum([a.shape[0] for a in arrs])
-            pts = torch.from_numpy(np.concatenate(arrs)).to(f"cuda:{self.device}")
+            # host clouds (what the nodes hand over, float64 [n, 3] from pygicp.downsample): converted to float32 straight INTO a pinned staging
+            # buffer (one pass instead of convert + concatenate + a pageable copy) and sent with one asynchronous copy; mrs_gicp_batch_set_clouds
+            # synchronises the stream before it returns, so the buffer (one per thread: the callbacks run concurrently) is free again by then
+            srcs = [np.asarray(c) for c in clouds]
+            offs = np.zeros(len(srcs) + 1, np.int64)
+            offs[1:] = np.cumsum([a.shape[0] for a in srcs])
+            total = int(offs[-1])
+            stage = _staging(total)
+            view = stage.numpy()
+            for a, lo, hi in zip(srcs, offs[:-1], offs[1:]):
+                np.copyto(view[lo:hi], a[:, :3], casting="same_kind")
+            pts = torch.empty((total, 3), dtype=torch.float32, device=f"cuda:{self.device}")
+            pts.copy_(stage[:total], non_blocking=True)
         assert offs.size == self.n_pairs + 1
         pts = pts.contiguous()
         assert pts.is_cuda and pts.dtype == torch.float32
