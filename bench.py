@@ -553,27 +553,35 @@ def sweep_legs(device, spec_pool, n_db=10_000):
         return dict({"pairs_per_s": nq * n_db / ms * 1e3, "ms": ms, "db_entries": n_db, "bytes_per_entry": bytes_per_entry,
                      "db_gbs": n_db * bytes_per_entry / ms / 1e6, "hbm_frac": n_db * bytes_per_entry / ms / 1e6 / HBM_PEAK_GBS}, **kw)
     TILED = 58624                                                      # MRS_RING_TILED_ENTRY_BYTES: what the tiled sweep streams per plane
+    # Protocols.  One query (HBM-bound, what a callback issues is ONE launch): bursts of 3 + 10 launches, as in rounds 3-5 -- a longer burst of this
+    # kernel measures LOWER (30 + 20 launches: 85 instead of 100 M pairs/s on the tiled entries; the row-layout kernel 86 either way).  Several
+    # queries (VALU-bound): the first ~40 launches after host-side gaps run below the steady rate (115 -> 128 -> 137 -> 142 M pairs/s over
+    # consecutive groups of 13 launches at 4 queries, tools/quick_sweep_order.py: the clocks come up), so those legs warm up for 30 launches
+    W1, R1 = 3, 10                                                     # one query
+    WQ, RQ = 30, 20                                                    # several queries, RING
+    W6, R6 = 1, 3                                                      # RING++, one query
+    W6Q, R6Q = 6, 8                                                    # RING++, several queries
     tiled = ring.spec_to_tiled(db)
     q1 = spec_pool[:1].contiguous()
-    out["ring_q1"] = entry(1, ev_ms(lambda: ring.corr_sweep_fft_tiled(q1, tiled), reps=10, warm=3), TILED, layout="dma-tiled (mrs_loopdb)")
-    out["ring_q1_row_layout"] = entry(1, ev_ms(lambda: ring.corr_sweep_fft(q1, db), reps=10, warm=3), 58560)
+    out["ring_q1"] = entry(1, ev_ms(lambda: ring.corr_sweep_fft_tiled(q1, tiled), reps=R1, warm=W1), TILED, layout="dma-tiled (mrs_loopdb)")
+    out["ring_q1_row_layout"] = entry(1, ev_ms(lambda: ring.corr_sweep_fft(q1, db), reps=R1, warm=W1), 58560)
     # several queries per sweep (round 6): the one-query LDS-DMA pipeline per (query, entry), the queries' workgroups grouped per XCD so that
-    # the entry leaves HBM once (profiles/r06_sweep_mq.md); hbm_frac = database bytes streamed ONCE per launch / time
+    # the entry leaves HBM once (profiles/r06_notes.md); hbm_frac = database bytes streamed ONCE per launch / time
     for nq in (4, 8):
         q = spec_pool[:nq].contiguous()
-        out[f"ring_q{nq}"] = entry(nq, ev_ms(lambda: ring.corr_sweep_fft_tiled_q(q, tiled), reps=10, warm=3), TILED, layout="dma-tiled (mrs_loopdb_query_multi)")
+        out[f"ring_q{nq}"] = entry(nq, ev_ms(lambda: ring.corr_sweep_fft_tiled_q(q, tiled), reps=RQ, warm=WQ), TILED, layout="dma-tiled (mrs_loopdb_query_multi)")
     q = spec_pool[:4].contiguous()
-    out["ring_q4_row_layout"] = entry(4, ev_ms(lambda: ring.corr_sweep_fft(q, db), reps=10, warm=3), 58560)
+    out["ring_q4_row_layout"] = entry(4, ev_ms(lambda: ring.corr_sweep_fft(q, db), reps=RQ, warm=WQ), 58560)
     del tiled
     db6 = torch.stack([db.roll(k, 0) for k in range(6)], 1).contiguous()   # RING++: [n_db][6][61][120] = 351 360 B each
     tiled6 = ring.spec_to_tiled(db6)
     q1 = db6[:1].contiguous()
-    out["ringpp_q1"] = entry(1, ev_ms(lambda: ring.corr_sweep_fft_tiled(q1, tiled6), reps=3, warm=1), 6 * TILED, layout="dma-tiled (mrs_loopdb)")
+    out["ringpp_q1"] = entry(1, ev_ms(lambda: ring.corr_sweep_fft_tiled(q1, tiled6), reps=R6, warm=W6), 6 * TILED, layout="dma-tiled (mrs_loopdb)")
     q = db6[:4].contiguous()
-    out["ringpp_q4"] = entry(4, ev_ms(lambda: ring.corr_sweep_fft_tiled_q(q, tiled6), reps=3, warm=1), 6 * TILED, layout="dma-tiled (mrs_loopdb_query_multi)")
+    out["ringpp_q4"] = entry(4, ev_ms(lambda: ring.corr_sweep_fft_tiled_q(q, tiled6), reps=R6Q, warm=W6Q), 6 * TILED, layout="dma-tiled (mrs_loopdb_query_multi)")
     del tiled6
-    out["ringpp_q1_row_layout"] = entry(1, ev_ms(lambda: ring.corr_sweep_fft(q1, db6), reps=3, warm=1), 351360)
-    out["ringpp_q4_row_layout"] = entry(4, ev_ms(lambda: ring.corr_sweep_fft(q, db6), reps=3, warm=1), 351360)
+    out["ringpp_q1_row_layout"] = entry(1, ev_ms(lambda: ring.corr_sweep_fft(q1, db6), reps=R6, warm=W6), 351360)
+    out["ringpp_q4_row_layout"] = entry(4, ev_ms(lambda: ring.corr_sweep_fft(q, db6), reps=R6Q, warm=W6Q), 351360)
     del db6
     # DiSCO (disco_ros/main.py:284-291): nearest 1024-d signature over the database, then ONE phase correlation
     g = torch.Generator(device=device).manual_seed(3)
