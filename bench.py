@@ -1350,7 +1350,7 @@ def result_line(S):
     return line
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -1396,7 +1396,11 @@ def main():
                     "while the descriptor kernel runs), persistent otherwise")
     ap.add_argument("--replica", choices=("f16", "f32"), default="f16", help="--exchange allgather: fp16 replicas (29 280 B, half the bytes) + exact "
                     "owner re-scoring of every candidate within 2e-3 of the acceptance threshold, or the exact fp32 entries themselves (58 560 B, no re-scoring)")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))               # bare `python bench.py --gpus N`: start the N ranks ourselves (one JSON line from rank 0)
